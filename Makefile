@@ -1,0 +1,57 @@
+# Top-level build: everything is built IN-TREE (the .so files travel to the GPU box with
+# gpurun; they are git-ignored).  `python -c "import __graft_entry__ as g; g.build()"` runs this.
+#
+#   spz_amd/lib/libspz_amd.so    HIP kernels + C ABI            (hipcc, gfx950)
+#   spz_amd/lib/libspz_host.so   C++ drop-in layer spz::saveSpz/loadSpz + gzip (g++, zlib)
+#   spz_amd/spz*.so              Python module `spz` (pybind11) over the C++ layer
+#   oracle/liboracle.so, oracle/_ref/libspz_ref.so   CPU checkers (tests only)
+
+ROOT    := $(dir $(abspath $(lastword $(MAKEFILE_LIST))))
+HIPCC   ?= /opt/rocm/bin/hipcc
+CXX     ?= g++
+PYTHON  ?= python3
+ARCH    ?= gfx950
+LIBDIR  := $(ROOT)spz_amd/lib
+CSRC    := $(ROOT)spz_amd/csrc
+INC     := $(ROOT)include
+
+# -ffp-contract=off: bit-exact quantisation needs every a*b+c rounded twice.
+HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math \
+            -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -I$(INC)
+CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -I$(INC)
+
+PYEXT   := $(shell $(PYTHON) -c "import sysconfig; print(sysconfig.get_config_var('EXT_SUFFIX'))")
+PYINC   := $(shell $(PYTHON) -c "import sysconfig, pybind11; print('-I' + sysconfig.get_paths()['include'] + ' -I' + pybind11.get_include())")
+
+all: device host python oracle
+
+device: $(LIBDIR)/libspz_amd.so
+host:   $(LIBDIR)/libspz_host.so
+python: $(ROOT)spz_amd/spz$(PYEXT)
+
+$(LIBDIR)/libspz_amd.so: $(CSRC)/spz_kernels.hip $(INC)/spz_amd.h
+	mkdir -p $(LIBDIR)
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/spz_kernels.hip
+
+$(LIBDIR)/libspz_host.so: $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp $(INC)/spz_amd_host.hpp $(INC)/spz_amd.h $(LIBDIR)/libspz_amd.so
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp -L$(LIBDIR) -lspz_amd -lz \
+	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
+
+$(ROOT)spz_amd/spz$(PYEXT): $(CSRC)/spz_py.cpp $(INC)/spz_amd_host.hpp $(LIBDIR)/libspz_host.so
+	$(CXX) $(CXXFLAGS) $(PYINC) -fvisibility=hidden -shared -o $@ $(CSRC)/spz_py.cpp \
+	    -L$(LIBDIR) -lspz_host -lspz_amd -Wl,-rpath,'$$ORIGIN/lib' -Wl,-rpath,/opt/rocm/lib
+
+oracle:
+	$(MAKE) -C $(ROOT)oracle
+
+# Kernel ISA + resource usage for inspection (not part of `all`).
+asm: $(CSRC)/spz_kernels.hip
+	mkdir -p $(ROOT)build
+	$(HIPCC) $(HIPFLAGS) -S --cuda-device-only -Rpass-analysis=kernel-resource-usage \
+	    -o $(ROOT)build/spz_kernels.s $(CSRC)/spz_kernels.hip
+
+clean:
+	rm -rf $(LIBDIR) $(ROOT)build $(ROOT)spz_amd/spz*.so
+	$(MAKE) -C $(ROOT)oracle clean
+
+.PHONY: all device host python oracle asm clean

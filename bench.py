@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""bench.py — SPZ encode+decode throughput on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path over one batch of synthetic input that is already
+resident in HBM: encode (float SoA -> packed stream, `from` flip fused) followed by decode
+(packed stream -> float SoA, `to` flip fused) of the same cloud.
+
+  N = 1  workload = BASELINE configs[2]+[3]: 10 M synthetic Gaussians, SH degree 3, v3
+         smallest-three rotations, encode from=RDF, decode to=RDF (RDF<->RUB fused).
+  N > 1  weak scaling: every rank owns a 10 M-point shard of an N x 10 M-point stream
+         (configs[4] at N = 8); per step each rank encodes its shard, ONE grouped gatherv
+         (RCCL send/recv) reassembles the byte stream on rank 0, and each rank decodes the
+         fragments it holds (floats stay sharded).  The gatherv overlaps the decode kernels.
+
+Prints ONE JSON line on rank 0 (contract in the task statement), with
+  roofline      : decode kernel, algorithmic bytes / HIP-event kernel time vs 8 TB/s HBM3E
+  cpu_baseline  : the reference's own packGaussians+unpackGaussians (oracle/_ref, kind
+                  "reference") or the C restatement (kind "port") on ONE host core.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+COORD = {"UNSPECIFIED": 0, "LDB": 1, "RDB": 2, "LUB": 3, "RUB": 4, "LDF": 5, "RDF": 6, "LUF": 7, "RUF": 8}
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--points", type=int, default=10_000_000, help="Gaussians per GPU")
+    ap.add_argument("--sh-degree", type=int, default=3)
+    ap.add_argument("--version", type=int, default=3)
+    ap.add_argument("--from-coord", default="RDF")
+    ap.add_argument("--to-coord", default="RDF")
+    ap.add_argument("--no-collective", action="store_true", help="N>1: skip the gatherv (kernels only)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-points", type=int, default=0, help="0 = the whole per-GPU workload")
+    ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
+    return ap.parse_args()
+
+
+def algorithmic_bytes_per_point(sh_degree, version):
+    """float bytes + packed bytes moved per Gaussian per direction."""
+    d = {0: 0, 1: 9, 2: 24, 3: 45}[sh_degree]
+    packed = (20 if version >= 3 else 19) + d
+    return (14 + d) * 4 + packed
+
+
+def cpu_baseline(cloud_t, n, sh_degree, frm, to, sample_points, gpu_stream_fn):
+    """Times the reference C++ (or the C port) on one host core over the same synthetic points and
+    checks that what was timed produced the same bytes as the GPU path."""
+    import numpy as np
+    from oracle.pyoracle import REF_SO, Oracle, Reference
+    from spz_amd.synth import FIELDS, floats_per_point
+
+    m = n if sample_points <= 0 else min(n, sample_points)
+    host = {k: cloud_t[k][: m * floats_per_point(k, sh_degree)].cpu().numpy() for k in FIELDS}
+    gpu_stream = gpu_stream_fn(m)
+    if os.path.exists(REF_SO):
+        kind = "reference"
+        t_pack, t_unpack, stream = Reference().bench_pack_unpack(host, m, sh_degree, frm, to, want_stream=True)
+    else:
+        kind = "port"
+        O = Oracle()
+        t0 = time.perf_counter()
+        stream = O.pack(host, m, sh_degree, False, frm)
+        t1 = time.perf_counter()
+        O.unpack(stream, to)
+        t2 = time.perf_counter()
+        t_pack, t_unpack = t1 - t0, t2 - t1
+    parity = bool(stream.size == gpu_stream.size and np.array_equal(stream, gpu_stream))
+    return {
+        "value": m / (t_pack + t_unpack),
+        "unit": "Gaussians/s",
+        "cores": 1,
+        "kind": kind,
+        "sample": f"{m} of the {n} Gaussians of the N=1 workload (SH{sh_degree}), packGaussians "
+                  f"{t_pack:.2f} s + unpackGaussians {t_unpack:.2f} s, gzip excluded; single-threaded as shipped, "
+                  f"host has {os.cpu_count()} cores",
+        "pack_gaussians_per_s": m / t_pack,
+        "unpack_gaussians_per_s": m / t_unpack,
+        "stream_bit_identical_to_gpu": parity,
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and world == 1:
+        # Launched directly with --gpus N: start the ranks as child processes (never exec after
+        # the GPU may have been initialised) and leave with their exit code.
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+               "--master-addr", "127.0.0.1", "--master-port", os.environ.get("MASTER_PORT", "29533"),
+               os.path.abspath(__file__)] + sys.argv[1:]
+        sys.exit(subprocess.call(cmd))
+
+    import torch
+    import torch.distributed as dist
+
+    from spz_amd import abi, device as D, shard
+    from spz_amd.synth import FIELDS, floats_per_point, make_cloud_torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    distributed = world > 1
+    if distributed:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n, deg, ver = args.points, args.sh_degree, args.version
+    frm, to = COORD[args.from_coord], COORD[args.to_coord]
+    cloud = make_cloud_torch(n, deg, 3 + 47 * rank, dev)           # seeds 3, 50, 97, ... per rank
+    lay = abi.stream_layout(n, deg, ver)
+    stream = torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev)
+    out = D.alloc_cloud(n, deg, dev)
+    hdr = D.make_header(n, deg, ver)
+
+    use_coll = distributed and not args.no_collective
+    plan = shard.plan_from_counts([n] * world, deg, ver) if distributed else None
+    global_stream = None
+    if use_coll and rank == 0:
+        global_stream = torch.empty(plan.layout.total_bytes, dtype=torch.uint8, device=dev)
+        shard.write_global_header(global_stream, plan)
+
+    K, W = args.steps, args.warmup
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
+
+    if use_coll and rank == 0:
+        # the root encodes straight into (and decodes straight from) its slot of the global stream
+        ghdr = D.make_header(plan.num_points, deg, ver)
+        run_encode = lambda: D.encode_shard(cloud, plan.first[0], n, plan.num_points, deg, global_stream,
+                                            from_coord=frm, version=ver, write_header=True)
+        run_decode = lambda: D.decode_shard(global_stream, ghdr, plan.first[0], n, to, out=out)
+    else:
+        run_encode = lambda: D.encode(cloud, n, deg, False, frm, ver, out=stream)
+        run_decode = lambda: D.decode(stream, hdr, to, out=out)
+
+    def step(k, timed):
+        e = ev[k] if timed else None
+        if e: e[0].record()
+        run_encode()
+        if e: e[1].record()
+        works = shard.gather_stream(None if rank == 0 else stream, plan, rank, global_stream, async_op=True) \
+            if use_coll else []
+        if e: e[2].record()
+        run_decode()
+        if e: e[3].record()
+        for w in works:
+            w.wait()
+
+    def fence():
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for k in range(W):
+        step(k, False)
+    fence()
+    t0 = time.perf_counter()
+    for k in range(K):
+        step(k, True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if distributed:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    enc_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / K
+    dec_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / K
+
+    # sanity inside the bench: the stream decodes back to what a re-encode reproduces
+    fixed_point = None
+    if frm == to and not (use_coll and rank == 0):
+        s2 = D.encode(out, n, deg, False, to, ver)
+        torch.cuda.synchronize()
+        fixed_point = bool(torch.equal(s2, stream))
+
+    if rank == 0:
+        bpp = algorithmic_bytes_per_point(deg, ver)
+        total_points = n * world
+        traffic = None
+        if os.path.exists(args.traffic_file):
+            try:
+                with open(args.traffic_file) as f:
+                    tj = json.load(f)
+                if tj.get("points") == n and tj.get("sh_degree") == deg:
+                    traffic = tj.get("decode_hbm_bytes_per_launch")
+            except (OSError, ValueError):
+                traffic = None
+        res = {
+            "metric": "Gaussians/s encode+decode (SH3, 10M pts)",
+            "value": total_points * K / elapsed,
+            "unit": "Gaussians/s",
+            "n_gpus": world,
+            "steps": K,
+            "warmup": W,
+            "ms_per_step": elapsed / K * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {
+                "workload": f"{n} synthetic Gaussians per GPU, SH degree {deg}, v{ver} "
+                            f"({'smallest-three' if ver >= 3 else 'first-three'} rotations), encode from={args.from_coord} "
+                            f"+ decode to={args.to_coord} with the coordinate flips fused, inputs resident in HBM",
+                "points_per_gpu": n, "sh_degree": deg, "version": ver,
+                "parallelism": ("single GPU" if world == 1 else
+                                f"point-range shards x{world}" + (", one grouped RCCL gatherv of the byte stream to "
+                                                                   "rank 0 per step, overlapped with decode"
+                                                                   if use_coll else ", no collective")),
+            },
+            "roofline": {
+                "bound": "hbm", "kernel": "spz_decode_kernel",
+                "achieved": n * bpp / (dec_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": n * bpp / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "traffic": traffic,
+                "algorithmic_bytes_per_launch": n * bpp, "avg_launch_ms": dec_ms,
+            },
+            "roofline_encode": {
+                "bound": "hbm", "kernel": "spz_encode_kernel",
+                "achieved": n * bpp / (enc_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": n * bpp / (enc_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
+                "algorithmic_bytes_per_launch": n * bpp, "avg_launch_ms": enc_ms,
+            },
+            "encode_gaussians_per_s_per_gpu": n / (enc_ms * 1e-3),
+            "decode_gaussians_per_s_per_gpu": n / (dec_ms * 1e-3),
+            "reencode_fixed_point": fixed_point,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            def gpu_stream_fn(m):
+                sub = {k: cloud[k][: m * floats_per_point(k, deg)] for k in FIELDS}
+                s = D.encode(sub, m, deg, False, frm, 3)
+                torch.cuda.synchronize()
+                return s.cpu().numpy()
+            res["cpu_baseline"] = cpu_baseline(cloud, n, deg, frm, to, args.cpu_sample_points, gpu_stream_fn)
+        print(json.dumps(res), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+/*
+ * spz_amd.h — C ABI of the MI355X-native SPZ pack/unpack path (libspz_amd.so).
+ *
+ * This is the drop-in boundary for the hot path of lanxinger/spz: everything a
+ * binding of the reference's packGaussians / unpackGaussians / (de)serialize
+ * step would need, as plain C: pointers, sizes, ints.  No C++ types, no torch
+ * types, no exceptions, no caller-visible allocation.  Citations are to
+ * /root/reference/src/cc (the interface each entry point replaces).
+ *
+ * Byte stream ("raw stream", pre-gzip), little-endian, load-spz.cc:131-139,533-546:
+ *   16-byte header | positions | alphas | colors | scales | rotations | sh
+ * gzip stays on the host (libspz_host.so, include/spz_amd_host.hpp).
+ *
+ * Float side: the six flat float32 arrays of GaussianCloud (splat-types.h:90-115):
+ *   positions[3N] xyz, scales[3N], rotations[4N] xyzw, alphas[N], colors[3N],
+ *   sh[N*shDim*3] laid out [point][coeff][rgb], shDim = 0,3,8,15.
+ *
+ * Memory spaces: *_device entry points take DEVICE pointers valid on the current
+ * HIP device and enqueue on `hip_stream` (a hipStream_t passed as void*, NULL =
+ * default stream) without synchronising.  *_host entry points take HOST pointers,
+ * stage through device memory on `device`, and return when the result is in
+ * host memory.  Every compute entry point fails with SPZ_AMD_ERR_NO_DEVICE when
+ * no HIP device is usable: there is no CPU fallback in this library.
+ *
+ * Alignment: float arrays need 4-byte alignment; stream pointers need none.
+ */
+#ifndef SPZ_AMD_H_
+#define SPZ_AMD_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SPZ_AMD_ABI_VERSION 1
+
+/* Status codes.  The header-validation codes mirror, one for one, the rejection
+ * branches of deserializePackedGaussians (load-spz.cc:553-568,591-594). */
+enum {
+  SPZ_AMD_OK = 0,
+  SPZ_AMD_ERR_INVALID_ARG = -1,     /* NULL pointer, bad degree/version/coord, checkSizes load-spz.cc:106-127 */
+  SPZ_AMD_ERR_HEADER_NOT_FOUND = -2, /* short header or wrong magic, load-spz.cc:553-556 */
+  SPZ_AMD_ERR_VERSION = -3,         /* version outside [1,3], load-spz.cc:557-560 */
+  SPZ_AMD_ERR_TOO_MANY_POINTS = -4, /* numPoints > limit, load-spz.cc:561-564 */
+  SPZ_AMD_ERR_SH_DEGREE = -5,       /* shDegree > 3, load-spz.cc:565-568 */
+  SPZ_AMD_ERR_SHORT_STREAM = -6,    /* "read error", load-spz.cc:591-594 */
+  SPZ_AMD_ERR_CAPACITY = -7,        /* output buffer too small */
+  SPZ_AMD_ERR_NO_DEVICE = -8,       /* no usable HIP device / runtime */
+  SPZ_AMD_ERR_HIP = -9,             /* a HIP call failed (see spz_amd_last_hip_error) */
+  SPZ_AMD_ERR_UNSUPPORTED = -10     /* e.g. encode of version 1 */
+};
+
+/* CoordinateSystem values, splat-types.h:24-34. */
+enum {
+  SPZ_AMD_UNSPECIFIED = 0, SPZ_AMD_LDB = 1, SPZ_AMD_RDB = 2, SPZ_AMD_LUB = 3, SPZ_AMD_RUB = 4,
+  SPZ_AMD_LDF = 5, SPZ_AMD_RDF = 6, SPZ_AMD_LUF = 7, SPZ_AMD_RUF = 8
+};
+
+/* Reader limit of the reference, load-spz.cc:549. */
+#define SPZ_AMD_REFERENCE_MAX_POINTS 10000000u
+
+/* PackedGaussiansHeader minus the magic, load-spz.cc:131-139. */
+typedef struct {
+  uint32_t version;        /* 1, 2 or 3 */
+  uint32_t num_points;
+  uint8_t sh_degree;       /* 0..3 */
+  uint8_t fractional_bits; /* writer: 12, load-spz.cc:270 */
+  uint8_t flags;           /* bit0 = antialiased, load-spz.cc:129 */
+  uint8_t reserved;
+} spz_amd_header;
+
+/* Section order of the stream, load-spz.cc:540-545. */
+enum { SPZ_AMD_SEC_POSITIONS = 0, SPZ_AMD_SEC_ALPHAS, SPZ_AMD_SEC_COLORS, SPZ_AMD_SEC_SCALES,
+       SPZ_AMD_SEC_ROTATIONS, SPZ_AMD_SEC_SH, SPZ_AMD_NUM_SECTIONS };
+
+typedef struct {
+  uint64_t total_bytes;                      /* 16 + sum(bytes) */
+  uint64_t offset[SPZ_AMD_NUM_SECTIONS];     /* byte offset of each section from stream start */
+  uint64_t bytes[SPZ_AMD_NUM_SECTIONS];      /* byte length of each section */
+  uint32_t bytes_per_point[SPZ_AMD_NUM_SECTIONS];
+} spz_amd_layout;
+
+/* GaussianCloud's arrays (splat-types.h:101-115) as raw pointers. sh may be NULL iff sh_degree==0. */
+typedef struct {
+  const float *positions, *scales, *rotations, *alphas, *colors, *sh;
+} spz_amd_cloud_in;
+typedef struct {
+  float *positions, *scales, *rotations, *alphas, *colors, *sh;
+} spz_amd_cloud_out;
+
+/* ---- introspection ---------------------------------------------------------------------- */
+int spz_amd_abi_version(void);
+const char *spz_amd_status_string(int status);
+/* Number of usable HIP devices (0 when there is none or the runtime fails to initialise). */
+int spz_amd_device_count(void);
+/* hipError_t value of the last failing HIP call on this thread (0 if none). */
+int spz_amd_last_hip_error(void);
+
+/* ---- stream geometry: replaces the size arithmetic spread over packGaussians
+ *      (load-spz.cc:273-278), serializePackedGaussians (:540-545) and
+ *      deserializePackedGaussians (:578-590).  Pure host function. ------------------------ */
+int spz_amd_stream_layout(uint64_t num_points, int sh_degree, int version, spz_amd_layout *out);
+
+/* ---- header: PackedGaussiansHeader write (load-spz.cc:534-539) / checks (:551-568).
+ *      Pure host functions on HOST memory.  spz_amd_peek_header applies the reference's
+ *      10 M point limit; the _ex form takes the limit (0 = none) for shards that are
+ *      reassembled into a stream larger than the reference itself can read. --------------- */
+int spz_amd_write_header(const spz_amd_header *hdr, uint8_t out16[16]);
+int spz_amd_peek_header(const uint8_t *stream, size_t size, spz_amd_header *out);
+int spz_amd_peek_header_ex(const uint8_t *stream, size_t size, uint64_t max_points, spz_amd_header *out);
+
+/* ---- encode: packGaussians (load-spz.cc:257-331) + serializePackedGaussians (:533-546)
+ *      fused: float SoA -> header + six sections written in place.
+ *      version: 3 (what the reference writes, :272) or 2 (first-three quaternions; the
+ *      reference has no v2 encoder, parity unpinned).  from_coord: PackOptions::from. -------- */
+int spz_amd_encode_device(const spz_amd_cloud_in *d_cloud, uint64_t num_points, int sh_degree,
+                          int antialiased, int from_coord, int version, uint8_t *d_stream,
+                          size_t capacity, void *hip_stream);
+
+/* ---- decode: the body of deserializePackedGaussians (section slicing, :569-590) +
+ *      unpackGaussians (:467-531) with the trailing convertCoordinates(RUB, to)
+ *      pass (:529, splat-types.h:134-164) fused into the same kernel.
+ *      `hdr` is the header the caller obtained from spz_amd_peek_header (the first 16
+ *      bytes of d_stream are not re-read).  to_coord: UnpackOptions::to. -------------------- */
+int spz_amd_decode_device(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr,
+                          int to_coord, const spz_amd_cloud_out *d_cloud, void *hip_stream);
+
+/* ---- point-range shards (multi-GPU / multi-stream).  The stream is attribute-major, so a
+ *      shard [first, first+count) of a num_points-total stream is six fragments at
+ *      offset[s] + first*bytes_per_point[s].  d_cloud holds only the shard's points.
+ *      encode_shard writes the fragments (and the header iff write_header != 0) into the
+ *      FULL stream buffer d_stream; decode_shard reads them from it. ------------------------ */
+int spz_amd_encode_shard_device(const spz_amd_cloud_in *d_cloud, uint64_t first, uint64_t count,
+                                uint64_t num_points_total, int sh_degree, int antialiased,
+                                int from_coord, int version, int write_header, uint8_t *d_stream,
+                                size_t capacity, void *hip_stream);
+int spz_amd_decode_shard_device(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr,
+                                uint64_t first, uint64_t count, int to_coord,
+                                const spz_amd_cloud_out *d_cloud, void *hip_stream);
+
+/* ---- GaussianCloud::convertCoordinates (splat-types.h:134-164) as a standalone in-place
+ *      device pass (the reference-shaped, un-fused second pass; kept for API parity and
+ *      for the fused-vs-unfused measurement).  Any of the three pointers may be NULL. ------- */
+int spz_amd_convert_coordinates_device(float *d_positions, float *d_rotations, float *d_sh,
+                                       uint64_t num_points, int sh_degree, int from_coord,
+                                       int to_coord, void *hip_stream);
+
+/* ---- host-pointer conveniences: H2D, kernel, D2H on `device`; blocking. ------------------ */
+int spz_amd_encode_host(const spz_amd_cloud_in *h_cloud, uint64_t num_points, int sh_degree,
+                        int antialiased, int from_coord, int version, uint8_t *h_stream,
+                        size_t capacity, int device);
+int spz_amd_decode_host(const uint8_t *h_stream, size_t size, int to_coord,
+                        const spz_amd_cloud_out *h_cloud, int device);
+int spz_amd_convert_coordinates_host(float *h_positions, float *h_rotations, float *h_sh,
+                                     uint64_t num_points, int sh_degree, int from_coord,
+                                     int to_coord, int device);
+
+/* ---- tables.  The alpha / colour decode tables (invSigmoid(b/255) load-spz.cc:87,518;
+ *      ((b/255)-0.5)/0.15 :522) and the 255 alpha-encode thresholds (smallest float whose
+ *      toUint8(sigmoid(a)*255) (:85,301) is >= v) are computed once on the host with the
+ *      reference's own expressions and libm, then kept in device memory.  This accessor
+ *      returns the host copies (for tests); any pointer may be NULL. ------------------------ */
+int spz_amd_get_tables(float alpha_decode[256], float color_decode[256], float alpha_thresholds[255]);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SPZ_AMD_H_ */

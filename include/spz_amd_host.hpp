@@ -1,0 +1,125 @@
+// spz_amd_host.hpp — C++ drop-in layer over the C ABI (include/spz_amd.h).
+//
+// Keeps the public C++ surface of lanxinger/spz for the save/load path so that
+// code written against the reference compiles against this header unchanged:
+//   namespace spz, GaussianCloud / PackedGaussians / PackOptions / UnpackOptions /
+//   CoordinateSystem (reference: src/cc/splat-types.h:24-34,90-186, src/cc/load-spz.h:42-67),
+//   saveSpz / loadSpz / loadSpzPacked / serializePackedGaussians / compressGzipped
+//   (reference: src/cc/load-spz.h:69-100) with the same argument meaning, ownership
+//   (everything by value / caller-owned vectors) and error behaviour (never throws; save ->
+//   false, load -> default-constructed cloud plus one "[SPZ ERROR] ..." line on stdout).
+//
+// The per-Gaussian quantise / dequantise work runs on the GPU through libspz_amd.so; gzip
+// stays on the host (zlib, same deflate parameters as load-spz.cc:186-214, so the .spz bytes
+// are identical).  There is no CPU fallback: without a usable HIP device saveSpz returns
+// false and loadSpz returns an empty cloud, each after logging
+// "[SPZ ERROR] spz_amd: <status>".  The device used is $SPZ_AMD_DEVICE (default 0).
+#pragma once
+
+#include <array>
+#include <cstdint>
+#include <iosfwd>
+#include <string>
+#include <vector>
+
+namespace spz {
+
+// splat-types.h:24-34
+enum class CoordinateSystem {
+  UNSPECIFIED = 0,
+  LDB = 1,
+  RDB = 2,
+  LUB = 3,
+  RUB = 4,
+  LDF = 5,
+  RDF = 6,
+  LUF = 7,
+  RUF = 8,
+};
+
+// splat-types.h:36-41: the three sign tables of a conversion.
+struct CoordinateConverter {
+  std::array<float, 3> flipP = {1.0f, 1.0f, 1.0f};
+  std::array<float, 3> flipQ = {1.0f, 1.0f, 1.0f};
+  std::array<float, 15> flipSh = {1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f,
+                                  1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f, 1.0f};
+};
+
+// splat-types.h:43-81
+CoordinateConverter coordinateConverter(CoordinateSystem from, CoordinateSystem to);
+
+// splat-types.h:90-186.  Same field names and layout semantics as the reference struct.
+struct GaussianCloud {
+  int32_t numPoints = 0;
+  int32_t shDegree = 0;
+  bool antialiased = false;
+  std::vector<float> positions;  // xyz
+  std::vector<float> scales;     // log scale xyz
+  std::vector<float> rotations;  // xyzw
+  std::vector<float> alphas;     // pre-sigmoid
+  std::vector<float> colors;     // SH DC rgb
+  std::vector<float> sh;         // [point][coeff][rgb]
+
+  // In-place flip between coordinate systems (splat-types.h:134-164); runs the GPU flip pass.
+  void convertCoordinates(CoordinateSystem from, CoordinateSystem to);
+  void rotate180DegAboutX() { convertCoordinates(CoordinateSystem::RUB, CoordinateSystem::RDF); }
+  // splat-types.h:170-185 (host utility, not on the hot path).
+  float medianVolume() const;
+};
+
+// load-spz.h:42-59.  at()/unpack(i) random access is out of scope.
+struct PackedGaussians {
+  int32_t numPoints = 0;
+  int32_t shDegree = 0;
+  int32_t fractionalBits = 0;
+  bool antialiased = false;
+  bool usesQuaternionSmallestThree = true;
+  std::vector<uint8_t> positions;
+  std::vector<uint8_t> scales;
+  std::vector<uint8_t> rotations;
+  std::vector<uint8_t> alphas;
+  std::vector<uint8_t> colors;
+  std::vector<uint8_t> sh;
+
+  bool usesFloat16() const;  // load-spz.cc:465
+};
+
+// load-spz.h:61-67
+struct PackOptions {
+  CoordinateSystem from = CoordinateSystem::UNSPECIFIED;
+};
+struct UnpackOptions {
+  CoordinateSystem to = CoordinateSystem::UNSPECIFIED;
+};
+
+// load-spz.h:69-100 -------------------------------------------------------------------------
+bool saveSpz(const GaussianCloud &gaussians, const PackOptions &options, std::vector<uint8_t> *output);
+bool saveSpz(const GaussianCloud &gaussians, const PackOptions &options, const std::string &filename);
+GaussianCloud loadSpz(const std::vector<uint8_t> &data, const UnpackOptions &options);
+GaussianCloud loadSpz(const uint8_t *data, int32_t size, const UnpackOptions &options);
+GaussianCloud loadSpz(const std::string &filename, const UnpackOptions &options);
+PackedGaussians loadSpzPacked(const std::string &filename);
+PackedGaussians loadSpzPacked(const uint8_t *data, int32_t size);
+PackedGaussians loadSpzPacked(const std::vector<uint8_t> &data);
+// .ply pair (load-spz.cc:691-934): binary little-endian 3DGS layout, RDF on disk.
+bool saveSplatToPly(const GaussianCloud &gaussians, const PackOptions &options, const std::string &filename);
+GaussianCloud loadSplatFromPly(const std::string &filename, const UnpackOptions &options);
+void serializePackedGaussians(const PackedGaussians &packed, std::ostream *out);
+bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out);
+
+// External-linkage internals of the reference (load-spz.cc:257,467,548), kept because
+// downstream code forward-declares them to skip gzip.
+PackedGaussians packGaussians(const GaussianCloud &g, const PackOptions &o);
+GaussianCloud unpackGaussians(const PackedGaussians &packed, const UnpackOptions &o);
+PackedGaussians deserializePackedGaussians(std::istream &in);
+
+// Extras of this implementation -------------------------------------------------------------
+// Inverse of compressGzipped (the reference keeps it file-local, load-spz.cc:141-182).
+bool decompressGzipped(const uint8_t *compressed, size_t size, std::vector<uint8_t> *out);
+// Raw (pre-gzip) stream <-> cloud, i.e. saveSpz / loadSpz without the zlib step.
+bool packToStream(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream);
+GaussianCloud unpackFromStream(const uint8_t *stream, size_t size, const UnpackOptions &o);
+// Status (spz_amd.h codes) of the last device call made by this thread; 0 = ok.
+int lastDeviceStatus();
+
+}  // namespace spz

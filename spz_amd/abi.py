@@ -1,0 +1,157 @@
+"""ctypes binding of the C ABI (include/spz_amd.h, spz_amd/lib/libspz_amd.so).
+
+This is the same boundary a cgo / JNI / N-API binding would use: plain pointers and sizes.
+PyTorch only supplies device memory and streams to it (``tensor.data_ptr()``,
+``torch.cuda.current_stream().cuda_stream``).  There is no CPU fallback: if the shared
+library is missing or no HIP device is usable, calls raise.
+"""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libspz_amd.so")
+
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_HEADER_NOT_FOUND = -2
+ERR_VERSION = -3
+ERR_TOO_MANY_POINTS = -4
+ERR_SH_DEGREE = -5
+ERR_SHORT_STREAM = -6
+ERR_CAPACITY = -7
+ERR_NO_DEVICE = -8
+ERR_HIP = -9
+ERR_UNSUPPORTED = -10
+
+UNSPECIFIED, LDB, RDB, LUB, RUB, LDF, RDF, LUF, RUF = range(9)
+NUM_SECTIONS = 6
+SEC_POSITIONS, SEC_ALPHAS, SEC_COLORS, SEC_SCALES, SEC_ROTATIONS, SEC_SH = range(6)
+REFERENCE_MAX_POINTS = 10_000_000
+
+# Every symbol include/spz_amd.h declares (tests check the library exports all of them).
+EXPORTS = (
+    "spz_amd_abi_version", "spz_amd_status_string", "spz_amd_device_count", "spz_amd_last_hip_error",
+    "spz_amd_stream_layout", "spz_amd_write_header", "spz_amd_peek_header", "spz_amd_peek_header_ex",
+    "spz_amd_encode_device", "spz_amd_decode_device", "spz_amd_encode_shard_device",
+    "spz_amd_decode_shard_device", "spz_amd_convert_coordinates_device", "spz_amd_encode_host",
+    "spz_amd_decode_host", "spz_amd_convert_coordinates_host", "spz_amd_get_tables",
+)
+
+
+class Header(C.Structure):
+    _fields_ = [("version", C.c_uint32), ("num_points", C.c_uint32), ("sh_degree", C.c_uint8),
+                ("fractional_bits", C.c_uint8), ("flags", C.c_uint8), ("reserved", C.c_uint8)]
+
+    @property
+    def antialiased(self):
+        return bool(self.flags & 1)
+
+
+class Layout(C.Structure):
+    _fields_ = [("total_bytes", C.c_uint64), ("offset", C.c_uint64 * NUM_SECTIONS),
+                ("bytes", C.c_uint64 * NUM_SECTIONS), ("bytes_per_point", C.c_uint32 * NUM_SECTIONS)]
+
+
+class CloudPtrs(C.Structure):
+    """spz_amd_cloud_in / spz_amd_cloud_out (same layout: six pointers)."""
+    _fields_ = [(k, C.c_void_p) for k in ("positions", "scales", "rotations", "alphas", "colors", "sh")]
+
+
+class SpzAmdError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        super().__init__(f"{where}: {status_string(status)} (status {status})")
+
+
+_lib = None
+
+
+def load_library():
+    """Load libspz_amd.so.  torch is imported first (when available) so that the HIP runtime
+    torch ships is the one both share (same SONAME libamdhip64.so.7)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} not found: build it with `make` (or __graft_entry__.build()); "
+                           "spz_amd has no CPU fallback")
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, u64, i32, sz = C.c_void_p, C.c_uint64, C.c_int, C.c_size_t
+    L.spz_amd_abi_version.restype = i32
+    L.spz_amd_status_string.restype = C.c_char_p
+    L.spz_amd_status_string.argtypes = [i32]
+    L.spz_amd_device_count.restype = i32
+    L.spz_amd_last_hip_error.restype = i32
+    L.spz_amd_stream_layout.restype = i32
+    L.spz_amd_stream_layout.argtypes = [u64, i32, i32, C.POINTER(Layout)]
+    L.spz_amd_write_header.restype = i32
+    L.spz_amd_write_header.argtypes = [C.POINTER(Header), vp]
+    L.spz_amd_peek_header.restype = i32
+    L.spz_amd_peek_header.argtypes = [vp, sz, C.POINTER(Header)]
+    L.spz_amd_peek_header_ex.restype = i32
+    L.spz_amd_peek_header_ex.argtypes = [vp, sz, u64, C.POINTER(Header)]
+    L.spz_amd_encode_device.restype = i32
+    L.spz_amd_encode_device.argtypes = [C.POINTER(CloudPtrs), u64, i32, i32, i32, i32, vp, sz, vp]
+    L.spz_amd_decode_device.restype = i32
+    L.spz_amd_decode_device.argtypes = [vp, sz, C.POINTER(Header), i32, C.POINTER(CloudPtrs), vp]
+    L.spz_amd_encode_shard_device.restype = i32
+    L.spz_amd_encode_shard_device.argtypes = [C.POINTER(CloudPtrs), u64, u64, u64, i32, i32, i32, i32, i32, vp, sz, vp]
+    L.spz_amd_decode_shard_device.restype = i32
+    L.spz_amd_decode_shard_device.argtypes = [vp, sz, C.POINTER(Header), u64, u64, i32, C.POINTER(CloudPtrs), vp]
+    L.spz_amd_convert_coordinates_device.restype = i32
+    L.spz_amd_convert_coordinates_device.argtypes = [vp, vp, vp, u64, i32, i32, i32, vp]
+    L.spz_amd_encode_host.restype = i32
+    L.spz_amd_encode_host.argtypes = [C.POINTER(CloudPtrs), u64, i32, i32, i32, i32, vp, sz, i32]
+    L.spz_amd_decode_host.restype = i32
+    L.spz_amd_decode_host.argtypes = [vp, sz, i32, C.POINTER(CloudPtrs), i32]
+    L.spz_amd_convert_coordinates_host.restype = i32
+    L.spz_amd_convert_coordinates_host.argtypes = [vp, vp, vp, u64, i32, i32, i32, i32]
+    L.spz_amd_get_tables.restype = i32
+    L.spz_amd_get_tables.argtypes = [vp, vp, vp]
+    _lib = L
+    return L
+
+
+def status_string(status):
+    return load_library().spz_amd_status_string(int(status)).decode()
+
+
+def check(status, where):
+    if status != OK:
+        raise SpzAmdError(status, where)
+
+
+def stream_layout(num_points, sh_degree, version=3):
+    lay = Layout()
+    check(load_library().spz_amd_stream_layout(int(num_points), int(sh_degree), int(version), C.byref(lay)),
+          "spz_amd_stream_layout")
+    return lay
+
+
+def write_header(version, num_points, sh_degree, fractional_bits=12, antialiased=False):
+    h = Header(int(version), int(num_points), int(sh_degree), int(fractional_bits), 1 if antialiased else 0, 0)
+    out = (C.c_uint8 * 16)()
+    check(load_library().spz_amd_write_header(C.byref(h), out), "spz_amd_write_header")
+    return bytes(out)
+
+
+def peek_header(stream_bytes, max_points=REFERENCE_MAX_POINTS):
+    """stream_bytes: bytes-like HOST data (at least the header; the full stream for the size check).
+    Returns (status, Header or None)."""
+    buf = (C.c_uint8 * len(stream_bytes)).from_buffer_copy(stream_bytes) if len(stream_bytes) else None
+    h = Header()
+    rc = load_library().spz_amd_peek_header_ex(buf, len(stream_bytes), int(max_points), C.byref(h))
+    return rc, (h if rc == OK else None)
+
+
+def get_tables():
+    import numpy as np
+    a = np.zeros(256, np.float32)
+    c = np.zeros(256, np.float32)
+    t = np.zeros(255, np.float32)
+    check(load_library().spz_amd_get_tables(a.ctypes.data, c.ctypes.data, t.ctypes.data), "spz_amd_get_tables")
+    return a, c, t

@@ -1,0 +1,492 @@
+// spz_host.cpp — C++ drop-in layer (namespace spz) over the C ABI of libspz_amd.so.
+//
+// Host-side mirror of the reference's save/load plumbing (/root/reference/src/cc/load-spz.cc
+// :141-214 gzip, :533-596 (de)serialise, :598-668 saveSpz/loadSpz overloads), re-plumbed so
+// that the per-Gaussian work goes through spz_amd_encode_host / spz_amd_decode_host and the
+// stream is written/read in place (no stringstream double copy).
+#include "spz_amd_host.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <istream>
+#include <ostream>
+
+#include "spz_amd.h"
+
+namespace spz {
+namespace {
+
+thread_local int g_last_status = SPZ_AMD_OK;
+
+// SpzLog, load-spz.cc:29-35: printf to stdout + newline + flush.
+void logLine(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  std::vprintf(fmt, ap);
+  va_end(ap);
+  std::printf("\n");
+  std::fflush(stdout);
+}
+
+int deviceIndex() {
+  const char *e = std::getenv("SPZ_AMD_DEVICE");
+  return e ? std::atoi(e) : 0;
+}
+
+int dimForDegree(int degree) {  // load-spz.cc:58-72
+  switch (degree) {
+    case 0: return 0;
+    case 1: return 3;
+    case 2: return 8;
+    case 3: return 15;
+    default:
+      logLine("[SPZ: ERROR] Unsupported SH degree: %d\n", degree);
+      return 0;
+  }
+}
+
+#define SPZ_CHECK(x)                                             \
+  if (!(x)) {                                                    \
+    logLine("[SPZ: ERROR] Check failed: %s:%d: %s", __FILE__, __LINE__, #x); \
+    return false;                                                \
+  }
+
+// checkSizes(const GaussianCloud&), load-spz.cc:106-117
+bool checkSizes(const GaussianCloud &g) {
+  SPZ_CHECK(g.numPoints >= 0);
+  SPZ_CHECK(g.shDegree >= 0);
+  SPZ_CHECK(g.shDegree <= 3);
+  const size_t n = static_cast<size_t>(g.numPoints);
+  SPZ_CHECK(g.positions.size() == n * 3);
+  SPZ_CHECK(g.scales.size() == n * 3);
+  SPZ_CHECK(g.rotations.size() == n * 4);
+  SPZ_CHECK(g.alphas.size() == n);
+  SPZ_CHECK(g.colors.size() == n * 3);
+  SPZ_CHECK(g.sh.size() == n * dimForDegree(g.shDegree) * 3);
+  return true;
+}
+
+// checkSizes(const PackedGaussians&, ...), load-spz.cc:119-127
+bool checkSizes(const PackedGaussians &p, int32_t numPoints, int32_t shDim, bool usesFloat16) {
+  const size_t n = static_cast<size_t>(numPoints);
+  SPZ_CHECK(p.positions.size() == n * 3 * (usesFloat16 ? 2 : 3));
+  SPZ_CHECK(p.scales.size() == n * 3);
+  SPZ_CHECK(p.rotations.size() == n * (p.usesQuaternionSmallestThree ? 4 : 3));
+  SPZ_CHECK(p.alphas.size() == n);
+  SPZ_CHECK(p.colors.size() == n * 3);
+  SPZ_CHECK(p.sh.size() == n * shDim * 3);
+  return true;
+}
+
+bool deviceFailed(int rc, const char *what) {
+  g_last_status = rc;
+  if (rc == SPZ_AMD_OK) return false;
+  logLine("[SPZ ERROR] spz_amd: %s: %s", what, spz_amd_status_string(rc));
+  return true;
+}
+
+// Header checks of deserializePackedGaussians (load-spz.cc:551-568,591-594) with its log lines.
+bool peekHeaderLogged(const uint8_t *stream, size_t size, spz_amd_header *hdr) {
+  const int rc = spz_amd_peek_header(stream, size, hdr);
+  switch (rc) {
+    case SPZ_AMD_OK: return true;
+    case SPZ_AMD_ERR_HEADER_NOT_FOUND:
+      logLine("[SPZ ERROR] deserializePackedGaussians: header not found");
+      break;
+    case SPZ_AMD_ERR_VERSION: {
+      uint32_t v = 0;
+      std::memcpy(&v, stream + 4, 4);
+      logLine("[SPZ ERROR] deserializePackedGaussians: version not supported: %d", v);
+      break;
+    }
+    case SPZ_AMD_ERR_TOO_MANY_POINTS: {
+      uint32_t n = 0;
+      std::memcpy(&n, stream + 8, 4);
+      logLine("[SPZ ERROR] deserializePackedGaussians: Too many points: %d", n);
+      break;
+    }
+    case SPZ_AMD_ERR_SH_DEGREE:
+      logLine("[SPZ ERROR] deserializePackedGaussians: Unsupported SH degree: %d", stream[12]);
+      break;
+    case SPZ_AMD_ERR_SHORT_STREAM:
+      logLine("[SPZ ERROR] deserializePackedGaussians: read error");
+      break;
+    default:
+      logLine("[SPZ ERROR] deserializePackedGaussians: %s", spz_amd_status_string(rc));
+      break;
+  }
+  return false;
+}
+
+bool readFile(const std::string &filename, std::vector<uint8_t> *data, bool log) {
+  std::ifstream in(filename, std::ios::binary | std::ios::ate);
+  if (!in.good()) {
+    if (log) logLine("[SPZ ERROR] Unable to open: %s", filename.c_str());
+    return false;
+  }
+  data->resize(static_cast<size_t>(in.tellg()));
+  in.seekg(0, std::ios::beg);
+  in.read(reinterpret_cast<char *>(data->data()), static_cast<std::streamsize>(data->size()));
+  if (!in.good()) {
+    if (log) logLine("[SPZ ERROR] Unable to load data from: %s", filename.c_str());
+    return false;
+  }
+  return true;
+}
+
+}  // namespace
+
+int lastDeviceStatus() { return g_last_status; }
+
+// ---- splat-types.h:43-81 ---------------------------------------------------------------------
+CoordinateConverter coordinateConverter(CoordinateSystem from, CoordinateSystem to) {
+  const int a = static_cast<int>(from) - 1, b = static_cast<int>(to) - 1;
+  bool mx = true, my = true, mz = true;
+  if (a >= 0 && b >= 0) {
+    mx = ((a >> 0) & 1) == ((b >> 0) & 1);
+    my = ((a >> 1) & 1) == ((b >> 1) & 1);
+    mz = ((a >> 2) & 1) == ((b >> 2) & 1);
+  }
+  const float x = mx ? 1.0f : -1.0f, y = my ? 1.0f : -1.0f, z = mz ? 1.0f : -1.0f;
+  CoordinateConverter c;
+  c.flipP = {x, y, z};
+  c.flipQ = {y * z, x * z, x * y};
+  c.flipSh = {y, z, x, x * y, y * z, 1.0f, x * z, 1.0f, y, x * y * z, y, z, x, z, x};
+  return c;
+}
+
+// ---- GaussianCloud methods ---------------------------------------------------------------------
+void GaussianCloud::convertCoordinates(CoordinateSystem from, CoordinateSystem to) {
+  g_last_status = SPZ_AMD_OK;
+  if (numPoints == 0) return;  // splat-types.h:135-138
+  // The reference derives the per-point sh count from the array sizes (splat-types.h:151-152).
+  const size_t coeffs = sh.size() / 3 / static_cast<size_t>(numPoints);
+  int degree = -1;
+  for (int d = 0; d <= 3; ++d) {
+    if (static_cast<size_t>(dimForDegree(d)) == coeffs) degree = d;
+  }
+  if (degree < 0) {
+    logLine("[SPZ ERROR] spz_amd: convertCoordinates: unsupported sh size %zu for %d points", sh.size(),
+            numPoints);
+    return;
+  }
+  const int f = static_cast<int>(from), t = static_cast<int>(to), dev = deviceIndex();
+  const size_t n = static_cast<size_t>(numPoints);
+  if (positions.size() == n * 3 && rotations.size() == n * 4 && sh.size() == n * coeffs * 3) {
+    deviceFailed(spz_amd_convert_coordinates_host(positions.empty() ? nullptr : positions.data(),
+                                                  rotations.empty() ? nullptr : rotations.data(),
+                                                  sh.empty() ? nullptr : sh.data(), n, degree, f, t, dev),
+                 "convertCoordinates");
+    return;
+  }
+  // Inconsistent sizes: each array is walked over its own length, like the reference loops.
+  if (positions.size() >= 3) {
+    deviceFailed(spz_amd_convert_coordinates_host(positions.data(), nullptr, nullptr, positions.size() / 3, 0, f,
+                                                  t, dev), "convertCoordinates");
+  }
+  if (rotations.size() >= 4) {
+    deviceFailed(spz_amd_convert_coordinates_host(nullptr, rotations.data(), nullptr, rotations.size() / 4, 0, f,
+                                                  t, dev), "convertCoordinates");
+  }
+  if (coeffs > 0) {
+    deviceFailed(spz_amd_convert_coordinates_host(nullptr, nullptr, sh.data(), n, degree, f, t, dev),
+                 "convertCoordinates");
+  }
+}
+
+float GaussianCloud::medianVolume() const {  // splat-types.h:170-185
+  if (numPoints == 0) return 0.01f;
+  std::vector<float> sums;
+  sums.reserve(scales.size() / 3);
+  for (size_t i = 0; i + 2 < scales.size(); i += 3) sums.push_back(scales[i] + scales[i + 1] + scales[i + 2]);
+  if (sums.empty()) return 0.01f;
+  std::sort(sums.begin(), sums.end());
+  const float median = sums[sums.size() / 2];
+  return static_cast<float>((M_PI * 4 / 3) * std::exp(median));
+}
+
+bool PackedGaussians::usesFloat16() const {  // load-spz.cc:465
+  return positions.size() == static_cast<size_t>(numPoints) * 3 * 2;
+}
+
+// ---- gzip, load-spz.cc:141-214 -------------------------------------------------------------------
+bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out) {
+  z_stream stream = {};
+  // Same parameters as load-spz.cc:190: default level, gzip wrapper, memLevel 9.
+  if (deflateInit2(&stream, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 9, Z_DEFAULT_STRATEGY) != Z_OK) {
+    return false;
+  }
+  out->clear();
+  std::vector<uint8_t> buffer(1u << 20);
+  const uint8_t *next = data;
+  size_t left = size;
+  bool success = false;
+  while (true) {
+    // deflate output does not depend on how the input is chunked; feed at most 1 GiB per call.
+    const size_t chunk = std::min<size_t>(left, size_t(1) << 30);
+    stream.next_in = const_cast<Bytef *>(reinterpret_cast<const Bytef *>(next));
+    stream.avail_in = static_cast<uInt>(chunk);
+    next += chunk;
+    left -= chunk;
+    const int flush = (left == 0) ? Z_FINISH : Z_NO_FLUSH;
+    int res = Z_OK;
+    do {
+      stream.next_out = buffer.data();
+      stream.avail_out = static_cast<uInt>(buffer.size());
+      res = deflate(&stream, flush);
+      if (res != Z_OK && res != Z_STREAM_END && res != Z_BUF_ERROR) break;
+      out->insert(out->end(), buffer.data(), buffer.data() + (buffer.size() - stream.avail_out));
+    } while (stream.avail_out == 0 || (flush == Z_FINISH && res != Z_STREAM_END));
+    if (res == Z_STREAM_END) {
+      success = true;
+      break;
+    }
+    if ((res != Z_OK && res != Z_BUF_ERROR) || left == 0) break;
+  }
+  deflateEnd(&stream);
+  return success;
+}
+
+bool decompressGzipped(const uint8_t *compressed, size_t size, std::vector<uint8_t> *out) {
+  z_stream stream = {};
+  // 16 | MAX_WBITS: gzip wrapper only (load-spz.cc:172).
+  if (inflateInit2(&stream, 16 | MAX_WBITS) != Z_OK) return false;
+  out->clear();
+  std::vector<uint8_t> buffer(1u << 20);
+  const uint8_t *next = compressed;
+  size_t left = size;
+  bool success = false;
+  int res = Z_OK;
+  while (res != Z_STREAM_END) {
+    if (stream.avail_in == 0) {
+      const size_t chunk = std::min<size_t>(left, size_t(1) << 30);
+      stream.next_in = const_cast<Bytef *>(next);
+      stream.avail_in = static_cast<uInt>(chunk);
+      next += chunk;
+      left -= chunk;
+    }
+    stream.next_out = buffer.data();
+    stream.avail_out = static_cast<uInt>(buffer.size());
+    res = inflate(&stream, Z_NO_FLUSH);
+    if (res != Z_OK && res != Z_STREAM_END) break;  // incl. Z_BUF_ERROR on truncated input
+    out->insert(out->end(), buffer.data(), buffer.data() + (buffer.size() - stream.avail_out));
+    if (res == Z_STREAM_END) success = true;
+  }
+  inflateEnd(&stream);
+  return success;
+}
+
+// ---- (de)serialise, load-spz.cc:533-596 ----------------------------------------------------------
+void serializePackedGaussians(const PackedGaussians &packed, std::ostream *out) {
+  spz_amd_header h = {};
+  h.version = 3;  // the reference writer never sets another version (load-spz.cc:133,534-539)
+  h.num_points = static_cast<uint32_t>(packed.numPoints);
+  h.sh_degree = static_cast<uint8_t>(packed.shDegree);
+  h.fractional_bits = static_cast<uint8_t>(packed.fractionalBits);
+  h.flags = static_cast<uint8_t>(packed.antialiased ? 1 : 0);
+  uint8_t raw[16];
+  spz_amd_write_header(&h, raw);
+  out->write(reinterpret_cast<const char *>(raw), 16);
+  auto put = [&](const std::vector<uint8_t> &v) {
+    out->write(reinterpret_cast<const char *>(v.data()), static_cast<std::streamsize>(v.size()));
+  };
+  put(packed.positions);
+  put(packed.alphas);
+  put(packed.colors);
+  put(packed.scales);
+  put(packed.rotations);
+  put(packed.sh);
+}
+
+namespace {
+
+PackedGaussians slicePacked(const uint8_t *stream, const spz_amd_header &hdr) {
+  spz_amd_layout lay;
+  spz_amd_stream_layout(hdr.num_points, hdr.sh_degree, static_cast<int>(hdr.version), &lay);
+  PackedGaussians r;
+  r.numPoints = static_cast<int32_t>(hdr.num_points);
+  r.shDegree = hdr.sh_degree;
+  r.fractionalBits = hdr.fractional_bits;
+  r.antialiased = (hdr.flags & 1) != 0;
+  r.usesQuaternionSmallestThree = hdr.version >= 3;
+  auto take = [&](int s) {
+    return std::vector<uint8_t>(stream + lay.offset[s], stream + lay.offset[s] + lay.bytes[s]);
+  };
+  r.positions = take(SPZ_AMD_SEC_POSITIONS);
+  r.alphas = take(SPZ_AMD_SEC_ALPHAS);
+  r.colors = take(SPZ_AMD_SEC_COLORS);
+  r.scales = take(SPZ_AMD_SEC_SCALES);
+  r.rotations = take(SPZ_AMD_SEC_ROTATIONS);
+  r.sh = take(SPZ_AMD_SEC_SH);
+  return r;
+}
+
+}  // namespace
+
+PackedGaussians deserializePackedGaussians(std::istream &in) {
+  std::vector<uint8_t> data((std::istreambuf_iterator<char>(in)), std::istreambuf_iterator<char>());
+  spz_amd_header hdr;
+  if (!peekHeaderLogged(data.data(), data.size(), &hdr)) return {};
+  return slicePacked(data.data(), hdr);
+}
+
+// ---- pack / unpack -------------------------------------------------------------------------------
+bool packToStream(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream) {
+  g_last_status = SPZ_AMD_OK;
+  if (!checkSizes(g)) {
+    // packGaussians returns an empty PackedGaussians{} (load-spz.cc:258-260) and saveSpz goes on
+    // to write it: a 0-point stream whose header carries the defaults (fractionalBits 0).
+    spz_amd_header h = {};
+    h.version = 3;
+    stream->assign(16, 0);
+    spz_amd_write_header(&h, stream->data());
+    return true;
+  }
+  spz_amd_layout lay;
+  if (spz_amd_stream_layout(static_cast<uint64_t>(g.numPoints), g.shDegree, 3, &lay) != SPZ_AMD_OK) return false;
+  stream->resize(lay.total_bytes);
+  spz_amd_cloud_in in = {g.positions.data(), g.scales.data(), g.rotations.data(),
+                         g.alphas.data(),    g.colors.data(), g.sh.empty() ? nullptr : g.sh.data()};
+  const int rc = spz_amd_encode_host(&in, static_cast<uint64_t>(g.numPoints), g.shDegree, g.antialiased ? 1 : 0,
+                                     static_cast<int>(o.from), 3, stream->data(), stream->size(), deviceIndex());
+  return !deviceFailed(rc, "encode");
+}
+
+GaussianCloud unpackFromStream(const uint8_t *stream, size_t size, const UnpackOptions &o) {
+  g_last_status = SPZ_AMD_OK;
+  spz_amd_header hdr;
+  if (!peekHeaderLogged(stream, size, &hdr)) return {};
+  GaussianCloud r;
+  r.numPoints = static_cast<int32_t>(hdr.num_points);
+  r.shDegree = hdr.sh_degree;
+  r.antialiased = (hdr.flags & 1) != 0;
+  const size_t n = hdr.num_points;
+  r.positions.resize(n * 3);
+  r.scales.resize(n * 3);
+  r.rotations.resize(n * 4);
+  r.alphas.resize(n);
+  r.colors.resize(n * 3);
+  r.sh.resize(n * dimForDegree(hdr.sh_degree) * 3);
+  spz_amd_cloud_out out = {r.positions.data(), r.scales.data(), r.rotations.data(),
+                           r.alphas.data(),    r.colors.data(), r.sh.empty() ? nullptr : r.sh.data()};
+  const int rc = spz_amd_decode_host(stream, size, static_cast<int>(o.to), &out, deviceIndex());
+  if (deviceFailed(rc, "decode")) return {};
+  return r;
+}
+
+PackedGaussians packGaussians(const GaussianCloud &g, const PackOptions &o) {
+  if (!checkSizes(g)) return {};
+  std::vector<uint8_t> stream;
+  if (!packToStream(g, o, &stream)) return {};
+  spz_amd_header hdr;
+  if (spz_amd_peek_header_ex(stream.data(), stream.size(), 0, &hdr) != SPZ_AMD_OK) return {};
+  return slicePacked(stream.data(), hdr);
+}
+
+GaussianCloud unpackGaussians(const PackedGaussians &packed, const UnpackOptions &o) {
+  g_last_status = SPZ_AMD_OK;
+  const int32_t shDim = dimForDegree(packed.shDegree);
+  const bool f16 = packed.usesFloat16();
+  if (!checkSizes(packed, packed.numPoints, shDim, f16)) return {};
+  // Re-assemble the stream (host memcpy) so that one fused decode launch handles it.
+  spz_amd_header h = {};
+  h.version = f16 ? 1u : (packed.usesQuaternionSmallestThree ? 3u : 2u);
+  if (packed.numPoints == 0) h.version = packed.usesQuaternionSmallestThree ? 3u : 2u;
+  h.num_points = static_cast<uint32_t>(packed.numPoints);
+  h.sh_degree = static_cast<uint8_t>(packed.shDegree);
+  h.fractional_bits = static_cast<uint8_t>(packed.fractionalBits);
+  h.flags = packed.antialiased ? 1 : 0;
+  std::vector<uint8_t> stream(16);
+  spz_amd_write_header(&h, stream.data());
+  for (const auto *v : {&packed.positions, &packed.alphas, &packed.colors, &packed.scales, &packed.rotations,
+                        &packed.sh}) {
+    stream.insert(stream.end(), v->begin(), v->end());
+  }
+  spz_amd_header hdr;
+  const int prc = spz_amd_peek_header_ex(stream.data(), stream.size(), 0, &hdr);
+  if (prc != SPZ_AMD_OK) {
+    deviceFailed(prc, "unpackGaussians");
+    return {};
+  }
+  GaussianCloud r;
+  r.numPoints = packed.numPoints;
+  r.shDegree = packed.shDegree;
+  r.antialiased = packed.antialiased;
+  const size_t n = static_cast<size_t>(packed.numPoints);
+  r.positions.resize(n * 3);
+  r.scales.resize(n * 3);
+  r.rotations.resize(n * 4);
+  r.alphas.resize(n);
+  r.colors.resize(n * 3);
+  r.sh.resize(n * shDim * 3);
+  if (n == 0) return r;
+  spz_amd_cloud_out out = {r.positions.data(), r.scales.data(), r.rotations.data(),
+                           r.alphas.data(),    r.colors.data(), r.sh.empty() ? nullptr : r.sh.data()};
+  const int rc = spz_amd_decode_host(stream.data(), stream.size(), static_cast<int>(o.to), &out, deviceIndex());
+  if (deviceFailed(rc, "decode")) return {};
+  return r;
+}
+
+// ---- saveSpz / loadSpz overloads, load-spz.cc:598-668 ---------------------------------------------
+bool saveSpz(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *out) {
+  std::vector<uint8_t> stream;
+  if (!packToStream(g, o, &stream)) return false;
+  return compressGzipped(stream.data(), stream.size(), out);
+}
+
+bool saveSpz(const GaussianCloud &g, const PackOptions &o, const std::string &filename) {
+  std::vector<uint8_t> data;
+  if (!saveSpz(g, o, &data)) return false;
+  // The file is opened only after encoding succeeded; result is out.good() (load-spz.cc:647-650).
+  std::ofstream out(filename, std::ios::binary | std::ios::out);
+  out.write(reinterpret_cast<const char *>(data.data()), static_cast<std::streamsize>(data.size()));
+  out.close();
+  return out.good();
+}
+
+PackedGaussians loadSpzPacked(const uint8_t *data, int32_t size) {
+  std::vector<uint8_t> stream;
+  if (!decompressGzipped(data, static_cast<size_t>(size), &stream)) return {};
+  spz_amd_header hdr;
+  if (!peekHeaderLogged(stream.data(), stream.size(), &hdr)) return {};
+  return slicePacked(stream.data(), hdr);
+}
+
+PackedGaussians loadSpzPacked(const std::vector<uint8_t> &data) {
+  return loadSpzPacked(data.data(), static_cast<int>(data.size()));
+}
+
+PackedGaussians loadSpzPacked(const std::string &filename) {
+  std::vector<uint8_t> data;
+  if (!readFile(filename, &data, /*log=*/false)) return {};
+  return loadSpzPacked(data);
+}
+
+GaussianCloud loadSpz(const uint8_t *data, int32_t size, const UnpackOptions &o) {
+  g_last_status = SPZ_AMD_OK;
+  std::vector<uint8_t> stream;
+  // A failed gunzip yields an empty PackedGaussians and hence an empty cloud, silently
+  // (load-spz.cc:609-612).
+  if (!decompressGzipped(data, static_cast<size_t>(size), &stream)) return {};
+  return unpackFromStream(stream.data(), stream.size(), o);
+}
+
+GaussianCloud loadSpz(const std::vector<uint8_t> &data, const UnpackOptions &o) {
+  return loadSpz(data.data(), static_cast<int32_t>(data.size()), o);
+}
+
+GaussianCloud loadSpz(const std::string &filename, const UnpackOptions &o) {
+  g_last_status = SPZ_AMD_OK;
+  std::vector<uint8_t> data;
+  if (!readFile(filename, &data, /*log=*/true)) return {};
+  return loadSpz(data, o);
+}
+
+}  // namespace spz

@@ -1,0 +1,1329 @@
+// spz_kernels.hip — hand-written HIP kernels (gfx950 / CDNA4) for the SPZ
+// per-Gaussian quantise / dequantise hot path, and the C ABI over them
+// (include/spz_amd.h).
+//
+// What this replaces in the reference (/root/reference/src/cc):
+//   encode  = packGaussians (load-spz.cc:257-331) + packQuaternionSmallestThree
+//             (:216-255) + serializePackedGaussians (:533-546)
+//   decode  = section slicing of deserializePackedGaussians (:569-590) +
+//             unpackGaussians (:467-531) + unpackQuaternion{FirstThree,SmallestThree}
+//             (:333-381) + GaussianCloud::convertCoordinates (splat-types.h:134-164)
+//             fused into one pass
+//   flip    = GaussianCloud::convertCoordinates as a standalone in-place pass.
+//
+// Design: this is an HBM-bound byte transform, no MFMA.  ONE
+// launch per direction covers all six sections: the grid is a flat list of
+// tiles (256 threads x kUnroll "units"), a block finds its section with a few
+// wave-uniform scalar compares and runs that section's body.  A unit is four
+// consecutive float elements (one 16-byte access on the float side) and the
+// 4 / 12 / 8 / 3 packed bytes they map to, so both sides of every section are
+// accessed lane-contiguously: 1 KiB per wave-instruction on the float side,
+// 256 B (768 B for 24-bit positions) on the byte side.  Section bases in the
+// stream are 16+9N, 16+10N, ... and therefore land on any byte alignment; the
+// byte side uses unaligned dword / dwordx3 accesses (global memory on gfx950
+// runs in unaligned-access mode), so there is no head/tail peel and no
+// per-section alignment case split.  Coordinate flips are sign-bit XORs picked
+// from small bit masks; every table-driven decode (alpha, colour) reads a 256
+// entry LDS table; the alpha encode (the only transcendental on the path) is an
+// 8-step branch-free binary search over 255 float thresholds in LDS.
+//
+// Bit-exactness rules: no FMA contraction anywhere on
+// the quantisation path (file-wide contract(off) + register barriers after the
+// multiplies that feed adds), round-half-away implemented exactly, IEEE divide
+// and sqrt (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt), f32
+// denormals preserved (hipcc default), float->int conversions reproduce the
+// x86-64 cvttss2si results of the reference build also outside the defined
+// domain (NaN / overflow -> "integer indefinite").
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+#include <mutex>
+
+#include "spz_amd.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// Geometry
+// ------------------------------------------------------------------------------------------
+constexpr int kBlock = 256;
+constexpr int kUnroll = 4;
+constexpr int kTileUnits = kBlock * kUnroll;  // units per tile; one unit = 4 float elements
+static_assert(kTileUnits % 3 == 1, "position phase arithmetic assumes kTileUnits == 1 (mod 3)");
+constexpr int kMaxBlocksPerCU = 8;
+
+enum SecKind : uint32_t {
+  KIND_POS24 = 0,  // 24-bit fixed point, 12 bytes per unit
+  KIND_POS16,      // legacy float16 positions (decode only), 8 bytes per unit
+  KIND_ALPHA,      // 4 bytes per unit, table / threshold search
+  KIND_COLOR,      // 4 bytes per unit
+  KIND_SCALE,      // 4 bytes per unit
+  KIND_ROT_S3,     // smallest-three quaternion: 1 point = 4 floats <-> 4 bytes
+  KIND_ROT_F3,     // first-three quaternion:    1 point = 4 floats <-> 3 bytes
+  KIND_SH,         // 4 bytes per unit, flip + bucket depend on (element % D)
+  KIND_FLIP_POS,   // in-place convertCoordinates passes (floats only)
+  KIND_FLIP_ROT,
+  KIND_FLIP_SH,
+};
+
+struct SecDesc {
+  uint8_t *bytes;              // stream side (encode writes, decode reads); unused by flip kinds
+  float *floats;               // float side
+  unsigned long long n_elems;  // float elements in this section
+  unsigned long long n_units;  // ceil(n_elems / 4)
+  uint32_t tile_begin;         // first tile of this section in the fused grid
+  uint32_t kind;
+};
+
+struct KParams {
+  SecDesc sec[SPZ_AMD_NUM_SECTIONS];
+  uint32_t n_sec;
+  uint32_t total_tiles;
+  uint32_t flip_p;                // bit a set: axis a is negated
+  uint32_t flip_q;                // bit i set: quaternion component i (x,y,z) is negated
+  unsigned long long sh_mask_ext; // bit j: element j of a point's D sh floats is negated; bits D..D+2 repeat 0..2
+  uint32_t sh_d;                  // 0, 9, 24, 45
+  float pos_scale;                // decode: 1 / (1 << fractionalBits)
+  const float *tables;            // device tables, see kTable* below
+  uint8_t *header_dst;            // encode: where the 16 header bytes go (nullptr: none)
+  uint32_t header_words[4];
+};
+
+constexpr int kTableAlphaDec = 0;    // 256 floats
+constexpr int kTableColorDec = 256;  // 256 floats
+constexpr int kTableAlphaThr = 512;  // 255 floats + 1 NaN pad
+constexpr int kTableFloats = 768;
+
+// ------------------------------------------------------------------------------------------
+// Unaligned access types.  The float side needs dword alignment only; the byte side none.
+// ------------------------------------------------------------------------------------------
+struct __attribute__((packed, aligned(4))) F32x4 { float x, y, z, w; };
+struct __attribute__((packed, aligned(1))) U32x1 { uint32_t a; };
+struct __attribute__((packed, aligned(1))) U32x2 { uint32_t a, b; };
+struct __attribute__((packed, aligned(1))) U32x3 { uint32_t a, b, c; };
+struct __attribute__((packed, aligned(1))) U8x3 { uint8_t a, b, c; };
+
+struct Raw3 { uint32_t a, b, c; };
+
+// ------------------------------------------------------------------------------------------
+// Exact scalar helpers
+// ------------------------------------------------------------------------------------------
+// Keeps a product in a register of its own so that no later add can be contracted with it,
+// whatever the compiler flags are.
+__device__ __forceinline__ float fmul_sep(float a, float b) {
+  float r = a * b;
+  asm volatile("" : "+v"(r));
+  return r;
+}
+__device__ __forceinline__ float fadd_sep(float a, float b) {
+  float r = a + b;
+  asm volatile("" : "+v"(r));
+  return r;
+}
+
+__device__ __forceinline__ bool is_nan_bits(uint32_t b) { return (b & 0x7fffffffu) > 0x7f800000u; }
+
+// v * (neg ? -1.0f : 1.0f) with the x86 mulss result also for NaN (a NaN operand is returned
+// quieted, sign untouched) and for zeros (0 * -1 = -0).
+__device__ __forceinline__ float mul_pm1(float v, uint32_t neg) {
+  uint32_t b = __float_as_uint(v);
+  uint32_t flipped = b ^ (neg << 31);
+  return __uint_as_float(is_nan_bits(b) ? (b | 0x00400000u) : flipped);
+}
+
+// std::round: half away from zero, exact (load-spz.cc:74,78,284).
+__device__ __forceinline__ float round_half_away(float x) {
+  float t = __builtin_truncf(x);
+  float d = __builtin_fabsf(x - t);  // exact
+  float one = __builtin_copysignf(1.0f, x);
+  return (d >= 0.5f) ? (t + one) : t;
+}
+
+// static_cast<int32_t>(float) as the reference's x86-64 build executes it (cvttss2si):
+// NaN and out-of-range give 0x80000000.
+__device__ __forceinline__ int32_t cvt_i32_x86(float r) {
+  return (r >= -2147483648.0f && r < 2147483648.0f) ? (int32_t)r : (int32_t)0x80000000;
+}
+
+// static_cast<uint32_t>(float) as x86-64 gcc executes it: 64-bit cvttss2si, low 32 bits.
+__device__ __forceinline__ uint32_t cvt_u32_x86(float r) {
+  if (r > -9223372036854775808.0f && r < 9223372036854775808.0f) {
+    return (uint32_t)(long long)r;
+  }
+  return 0u;
+}
+
+// toUint8 (load-spz.cc:74): static_cast<uint8_t>(clamp(round(x), 0, 255)).
+__device__ __forceinline__ uint32_t to_uint8(float x) {
+  float r = round_half_away(x);
+  r = (r < 0.0f) ? 0.0f : ((255.0f < r) ? 255.0f : r);  // std::clamp; NaN falls through
+  return (uint32_t)cvt_i32_x86(r) & 0xffu;
+}
+
+// quantizeSH (load-spz.cc:77-81) for bucket = 1 << shift.
+__device__ __forceinline__ uint32_t quantize_sh(float x, uint32_t shift) {
+  float t = round_half_away(x * 128.0f) + 128.0f;
+  int32_t q = cvt_i32_x86(t);
+  int32_t bucket = 1 << shift;
+  int32_t s = q + (bucket >> 1);
+  // (s / bucket * bucket) truncates toward zero: every negative s ends <= 0 and clamps to 0.
+  int32_t v = s & ~(bucket - 1);
+  v = (s < 0) ? 0 : ((v > 255) ? 255 : v);
+  return (uint32_t)v;
+}
+
+constexpr float kSqrt1_2 = (float)0.707106781186547524401;  // load-spz.cc:46
+
+// packQuaternionSmallestThree (load-spz.cc:216-255) incl. normalized() (splat-types.cc:71-74).
+__device__ __forceinline__ uint32_t pack_quat_smallest_three(F32x4 r, uint32_t flip_q) {
+  float n2 = fadd_sep(fadd_sep(fadd_sep(fmul_sep(r.x, r.x), fmul_sep(r.y, r.y)), fmul_sep(r.z, r.z)),
+                      fmul_sep(r.w, r.w));
+  float norm = __builtin_sqrtf(n2);
+  float q0 = mul_pm1(r.x / norm, flip_q & 1u);
+  float q1 = mul_pm1(r.y / norm, (flip_q >> 1) & 1u);
+  float q2 = mul_pm1(r.z / norm, (flip_q >> 2) & 1u);
+  float q3 = r.w / norm;
+  // argmax |q|, strict >, first wins
+  uint32_t iL = 0;
+  float best = __builtin_fabsf(q0);
+  if (__builtin_fabsf(q1) > best) { iL = 1; best = __builtin_fabsf(q1); }
+  if (__builtin_fabsf(q2) > best) { iL = 2; best = __builtin_fabsf(q2); }
+  if (__builtin_fabsf(q3) > best) { iL = 3; best = __builtin_fabsf(q3); }
+  float qL = (iL == 0) ? q0 : (iL == 1) ? q1 : (iL == 2) ? q2 : q3;
+  uint32_t negate = (qL < 0.0f) ? 1u : 0u;
+  uint32_t comp = iL;
+  const float qs[4] = {q0, q1, q2, q3};
+#pragma unroll
+  for (uint32_t i = 0; i < 4; ++i) {
+    uint32_t negbit = ((qs[i] < 0.0f) ? 1u : 0u) ^ negate;
+    float m = fmul_sep(511.0f, __builtin_fabsf(qs[i]) / kSqrt1_2) + 0.5f;
+    uint32_t mag = cvt_u32_x86(m);
+    uint32_t next = (comp << 10) | (negbit << 9) | mag;
+    comp = (i != iL) ? next : comp;
+  }
+  return comp;
+}
+
+// PARITY UNPINNED (no v2 encoder in the reference): upstream nianticlabs/spz v1.x
+// first-three encoder — normalise, flip, scale by +-127.5 so that w >= 0, offset, toUint8.
+__device__ __forceinline__ uint32_t pack_quat_first_three(F32x4 r, uint32_t flip_q) {
+  float n2 = fadd_sep(fadd_sep(fadd_sep(fmul_sep(r.x, r.x), fmul_sep(r.y, r.y)), fmul_sep(r.z, r.z)),
+                      fmul_sep(r.w, r.w));
+  float norm = __builtin_sqrtf(n2);
+  float q0 = mul_pm1(r.x / norm, flip_q & 1u);
+  float q1 = mul_pm1(r.y / norm, (flip_q >> 1) & 1u);
+  float q2 = mul_pm1(r.z / norm, (flip_q >> 2) & 1u);
+  float q3 = r.w / norm;
+  float s = (q3 < 0.0f) ? -127.5f : 127.5f;
+  uint32_t b0 = to_uint8(fmul_sep(q0, s) + 127.5f);
+  uint32_t b1 = to_uint8(fmul_sep(q1, s) + 127.5f);
+  uint32_t b2 = to_uint8(fmul_sep(q2, s) + 127.5f);
+  return b0 | (b1 << 8) | (b2 << 16);
+}
+
+// unpackQuaternionSmallestThree (load-spz.cc:347-381) followed by the flip pass.
+__device__ __forceinline__ F32x4 unpack_quat_smallest_three(uint32_t comp, uint32_t flip_q) {
+  const uint32_t iL = comp >> 30;
+  float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
+  float sum = 0.0f;
+#pragma unroll
+  for (int i = 3; i >= 0; --i) {
+    const bool take = ((uint32_t)i != iL);
+    uint32_t mag = comp & 511u;
+    uint32_t neg = (comp >> 9) & 1u;
+    float c = fmul_sep(kSqrt1_2, (float)mag) / 511.0f;
+    c = __uint_as_float(__float_as_uint(c) ^ (neg << 31));
+    float s2 = sum + fmul_sep(c, c);
+    v[i] = take ? c : 0.0f;
+    sum = take ? s2 : sum;
+    comp = take ? (comp >> 10) : comp;
+  }
+  // sqrt(1.0f - sum): ::sqrt(double) rounded to float == correctly rounded sqrtf; a negative
+  // argument yields the x86 default NaN (sign bit set).
+  float d = 1.0f - sum;
+  float big = (d < 0.0f) ? __uint_as_float(0xffc00000u) : __builtin_sqrtf(d);
+  float x = (iL == 0) ? big : v[0];
+  float y = (iL == 1) ? big : v[1];
+  float z = (iL == 2) ? big : v[2];
+  float w = (iL == 3) ? big : v[3];
+  F32x4 o;
+  o.x = mul_pm1(x, flip_q & 1u);
+  o.y = mul_pm1(y, (flip_q >> 1) & 1u);
+  o.z = mul_pm1(z, (flip_q >> 2) & 1u);
+  o.w = w;
+  return o;
+}
+
+// unpackQuaternionFirstThree (load-spz.cc:333-345) followed by the flip pass.
+__device__ __forceinline__ F32x4 unpack_quat_first_three(uint32_t r3, uint32_t flip_q) {
+  constexpr float k = 1.0f / 127.5f;
+  float x = fmul_sep((float)(r3 & 0xffu), k) + (-1.0f);
+  float y = fmul_sep((float)((r3 >> 8) & 0xffu), k) + (-1.0f);
+  float z = fmul_sep((float)((r3 >> 16) & 0xffu), k) + (-1.0f);
+  float sq = fadd_sep(fadd_sep(fmul_sep(x, x), fmul_sep(y, y)), fmul_sep(z, z));
+  float d = 1.0f - sq;
+  float m = (0.0f < d) ? d : 0.0f;  // std::max(0.0f, d)
+  F32x4 o;
+  o.x = mul_pm1(x, flip_q & 1u);
+  o.y = mul_pm1(y, (flip_q >> 1) & 1u);
+  o.z = mul_pm1(z, (flip_q >> 2) & 1u);
+  o.w = __builtin_sqrtf(m);
+  return o;
+}
+
+// halfToFloat (splat-types.cc:8-27): exact widening; every NaN becomes the positive quiet NaN.
+__device__ __forceinline__ float half_to_float(uint32_t h) {
+  h &= 0xffffu;
+  if ((h & 0x7c00u) == 0x7c00u && (h & 0x3ffu) != 0) return __uint_as_float(0x7fc00000u);
+  _Float16 f;
+  uint16_t hh = (uint16_t)h;
+  __builtin_memcpy(&f, &hh, 2);
+  return (float)f;
+}
+
+// Alpha encode: number of thresholds <= a (NaN -> 0), thresholds ascending, thr[255] = NaN.
+__device__ __forceinline__ uint32_t alpha_byte(float a, const float *thr) {
+  uint32_t lo = 0;
+#pragma unroll
+  for (uint32_t step = 128; step >= 1; step >>= 1) {
+    lo += (a >= thr[lo + step - 1]) ? step : 0u;
+  }
+  return lo;
+}
+
+// ------------------------------------------------------------------------------------------
+// Per-unit sign-bit selectors
+// ------------------------------------------------------------------------------------------
+// positions: element e = 4u + c sits on axis e % 3 = (u + c) % 3.
+__device__ __forceinline__ uint32_t pos_sign_bits(uint32_t flip_p, uint32_t unit_mod3) {
+  uint32_t rep = flip_p | (flip_p << 3);  // bits 0..5
+  return (rep >> unit_mod3) & 0xfu;
+}
+
+// ------------------------------------------------------------------------------------------
+// Decode
+// ------------------------------------------------------------------------------------------
+template <int KIND>
+__device__ __forceinline__ Raw3 load_raw(const uint8_t *__restrict__ src, unsigned long long u) {
+  Raw3 r = {0u, 0u, 0u};
+  if constexpr (KIND == KIND_POS24) {
+    U32x3 t = *reinterpret_cast<const U32x3 *>(src + u * 12ull);
+    r.a = t.a; r.b = t.b; r.c = t.c;
+  } else if constexpr (KIND == KIND_POS16) {
+    U32x2 t = *reinterpret_cast<const U32x2 *>(src + u * 8ull);
+    r.a = t.a; r.b = t.b;
+  } else if constexpr (KIND == KIND_ROT_F3) {
+    U8x3 t = *reinterpret_cast<const U8x3 *>(src + u * 3ull);
+    r.a = (uint32_t)t.a | ((uint32_t)t.b << 8) | ((uint32_t)t.c << 16);
+  } else {
+    r.a = reinterpret_cast<const U32x1 *>(src + u * 4ull)->a;
+  }
+  return r;
+}
+
+// Partial last unit: only `m` (1..3) elements exist; read exactly their bytes.
+template <int KIND>
+__device__ __forceinline__ Raw3 load_raw_partial(const uint8_t *__restrict__ src, unsigned long long u, uint32_t m) {
+  constexpr uint32_t bpe = (KIND == KIND_POS24) ? 3u : (KIND == KIND_POS16) ? 2u : 1u;  // bytes per element
+  const uint8_t *p = src + u * (4ull * bpe);
+  uint32_t w[3] = {0u, 0u, 0u};
+  for (uint32_t i = 0; i < m * bpe; ++i) w[i >> 2] |= (uint32_t)p[i] << ((i & 3u) * 8u);
+  return Raw3{w[0], w[1], w[2]};
+}
+
+struct DecodeCtx {
+  uint32_t flip_p, flip_q;
+  unsigned long long sh_mask_ext;
+  float pos_scale;
+  const float *lut;  // LDS
+};
+
+template <int KIND, int D>
+__device__ __forceinline__ F32x4 decode_unit(Raw3 raw, uint32_t phase, const DecodeCtx &c) {
+  F32x4 o;
+  if constexpr (KIND == KIND_POS24) {
+    // load-spz.cc:496-502: sign-extended 24-bit * scale, then flipP
+    uint32_t v0 = raw.a & 0xffffffu;
+    uint32_t v1 = (raw.a >> 24) | ((raw.b & 0xffffu) << 8);
+    uint32_t v2 = (raw.b >> 16) | ((raw.c & 0xffu) << 16);
+    uint32_t v3 = raw.c >> 8;
+    uint32_t sb = pos_sign_bits(c.flip_p, phase);
+    o.x = mul_pm1((float)((int32_t)(v0 << 8) >> 8) * c.pos_scale, sb & 1u);
+    o.y = mul_pm1((float)((int32_t)(v1 << 8) >> 8) * c.pos_scale, (sb >> 1) & 1u);
+    o.z = mul_pm1((float)((int32_t)(v2 << 8) >> 8) * c.pos_scale, (sb >> 2) & 1u);
+    o.w = mul_pm1((float)((int32_t)(v3 << 8) >> 8) * c.pos_scale, (sb >> 3) & 1u);
+  } else if constexpr (KIND == KIND_POS16) {
+    uint32_t sb = pos_sign_bits(c.flip_p, phase);
+    o.x = mul_pm1(half_to_float(raw.a), sb & 1u);
+    o.y = mul_pm1(half_to_float(raw.a >> 16), (sb >> 1) & 1u);
+    o.z = mul_pm1(half_to_float(raw.b), (sb >> 2) & 1u);
+    o.w = mul_pm1(half_to_float(raw.b >> 16), (sb >> 3) & 1u);
+  } else if constexpr (KIND == KIND_ALPHA) {
+    const float *t = c.lut + kTableAlphaDec;  // invSigmoid(b / 255.0f), load-spz.cc:518
+    o.x = t[raw.a & 0xffu];
+    o.y = t[(raw.a >> 8) & 0xffu];
+    o.z = t[(raw.a >> 16) & 0xffu];
+    o.w = t[raw.a >> 24];
+  } else if constexpr (KIND == KIND_COLOR) {
+    const float *t = c.lut + kTableColorDec;  // ((b / 255.0f) - 0.5f) / 0.15f, load-spz.cc:522
+    o.x = t[raw.a & 0xffu];
+    o.y = t[(raw.a >> 8) & 0xffu];
+    o.z = t[(raw.a >> 16) & 0xffu];
+    o.w = t[raw.a >> 24];
+  } else if constexpr (KIND == KIND_SCALE) {
+    // b / 16.0f - 10.0f, load-spz.cc:506 (the quotient is exact)
+    o.x = (float)(raw.a & 0xffu) / 16.0f - 10.0f;
+    o.y = (float)((raw.a >> 8) & 0xffu) / 16.0f - 10.0f;
+    o.z = (float)((raw.a >> 16) & 0xffu) / 16.0f - 10.0f;
+    o.w = (float)(raw.a >> 24) / 16.0f - 10.0f;
+  } else if constexpr (KIND == KIND_ROT_S3) {
+    o = unpack_quat_smallest_three(raw.a, c.flip_q);
+  } else if constexpr (KIND == KIND_ROT_F3) {
+    o = unpack_quat_first_three(raw.a, c.flip_q);
+  } else {  // KIND_SH: (b - 128) / 128 (load-spz.cc:83), then flipSh of coefficient (e % D) / 3
+    uint32_t sb = (uint32_t)(c.sh_mask_ext >> phase) & 0xfu;
+    o.x = mul_pm1(((float)(raw.a & 0xffu) - 128.0f) / 128.0f, sb & 1u);
+    o.y = mul_pm1(((float)((raw.a >> 8) & 0xffu) - 128.0f) / 128.0f, (sb >> 1) & 1u);
+    o.z = mul_pm1(((float)((raw.a >> 16) & 0xffu) - 128.0f) / 128.0f, (sb >> 2) & 1u);
+    o.w = mul_pm1(((float)(raw.a >> 24) - 128.0f) / 128.0f, (sb >> 3) & 1u);
+  }
+  return o;
+}
+
+// Phase of a unit inside its tile: positions -> unit % 3, sh -> (4 * unit) % D, else unused.
+template <int KIND, int D>
+__device__ __forceinline__ uint32_t tile_phase_base(uint32_t tile_local) {
+  if constexpr (KIND == KIND_POS24 || KIND == KIND_POS16 || KIND == KIND_FLIP_POS) {
+    return tile_local % 3u;  // kTileUnits == 1 (mod 3)
+  } else if constexpr ((KIND == KIND_SH || KIND == KIND_FLIP_SH) && D > 0) {
+    return ((tile_local % (uint32_t)D) * ((4u * kTileUnits) % (uint32_t)D)) % (uint32_t)D;
+  } else {
+    return 0u;
+  }
+}
+template <int KIND, int D>
+__device__ __forceinline__ uint32_t unit_phase(uint32_t base, uint32_t local) {
+  if constexpr (KIND == KIND_POS24 || KIND == KIND_POS16 || KIND == KIND_FLIP_POS) {
+    return (base + local) % 3u;
+  } else if constexpr ((KIND == KIND_SH || KIND == KIND_FLIP_SH) && D > 0) {
+    return (base + 4u * local) % (uint32_t)D;
+  } else {
+    return 0u;
+  }
+}
+
+__device__ __forceinline__ void store_f4(float *__restrict__ dst, unsigned long long u, F32x4 v) {
+  *reinterpret_cast<F32x4 *>(dst + u * 4ull) = v;
+}
+__device__ __forceinline__ F32x4 load_f4(const float *__restrict__ src, unsigned long long u) {
+  return *reinterpret_cast<const F32x4 *>(src + u * 4ull);
+}
+
+template <int KIND, int D>
+__device__ __forceinline__ void decode_tile(const SecDesc &s, uint32_t tile_local, const DecodeCtx &c) {
+  const unsigned long long base = (unsigned long long)tile_local * kTileUnits;
+  const uint32_t tid = threadIdx.x;
+  const uint8_t *__restrict__ src = s.bytes;
+  float *__restrict__ dst = s.floats;
+  const unsigned long long full_units = s.n_elems >> 2;
+  const uint32_t pb = tile_phase_base<KIND, D>(tile_local);
+  if (base + kTileUnits <= full_units) {
+    Raw3 raw[kUnroll];
+#pragma unroll
+    for (int r = 0; r < kUnroll; ++r) raw[r] = load_raw<KIND>(src, base + (uint32_t)(r * kBlock) + tid);
+#pragma unroll
+    for (int r = 0; r < kUnroll; ++r) {
+      const uint32_t local = (uint32_t)(r * kBlock) + tid;
+      store_f4(dst, base + local, decode_unit<KIND, D>(raw[r], unit_phase<KIND, D>(pb, local), c));
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < kUnroll; ++r) {
+      const uint32_t local = (uint32_t)(r * kBlock) + tid;
+      const unsigned long long u = base + local;
+      if (u < full_units) {
+        store_f4(dst, u, decode_unit<KIND, D>(load_raw<KIND>(src, u), unit_phase<KIND, D>(pb, local), c));
+      } else if (u < s.n_units) {
+        if constexpr (KIND != KIND_ROT_S3 && KIND != KIND_ROT_F3) {
+          const uint32_t m = (uint32_t)(s.n_elems - u * 4ull);  // 1..3 valid elements
+          F32x4 v = decode_unit<KIND, D>(load_raw_partial<KIND>(src, u, m), unit_phase<KIND, D>(pb, local), c);
+          float *p = dst + u * 4ull;
+          p[0] = v.x;
+          if (m > 1) p[1] = v.y;
+          if (m > 2) p[2] = v.z;
+        }
+      }
+    }
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ void decode_tile_sh_dispatch(const SecDesc &s, uint32_t tile_local, const DecodeCtx &c,
+                                                        uint32_t sh_d) {
+  if (sh_d == 45u) decode_tile<KIND, 45>(s, tile_local, c);
+  else if (sh_d == 24u) decode_tile<KIND, 24>(s, tile_local, c);
+  else decode_tile<KIND, 9>(s, tile_local, c);
+}
+
+__device__ __forceinline__ uint32_t find_section(const KParams &p, uint32_t tile) {
+  uint32_t si = 0;
+#pragma unroll
+  for (uint32_t k = 1; k < SPZ_AMD_NUM_SECTIONS; ++k) {
+    if (k < p.n_sec && tile >= p.sec[k].tile_begin) si = k;
+  }
+  return si;
+}
+
+__device__ __forceinline__ void stage_tables(float *lut, const float *__restrict__ tables) {
+  for (uint32_t i = threadIdx.x; i < kTableFloats; i += kBlock) lut[i] = tables[i];
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(kBlock) void spz_decode_kernel(const KParams p) {
+  __shared__ float lut[kTableFloats];
+  bool lut_ready = false;
+  DecodeCtx c;
+  c.flip_p = p.flip_p;
+  c.flip_q = p.flip_q;
+  c.sh_mask_ext = p.sh_mask_ext;
+  c.pos_scale = p.pos_scale;
+  c.lut = lut;
+  for (uint32_t tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+    const uint32_t si = find_section(p, tile);
+    const SecDesc &s = p.sec[si];
+    const uint32_t tl = tile - s.tile_begin;
+    switch (s.kind) {
+      case KIND_POS24: decode_tile<KIND_POS24, 0>(s, tl, c); break;
+      case KIND_POS16: decode_tile<KIND_POS16, 0>(s, tl, c); break;
+      case KIND_ALPHA:
+      case KIND_COLOR:
+        if (!lut_ready) {
+          stage_tables(lut, p.tables);
+          lut_ready = true;
+        }
+        if (s.kind == KIND_ALPHA) decode_tile<KIND_ALPHA, 0>(s, tl, c);
+        else decode_tile<KIND_COLOR, 0>(s, tl, c);
+        break;
+      case KIND_SCALE: decode_tile<KIND_SCALE, 0>(s, tl, c); break;
+      case KIND_ROT_S3: decode_tile<KIND_ROT_S3, 0>(s, tl, c); break;
+      case KIND_ROT_F3: decode_tile<KIND_ROT_F3, 0>(s, tl, c); break;
+      case KIND_SH: decode_tile_sh_dispatch<KIND_SH>(s, tl, c, p.sh_d); break;
+      default: break;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Encode
+// ------------------------------------------------------------------------------------------
+struct EncodeCtx {
+  uint32_t flip_p, flip_q;
+  unsigned long long sh_mask_ext;
+  const float *lut;  // LDS
+};
+
+// Returns the packed bytes of one unit in (a, b, c): 12 bytes for positions, 4 (or 3) otherwise.
+template <int KIND, int D>
+__device__ __forceinline__ Raw3 encode_unit(F32x4 v, uint32_t phase, const EncodeCtx &c) {
+  Raw3 o = {0u, 0u, 0u};
+  if constexpr (KIND == KIND_POS24) {
+    // load-spz.cc:282-288: (int32)round(flipP * p * 4096), low 24 bits LE
+    uint32_t sb = pos_sign_bits(c.flip_p, phase);
+    uint32_t f0 = (uint32_t)cvt_i32_x86(round_half_away(mul_pm1(v.x, sb & 1u) * 4096.0f)) & 0xffffffu;
+    uint32_t f1 = (uint32_t)cvt_i32_x86(round_half_away(mul_pm1(v.y, (sb >> 1) & 1u) * 4096.0f)) & 0xffffffu;
+    uint32_t f2 = (uint32_t)cvt_i32_x86(round_half_away(mul_pm1(v.z, (sb >> 2) & 1u) * 4096.0f)) & 0xffffffu;
+    uint32_t f3 = (uint32_t)cvt_i32_x86(round_half_away(mul_pm1(v.w, (sb >> 3) & 1u) * 4096.0f)) & 0xffffffu;
+    o.a = f0 | (f1 << 24);
+    o.b = (f1 >> 8) | (f2 << 16);
+    o.c = (f2 >> 16) | (f3 << 8);
+  } else if constexpr (KIND == KIND_ALPHA) {
+    // toUint8(sigmoid(a) * 255) (load-spz.cc:85,301) == number of thresholds <= a
+    const float *t = c.lut + kTableAlphaThr;
+    o.a = alpha_byte(v.x, t) | (alpha_byte(v.y, t) << 8) | (alpha_byte(v.z, t) << 16) | (alpha_byte(v.w, t) << 24);
+  } else if constexpr (KIND == KIND_COLOR) {
+    // toUint8(c * (0.15f * 255.0f) + (0.5f * 255.0f)), load-spz.cc:306: mul and add round separately
+    constexpr float k = 0.15f * 255.0f;
+    constexpr float h = 0.5f * 255.0f;
+    o.a = to_uint8(fmul_sep(v.x, k) + h) | (to_uint8(fmul_sep(v.y, k) + h) << 8) |
+          (to_uint8(fmul_sep(v.z, k) + h) << 16) | (to_uint8(fmul_sep(v.w, k) + h) << 24);
+  } else if constexpr (KIND == KIND_SCALE) {
+    // toUint8((s + 10.0f) * 16.0f), load-spz.cc:291
+    o.a = to_uint8(fadd_sep(v.x, 10.0f) * 16.0f) | (to_uint8(fadd_sep(v.y, 10.0f) * 16.0f) << 8) |
+          (to_uint8(fadd_sep(v.z, 10.0f) * 16.0f) << 16) | (to_uint8(fadd_sep(v.w, 10.0f) * 16.0f) << 24);
+  } else if constexpr (KIND == KIND_ROT_S3) {
+    o.a = pack_quat_smallest_three(v, c.flip_q);
+  } else if constexpr (KIND == KIND_ROT_F3) {
+    o.a = pack_quat_first_three(v, c.flip_q);
+  } else {  // KIND_SH, load-spz.cc:315-327: 5 bits for the 9 degree-1 values, 4 bits for the rest
+    uint32_t sb = (uint32_t)(c.sh_mask_ext >> phase) & 0xfu;
+    uint32_t j0 = phase, j1 = phase + 1, j2 = phase + 2, j3 = phase + 3;
+    j1 -= (j1 >= (uint32_t)D) ? (uint32_t)D : 0u;
+    j2 -= (j2 >= (uint32_t)D) ? (uint32_t)D : 0u;
+    j3 -= (j3 >= (uint32_t)D) ? (uint32_t)D : 0u;
+    o.a = quantize_sh(mul_pm1(v.x, sb & 1u), (j0 < 9u) ? 3u : 4u) |
+          (quantize_sh(mul_pm1(v.y, (sb >> 1) & 1u), (j1 < 9u) ? 3u : 4u) << 8) |
+          (quantize_sh(mul_pm1(v.z, (sb >> 2) & 1u), (j2 < 9u) ? 3u : 4u) << 16) |
+          (quantize_sh(mul_pm1(v.w, (sb >> 3) & 1u), (j3 < 9u) ? 3u : 4u) << 24);
+  }
+  return o;
+}
+
+template <int KIND>
+__device__ __forceinline__ void store_raw(uint8_t *__restrict__ dst, unsigned long long u, Raw3 r) {
+  if constexpr (KIND == KIND_POS24) {
+    U32x3 t;
+    t.a = r.a; t.b = r.b; t.c = r.c;
+    *reinterpret_cast<U32x3 *>(dst + u * 12ull) = t;
+  } else if constexpr (KIND == KIND_ROT_F3) {
+    U8x3 t;
+    t.a = (uint8_t)r.a; t.b = (uint8_t)(r.a >> 8); t.c = (uint8_t)(r.a >> 16);
+    *reinterpret_cast<U8x3 *>(dst + u * 3ull) = t;
+  } else {
+    reinterpret_cast<U32x1 *>(dst + u * 4ull)->a = r.a;
+  }
+}
+
+template <int KIND, int D>
+__device__ __forceinline__ void encode_tile(const SecDesc &s, uint32_t tile_local, const EncodeCtx &c) {
+  const unsigned long long base = (unsigned long long)tile_local * kTileUnits;
+  const uint32_t tid = threadIdx.x;
+  const float *__restrict__ src = s.floats;
+  uint8_t *__restrict__ dst = s.bytes;
+  const unsigned long long full_units = s.n_elems >> 2;
+  const uint32_t pb = tile_phase_base<KIND, D>(tile_local);
+  if (base + kTileUnits <= full_units) {
+    F32x4 v[kUnroll];
+#pragma unroll
+    for (int r = 0; r < kUnroll; ++r) v[r] = load_f4(src, base + (uint32_t)(r * kBlock) + tid);
+#pragma unroll
+    for (int r = 0; r < kUnroll; ++r) {
+      const uint32_t local = (uint32_t)(r * kBlock) + tid;
+      store_raw<KIND>(dst, base + local, encode_unit<KIND, D>(v[r], unit_phase<KIND, D>(pb, local), c));
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < kUnroll; ++r) {
+      const uint32_t local = (uint32_t)(r * kBlock) + tid;
+      const unsigned long long u = base + local;
+      if (u < full_units) {
+        store_raw<KIND>(dst, u, encode_unit<KIND, D>(load_f4(src, u), unit_phase<KIND, D>(pb, local), c));
+      } else if (u < s.n_units) {
+        if constexpr (KIND != KIND_ROT_S3 && KIND != KIND_ROT_F3) {
+          const uint32_t m = (uint32_t)(s.n_elems - u * 4ull);  // 1..3 valid elements
+          const float *p = src + u * 4ull;
+          F32x4 v;
+          v.x = p[0];
+          v.y = (m > 1) ? p[1] : 0.0f;
+          v.z = (m > 2) ? p[2] : 0.0f;
+          v.w = 0.0f;
+          Raw3 r3 = encode_unit<KIND, D>(v, unit_phase<KIND, D>(pb, local), c);
+          constexpr uint32_t bpe = (KIND == KIND_POS24) ? 3u : 1u;
+          uint8_t *q = dst + u * (4ull * bpe);
+          const uint32_t w[3] = {r3.a, r3.b, r3.c};
+          for (uint32_t i = 0; i < m * bpe; ++i) q[i] = (uint8_t)(w[i >> 2] >> ((i & 3u) * 8u));
+        }
+      }
+    }
+  }
+}
+
+template <int KIND>
+__device__ __forceinline__ void encode_tile_sh_dispatch(const SecDesc &s, uint32_t tile_local, const EncodeCtx &c,
+                                                        uint32_t sh_d) {
+  if (sh_d == 45u) encode_tile<KIND, 45>(s, tile_local, c);
+  else if (sh_d == 24u) encode_tile<KIND, 24>(s, tile_local, c);
+  else encode_tile<KIND, 9>(s, tile_local, c);
+}
+
+__global__ __launch_bounds__(kBlock) void spz_encode_kernel(const KParams p) {
+  __shared__ float lut[kTableFloats];
+  bool lut_ready = false;
+  EncodeCtx c;
+  c.flip_p = p.flip_p;
+  c.flip_q = p.flip_q;
+  c.sh_mask_ext = p.sh_mask_ext;
+  c.lut = lut;
+  if (blockIdx.x == 0 && threadIdx.x < 16 && p.header_dst != nullptr) {
+    // PackedGaussiansHeader, load-spz.cc:131-139,534-539
+    p.header_dst[threadIdx.x] = (uint8_t)(p.header_words[threadIdx.x >> 2] >> ((threadIdx.x & 3u) * 8u));
+  }
+  for (uint32_t tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+    const uint32_t si = find_section(p, tile);
+    const SecDesc &s = p.sec[si];
+    const uint32_t tl = tile - s.tile_begin;
+    switch (s.kind) {
+      case KIND_POS24: encode_tile<KIND_POS24, 0>(s, tl, c); break;
+      case KIND_ALPHA:
+        if (!lut_ready) {
+          stage_tables(lut, p.tables);
+          lut_ready = true;
+        }
+        encode_tile<KIND_ALPHA, 0>(s, tl, c);
+        break;
+      case KIND_COLOR: encode_tile<KIND_COLOR, 0>(s, tl, c); break;
+      case KIND_SCALE: encode_tile<KIND_SCALE, 0>(s, tl, c); break;
+      case KIND_ROT_S3: encode_tile<KIND_ROT_S3, 0>(s, tl, c); break;
+      case KIND_ROT_F3: encode_tile<KIND_ROT_F3, 0>(s, tl, c); break;
+      case KIND_SH: encode_tile_sh_dispatch<KIND_SH>(s, tl, c, p.sh_d); break;
+      default: break;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// Standalone in-place convertCoordinates (splat-types.h:134-164)
+// ------------------------------------------------------------------------------------------
+template <int KIND, int D>
+__device__ __forceinline__ F32x4 flip_unit(F32x4 v, uint32_t phase, const KParams &p) {
+  uint32_t sb;
+  if constexpr (KIND == KIND_FLIP_POS) sb = pos_sign_bits(p.flip_p, phase);
+  else if constexpr (KIND == KIND_FLIP_ROT) sb = p.flip_q & 7u;
+  else sb = (uint32_t)(p.sh_mask_ext >> phase) & 0xfu;
+  F32x4 o;
+  o.x = mul_pm1(v.x, sb & 1u);
+  o.y = mul_pm1(v.y, (sb >> 1) & 1u);
+  o.z = mul_pm1(v.z, (sb >> 2) & 1u);
+  o.w = (KIND == KIND_FLIP_ROT) ? v.w : mul_pm1(v.w, (sb >> 3) & 1u);  // w is never touched (:146)
+  return o;
+}
+
+template <int KIND, int D>
+__device__ __forceinline__ void flip_tile(const SecDesc &s, uint32_t tile_local, const KParams &p) {
+  const unsigned long long base = (unsigned long long)tile_local * kTileUnits;
+  const uint32_t tid = threadIdx.x;
+  float *buf = s.floats;
+  const unsigned long long full_units = s.n_elems >> 2;
+  const uint32_t pb = tile_phase_base<KIND, D>(tile_local);
+#pragma unroll
+  for (int r = 0; r < kUnroll; ++r) {
+    const uint32_t local = (uint32_t)(r * kBlock) + tid;
+    const unsigned long long u = base + local;
+    const uint32_t ph = unit_phase<KIND, D>(pb, local);
+    if (u < full_units) {
+      store_f4(buf, u, flip_unit<KIND, D>(load_f4(buf, u), ph, p));
+    } else if (u < s.n_units) {
+      const uint32_t m = (uint32_t)(s.n_elems - u * 4ull);
+      float *q = buf + u * 4ull;
+      F32x4 v;
+      v.x = q[0];
+      v.y = (m > 1) ? q[1] : 0.0f;
+      v.z = (m > 2) ? q[2] : 0.0f;
+      v.w = 0.0f;
+      F32x4 o = flip_unit<KIND, D>(v, ph, p);
+      q[0] = o.x;
+      if (m > 1) q[1] = o.y;
+      if (m > 2) q[2] = o.z;
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlock) void spz_flip_kernel(const KParams p) {
+  for (uint32_t tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+    const uint32_t si = find_section(p, tile);
+    const SecDesc &s = p.sec[si];
+    const uint32_t tl = tile - s.tile_begin;
+    switch (s.kind) {
+      case KIND_FLIP_POS: flip_tile<KIND_FLIP_POS, 0>(s, tl, p); break;
+      case KIND_FLIP_ROT: flip_tile<KIND_FLIP_ROT, 0>(s, tl, p); break;
+      case KIND_FLIP_SH:
+        if (p.sh_d == 45u) flip_tile<KIND_FLIP_SH, 45>(s, tl, p);
+        else if (p.sh_d == 24u) flip_tile<KIND_FLIP_SH, 24>(s, tl, p);
+        else flip_tile<KIND_FLIP_SH, 9>(s, tl, p);
+        break;
+      default: break;
+    }
+  }
+}
+
+// ==========================================================================================
+// Host side
+// ==========================================================================================
+thread_local int g_last_hip_error = 0;
+
+#define SPZ_HIP_TRY(expr)                            \
+  do {                                               \
+    hipError_t e_ = (expr);                          \
+    if (e_ != hipSuccess) {                          \
+      g_last_hip_error = (int)e_;                    \
+      return SPZ_AMD_ERR_HIP;                        \
+    }                                                \
+  } while (0)
+
+constexpr uint32_t kMagic = 0x5053474eu;  // load-spz.cc:132
+constexpr int kMaxDevices = 64;
+
+int sh_dim_for_degree(int d) {  // load-spz.cc:58-72
+  switch (d) {
+    case 0: return 0;
+    case 1: return 3;
+    case 2: return 8;
+    case 3: return 15;
+    default: return -1;
+  }
+}
+
+// axesMatch + coordinateConverter (splat-types.h:43-81) reduced to sign masks.
+struct FlipMasks {
+  uint32_t p;           // bit a: axis a negated
+  uint32_t q;           // bit i: quaternion x/y/z negated
+  uint32_t sh15;        // bit k: sh coefficient k negated
+};
+
+FlipMasks flip_masks(int from, int to) {
+  FlipMasks m = {0, 0, 0};
+  int a = from - 1, b = to - 1;
+  if (a < 0 || b < 0) return m;
+  const uint32_t x = (((a >> 0) & 1) != ((b >> 0) & 1)) ? 1u : 0u;  // 1 = negative
+  const uint32_t y = (((a >> 1) & 1) != ((b >> 1) & 1)) ? 1u : 0u;
+  const uint32_t z = (((a >> 2) & 1) != ((b >> 2) & 1)) ? 1u : 0u;
+  m.p = x | (y << 1) | (z << 2);
+  m.q = (y ^ z) | ((x ^ z) << 1) | ((x ^ y) << 2);
+  // flipSh = {y, z, x, xy, yz, 1, xz, 1, y, xyz, y, z, x, z, x}
+  const uint32_t sh[15] = {y, z, x, x ^ y, y ^ z, 0, x ^ z, 0, y, x ^ y ^ z, y, z, x, z, x};
+  for (int k = 0; k < 15; ++k) m.sh15 |= sh[k] << k;
+  return m;
+}
+
+// Per-element mask over a point's D = 3*shDim sh floats, with elements 0..2 repeated at D..D+2
+// so that a 4-element window starting anywhere in [0, D) can be read with one shift.
+unsigned long long sh_elem_mask_ext(uint32_t sh15, int sh_dim) {
+  unsigned long long m = 0;
+  const int D = sh_dim * 3;
+  for (int j = 0; j < D; ++j) {
+    if ((sh15 >> (j / 3)) & 1u) m |= 1ull << j;
+  }
+  if (D > 0) m |= (m & 7ull) << D;
+  return m;
+}
+
+// ---- tables -----------------------------------------------------------------------------
+struct Tables {
+  float host[kTableFloats];
+  float *dev[kMaxDevices];
+  bool host_ready;
+};
+Tables g_tables = {};
+std::mutex g_tables_mutex;
+
+// The reference's own expressions (load-spz.cc:74,85,87,301,518,522), evaluated with the host
+// libm the reference itself links against; volatile stops the host compiler from folding or
+// contracting anything.
+float ref_sigmoid_host(float x) {
+  volatile float e = std::exp(-x);
+  volatile float d = 1 + e;
+  volatile float s = 1 / d;
+  return s;
+}
+uint8_t ref_alpha_byte_host(float a) {
+  volatile float t = ref_sigmoid_host(a) * 255.0f;
+  float r = std::round(t);
+  r = (r < 0.0f) ? 0.0f : ((255.0f < r) ? 255.0f : r);
+  return (uint8_t)(int)r;
+}
+uint32_t float_key(float f) {  // monotone map float -> uint32 (total order)
+  uint32_t b;
+  std::memcpy(&b, &f, 4);
+  return (b >> 31) ? ~b : (b | 0x80000000u);
+}
+float key_float(uint32_t k) {
+  uint32_t b = (k >> 31) ? (k & 0x7fffffffu) : ~k;
+  float f;
+  std::memcpy(&f, &b, 4);
+  return f;
+}
+
+void build_host_tables() {
+  float *t = g_tables.host;
+  for (int b = 0; b < 256; ++b) {
+    volatile float x = b / 255.0f;
+    volatile float om = 1.0f - x;
+    volatile float ratio = x / om;
+    t[kTableAlphaDec + b] = std::log(ratio);  // invSigmoid, load-spz.cc:87
+    volatile float c0 = x - 0.5f;
+    t[kTableColorDec + b] = c0 / 0.15f;       // load-spz.cc:522
+  }
+  // thresholds: thr[v-1] = smallest float a (total order) with alpha_byte(a) >= v
+  const uint32_t klo = float_key(-INFINITY), khi = float_key(INFINITY);
+  for (int v = 1; v <= 255; ++v) {
+    uint32_t lo = klo, hi = khi;  // byte(lo) = 0 < v <= 255 = byte(hi)
+    while (hi - lo > 1) {
+      uint32_t mid = lo + (hi - lo) / 2;
+      if (ref_alpha_byte_host(key_float(mid)) >= v) hi = mid;
+      else lo = mid;
+    }
+    t[kTableAlphaThr + v - 1] = key_float(hi);
+  }
+  t[kTableAlphaThr + 255] = NAN;
+  g_tables.host_ready = true;
+}
+
+int ensure_tables(int device, const float **dev_tables) {
+  if (device < 0 || device >= kMaxDevices) return SPZ_AMD_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(g_tables_mutex);
+  if (!g_tables.host_ready) build_host_tables();
+  if (g_tables.dev[device] == nullptr) {
+    float *d = nullptr;
+    SPZ_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), sizeof(float) * kTableFloats));
+    hipError_t e = hipMemcpy(d, g_tables.host, sizeof(float) * kTableFloats, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+      g_last_hip_error = (int)e;
+      (void)hipFree(d);
+      return SPZ_AMD_ERR_HIP;
+    }
+    g_tables.dev[device] = d;
+  }
+  *dev_tables = g_tables.dev[device];
+  return SPZ_AMD_OK;
+}
+
+int current_device(int *device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_last_hip_error = (int)e;
+    return SPZ_AMD_ERR_NO_DEVICE;
+  }
+  SPZ_HIP_TRY(hipGetDevice(device));
+  return SPZ_AMD_OK;
+}
+
+int grid_for(int device, uint32_t total_tiles, uint32_t *grid) {
+  static int cus[kMaxDevices] = {0};
+  if (cus[device] == 0) {
+    int n = 0;
+    SPZ_HIP_TRY(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device));
+    cus[device] = (n > 0) ? n : 256;
+  }
+  uint32_t cap = (uint32_t)cus[device] * kMaxBlocksPerCU;
+  uint32_t g = total_tiles < cap ? total_tiles : cap;
+  *grid = g > 0 ? g : 1;
+  return SPZ_AMD_OK;
+}
+
+uint32_t tiles_for_units(unsigned long long units) {
+  return (uint32_t)((units + kTileUnits - 1) / kTileUnits);
+}
+
+// Appends a section to the fused grid (skips empty ones).
+void add_section(KParams *p, uint32_t kind, uint8_t *bytes, float *floats, unsigned long long n_elems) {
+  if (n_elems == 0) return;
+  SecDesc &s = p->sec[p->n_sec++];
+  s.bytes = bytes;
+  s.floats = floats;
+  s.n_elems = n_elems;
+  s.n_units = (n_elems + 3) / 4;
+  s.tile_begin = p->total_tiles;
+  s.kind = kind;
+  p->total_tiles += tiles_for_units(s.n_units);
+}
+
+bool valid_coord(int c) { return c >= 0 && c <= 8; }
+
+int layout_impl(uint64_t n, int sh_degree, int version, spz_amd_layout *out) {
+  const int sd = sh_dim_for_degree(sh_degree);
+  if (sd < 0 || version < 1 || version > 3 || out == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  const uint32_t bpp[SPZ_AMD_NUM_SECTIONS] = {version == 1 ? 6u : 9u, 1u, 3u, 3u, version >= 3 ? 4u : 3u,
+                                               (uint32_t)sd * 3u};
+  uint64_t off = 16;
+  for (int s = 0; s < SPZ_AMD_NUM_SECTIONS; ++s) {
+    out->bytes_per_point[s] = bpp[s];
+    out->offset[s] = off;
+    out->bytes[s] = n * bpp[s];
+    off += out->bytes[s];
+  }
+  out->total_bytes = off;
+  return SPZ_AMD_OK;
+}
+
+int encode_impl(const spz_amd_cloud_in *cl, uint64_t first, uint64_t count, uint64_t n_total, int sh_degree,
+                int antialiased, int from_coord, int version, int write_header, uint8_t *d_stream,
+                size_t capacity, void *hip_stream) {
+  if (cl == nullptr || d_stream == nullptr || !valid_coord(from_coord)) return SPZ_AMD_ERR_INVALID_ARG;
+  if (version == 1) return SPZ_AMD_ERR_UNSUPPORTED;
+  spz_amd_layout lay;
+  int rc = layout_impl(n_total, sh_degree, version, &lay);
+  if (rc != SPZ_AMD_OK) return rc;
+  if (n_total > 0xffffffffull || first > n_total || count > n_total - first) return SPZ_AMD_ERR_INVALID_ARG;
+  if (capacity < lay.total_bytes) return SPZ_AMD_ERR_CAPACITY;
+  const int sd = sh_dim_for_degree(sh_degree);
+  if (count > 0 && (!cl->positions || !cl->scales || !cl->rotations || !cl->alphas || !cl->colors ||
+                    (sd > 0 && !cl->sh))) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  int device = 0;
+  rc = current_device(&device);
+  if (rc != SPZ_AMD_OK) return rc;
+  KParams p = {};
+  rc = ensure_tables(device, &p.tables);
+  if (rc != SPZ_AMD_OK) return rc;
+
+  const FlipMasks fm = flip_masks(from_coord, SPZ_AMD_RUB);  // load-spz.cc:263
+  p.flip_p = fm.p;
+  p.flip_q = fm.q;
+  p.sh_mask_ext = sh_elem_mask_ext(fm.sh15, sd);
+  p.sh_d = (uint32_t)sd * 3u;
+  p.pos_scale = 0.0f;
+  auto frag = [&](int s) { return d_stream + lay.offset[s] + first * lay.bytes_per_point[s]; };
+  auto fl = [](const float *q) { return const_cast<float *>(q); };
+  // Largest sections first so the tail of the grid is made of the small ones.
+  add_section(&p, KIND_SH, frag(SPZ_AMD_SEC_SH), fl(cl->sh), count * (uint64_t)sd * 3u);
+  add_section(&p, KIND_POS24, frag(SPZ_AMD_SEC_POSITIONS), fl(cl->positions), count * 3u);
+  add_section(&p, version >= 3 ? KIND_ROT_S3 : KIND_ROT_F3, frag(SPZ_AMD_SEC_ROTATIONS), fl(cl->rotations),
+              count * 4u);
+  add_section(&p, KIND_SCALE, frag(SPZ_AMD_SEC_SCALES), fl(cl->scales), count * 3u);
+  add_section(&p, KIND_COLOR, frag(SPZ_AMD_SEC_COLORS), fl(cl->colors), count * 3u);
+  add_section(&p, KIND_ALPHA, frag(SPZ_AMD_SEC_ALPHAS), fl(cl->alphas), count);
+  if (write_header) {
+    p.header_dst = d_stream;
+    p.header_words[0] = kMagic;
+    p.header_words[1] = (uint32_t)version;
+    p.header_words[2] = (uint32_t)n_total;
+    p.header_words[3] = (uint32_t)sh_degree | (12u << 8) | ((antialiased ? 1u : 0u) << 16);
+  }
+  if (p.total_tiles == 0 && !write_header) return SPZ_AMD_OK;
+  uint32_t grid = 1;
+  rc = grid_for(device, p.total_tiles, &grid);
+  if (rc != SPZ_AMD_OK) return rc;
+  hipLaunchKernelGGL(spz_encode_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(hip_stream), p);
+  SPZ_HIP_TRY(hipGetLastError());
+  return SPZ_AMD_OK;
+}
+
+int check_header_fields(const spz_amd_header *h) {
+  if (h == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  if (h->version < 1 || h->version > 3) return SPZ_AMD_ERR_VERSION;
+  if (h->sh_degree > 3) return SPZ_AMD_ERR_SH_DEGREE;
+  return SPZ_AMD_OK;
+}
+
+int decode_impl(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr, uint64_t first, uint64_t count,
+                int to_coord, const spz_amd_cloud_out *cl, void *hip_stream) {
+  if (d_stream == nullptr || cl == nullptr || !valid_coord(to_coord)) return SPZ_AMD_ERR_INVALID_ARG;
+  int rc = check_header_fields(hdr);
+  if (rc != SPZ_AMD_OK) return rc;
+  const uint64_t n_total = hdr->num_points;
+  if (first > n_total || count > n_total - first) return SPZ_AMD_ERR_INVALID_ARG;
+  spz_amd_layout lay;
+  rc = layout_impl(n_total, hdr->sh_degree, (int)hdr->version, &lay);
+  if (rc != SPZ_AMD_OK) return rc;
+  if (size < lay.total_bytes) return SPZ_AMD_ERR_SHORT_STREAM;  // load-spz.cc:591-594
+  const int sd = sh_dim_for_degree(hdr->sh_degree);
+  if (count > 0 && (!cl->positions || !cl->scales || !cl->rotations || !cl->alphas || !cl->colors ||
+                    (sd > 0 && !cl->sh))) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  if (count == 0) return SPZ_AMD_OK;
+  int device = 0;
+  rc = current_device(&device);
+  if (rc != SPZ_AMD_OK) return rc;
+  KParams p = {};
+  rc = ensure_tables(device, &p.tables);
+  if (rc != SPZ_AMD_OK) return rc;
+
+  const FlipMasks fm = flip_masks(SPZ_AMD_RUB, to_coord);  // load-spz.cc:529
+  p.flip_p = fm.p;
+  p.flip_q = fm.q;
+  p.sh_mask_ext = sh_elem_mask_ext(fm.sh15, sd);
+  p.sh_d = (uint32_t)sd * 3u;
+  // float scale = 1.0 / (1 << fractionalBits) (load-spz.cc:495); x86 masks the shift count to 5 bits
+  p.pos_scale = (float)(1.0 / (double)(int32_t)(1u << (hdr->fractional_bits & 31)));
+  auto frag = [&](int s) { return const_cast<uint8_t *>(d_stream) + lay.offset[s] + first * lay.bytes_per_point[s]; };
+  add_section(&p, KIND_SH, frag(SPZ_AMD_SEC_SH), cl->sh, count * (uint64_t)sd * 3u);
+  add_section(&p, hdr->version == 1 ? KIND_POS16 : KIND_POS24, frag(SPZ_AMD_SEC_POSITIONS), cl->positions,
+              count * 3u);
+  add_section(&p, hdr->version >= 3 ? KIND_ROT_S3 : KIND_ROT_F3, frag(SPZ_AMD_SEC_ROTATIONS), cl->rotations,
+              count * 4u);
+  add_section(&p, KIND_SCALE, frag(SPZ_AMD_SEC_SCALES), cl->scales, count * 3u);
+  add_section(&p, KIND_COLOR, frag(SPZ_AMD_SEC_COLORS), cl->colors, count * 3u);
+  add_section(&p, KIND_ALPHA, frag(SPZ_AMD_SEC_ALPHAS), cl->alphas, count);
+  uint32_t grid = 1;
+  rc = grid_for(device, p.total_tiles, &grid);
+  if (rc != SPZ_AMD_OK) return rc;
+  hipLaunchKernelGGL(spz_decode_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(hip_stream), p);
+  SPZ_HIP_TRY(hipGetLastError());
+  return SPZ_AMD_OK;
+}
+
+// RAII device buffer for the *_host entry points.
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(size_t bytes) {
+    if (bytes == 0) return SPZ_AMD_OK;
+    SPZ_HIP_TRY(hipMalloc(&p, bytes));
+    return SPZ_AMD_OK;
+  }
+};
+
+struct DeviceGuard {
+  int prev = -1;
+  bool active = false;
+  int enter(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+      g_last_hip_error = (int)e;
+      return SPZ_AMD_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) return SPZ_AMD_ERR_INVALID_ARG;
+    SPZ_HIP_TRY(hipGetDevice(&prev));
+    SPZ_HIP_TRY(hipSetDevice(device));
+    active = true;
+    return SPZ_AMD_OK;
+  }
+  ~DeviceGuard() {
+    if (active && prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+}  // namespace
+
+// ==========================================================================================
+// C ABI
+// ==========================================================================================
+extern "C" {
+
+int spz_amd_abi_version(void) { return SPZ_AMD_ABI_VERSION; }
+
+const char *spz_amd_status_string(int status) {
+  switch (status) {
+    case SPZ_AMD_OK: return "ok";
+    case SPZ_AMD_ERR_INVALID_ARG: return "invalid argument";
+    case SPZ_AMD_ERR_HEADER_NOT_FOUND: return "header not found";
+    case SPZ_AMD_ERR_VERSION: return "version not supported";
+    case SPZ_AMD_ERR_TOO_MANY_POINTS: return "too many points";
+    case SPZ_AMD_ERR_SH_DEGREE: return "unsupported SH degree";
+    case SPZ_AMD_ERR_SHORT_STREAM: return "read error";
+    case SPZ_AMD_ERR_CAPACITY: return "output buffer too small";
+    case SPZ_AMD_ERR_NO_DEVICE: return "no usable HIP device";
+    case SPZ_AMD_ERR_HIP: return "HIP runtime error";
+    case SPZ_AMD_ERR_UNSUPPORTED: return "unsupported operation";
+    default: return "unknown status";
+  }
+}
+
+int spz_amd_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    return 0;
+  }
+  return n;
+}
+
+int spz_amd_last_hip_error(void) { return g_last_hip_error; }
+
+int spz_amd_stream_layout(uint64_t num_points, int sh_degree, int version, spz_amd_layout *out) {
+  return layout_impl(num_points, sh_degree, version, out);
+}
+
+int spz_amd_write_header(const spz_amd_header *hdr, uint8_t out16[16]) {
+  if (hdr == nullptr || out16 == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  const uint32_t w[3] = {kMagic, hdr->version, hdr->num_points};
+  for (int i = 0; i < 12; ++i) out16[i] = (uint8_t)(w[i >> 2] >> ((i & 3) * 8));
+  out16[12] = hdr->sh_degree;
+  out16[13] = hdr->fractional_bits;
+  out16[14] = hdr->flags;
+  out16[15] = hdr->reserved;
+  return SPZ_AMD_OK;
+}
+
+int spz_amd_peek_header_ex(const uint8_t *stream, size_t size, uint64_t max_points, spz_amd_header *out) {
+  if (out == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  if (stream == nullptr) return size == 0 ? SPZ_AMD_ERR_HEADER_NOT_FOUND : SPZ_AMD_ERR_INVALID_ARG;
+  auto u32 = [&](int o) {
+    return (uint32_t)stream[o] | ((uint32_t)stream[o + 1] << 8) | ((uint32_t)stream[o + 2] << 16) |
+           ((uint32_t)stream[o + 3] << 24);
+  };
+  if (size < 16 || u32(0) != kMagic) return SPZ_AMD_ERR_HEADER_NOT_FOUND;
+  spz_amd_header h;
+  h.version = u32(4);
+  h.num_points = u32(8);
+  h.sh_degree = stream[12];
+  h.fractional_bits = stream[13];
+  h.flags = stream[14];
+  h.reserved = stream[15];
+  if (h.version < 1 || h.version > 3) return SPZ_AMD_ERR_VERSION;
+  if (max_points != 0 && h.num_points > max_points) return SPZ_AMD_ERR_TOO_MANY_POINTS;
+  if (h.sh_degree > 3) return SPZ_AMD_ERR_SH_DEGREE;
+  spz_amd_layout lay;
+  int rc = layout_impl(h.num_points, h.sh_degree, (int)h.version, &lay);
+  if (rc != SPZ_AMD_OK) return rc;
+  if (size < lay.total_bytes) return SPZ_AMD_ERR_SHORT_STREAM;
+  *out = h;
+  return SPZ_AMD_OK;
+}
+
+int spz_amd_peek_header(const uint8_t *stream, size_t size, spz_amd_header *out) {
+  return spz_amd_peek_header_ex(stream, size, SPZ_AMD_REFERENCE_MAX_POINTS, out);
+}
+
+int spz_amd_encode_device(const spz_amd_cloud_in *d_cloud, uint64_t num_points, int sh_degree, int antialiased,
+                          int from_coord, int version, uint8_t *d_stream, size_t capacity, void *hip_stream) {
+  return encode_impl(d_cloud, 0, num_points, num_points, sh_degree, antialiased, from_coord, version, 1, d_stream,
+                     capacity, hip_stream);
+}
+
+int spz_amd_encode_shard_device(const spz_amd_cloud_in *d_cloud, uint64_t first, uint64_t count,
+                                uint64_t num_points_total, int sh_degree, int antialiased, int from_coord,
+                                int version, int write_header, uint8_t *d_stream, size_t capacity,
+                                void *hip_stream) {
+  return encode_impl(d_cloud, first, count, num_points_total, sh_degree, antialiased, from_coord, version,
+                     write_header, d_stream, capacity, hip_stream);
+}
+
+int spz_amd_decode_device(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr, int to_coord,
+                          const spz_amd_cloud_out *d_cloud, void *hip_stream) {
+  if (hdr == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  return decode_impl(d_stream, size, hdr, 0, hdr->num_points, to_coord, d_cloud, hip_stream);
+}
+
+int spz_amd_decode_shard_device(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr, uint64_t first,
+                                uint64_t count, int to_coord, const spz_amd_cloud_out *d_cloud,
+                                void *hip_stream) {
+  return decode_impl(d_stream, size, hdr, first, count, to_coord, d_cloud, hip_stream);
+}
+
+int spz_amd_convert_coordinates_device(float *d_positions, float *d_rotations, float *d_sh, uint64_t num_points,
+                                       int sh_degree, int from_coord, int to_coord, void *hip_stream) {
+  const int sd = sh_dim_for_degree(sh_degree);
+  if (sd < 0 || !valid_coord(from_coord) || !valid_coord(to_coord)) return SPZ_AMD_ERR_INVALID_ARG;
+  if (num_points == 0) return SPZ_AMD_OK;  // splat-types.h:135-138
+  int device = 0;
+  int rc = current_device(&device);
+  if (rc != SPZ_AMD_OK) return rc;
+  KParams p = {};
+  const FlipMasks fm = flip_masks(from_coord, to_coord);
+  p.flip_p = fm.p;
+  p.flip_q = fm.q;
+  p.sh_mask_ext = sh_elem_mask_ext(fm.sh15, sd);
+  p.sh_d = (uint32_t)sd * 3u;
+  if (d_sh) add_section(&p, KIND_FLIP_SH, nullptr, d_sh, num_points * (uint64_t)sd * 3u);
+  if (d_positions) add_section(&p, KIND_FLIP_POS, nullptr, d_positions, num_points * 3u);
+  if (d_rotations) add_section(&p, KIND_FLIP_ROT, nullptr, d_rotations, num_points * 4u);
+  if (p.total_tiles == 0) return SPZ_AMD_OK;
+  uint32_t grid = 1;
+  rc = grid_for(device, p.total_tiles, &grid);
+  if (rc != SPZ_AMD_OK) return rc;
+  hipLaunchKernelGGL(spz_flip_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(hip_stream), p);
+  SPZ_HIP_TRY(hipGetLastError());
+  return SPZ_AMD_OK;
+}
+
+int spz_amd_encode_host(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int antialiased, int from_coord,
+                        int version, uint8_t *h_stream, size_t capacity, int device) {
+  if (h == nullptr || h_stream == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  spz_amd_layout lay;
+  int rc = layout_impl(n, sh_degree, version, &lay);
+  if (rc != SPZ_AMD_OK) return rc;
+  if (version == 1) return SPZ_AMD_ERR_UNSUPPORTED;
+  if (capacity < lay.total_bytes) return SPZ_AMD_ERR_CAPACITY;
+  const int sd = sh_dim_for_degree(sh_degree);
+  if (n > 0 && (!h->positions || !h->scales || !h->rotations || !h->alphas || !h->colors || (sd > 0 && !h->sh))) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  DeviceGuard guard;
+  rc = guard.enter(device);
+  if (rc != SPZ_AMD_OK) return rc;
+  const size_t cnt[6] = {n * 3, n * 3, n * 4, n, n * 3, n * (size_t)sd * 3};
+  const float *src[6] = {h->positions, h->scales, h->rotations, h->alphas, h->colors, h->sh};
+  DevBuf fb[6], sb;
+  for (int i = 0; i < 6; ++i) {
+    rc = fb[i].alloc(cnt[i] * sizeof(float));
+    if (rc != SPZ_AMD_OK) return rc;
+    if (cnt[i]) SPZ_HIP_TRY(hipMemcpyAsync(fb[i].p, src[i], cnt[i] * sizeof(float), hipMemcpyHostToDevice, nullptr));
+  }
+  rc = sb.alloc(lay.total_bytes);
+  if (rc != SPZ_AMD_OK) return rc;
+  spz_amd_cloud_in d = {(const float *)fb[0].p, (const float *)fb[1].p, (const float *)fb[2].p,
+                        (const float *)fb[3].p, (const float *)fb[4].p, (const float *)fb[5].p};
+  rc = encode_impl(&d, 0, n, n, sh_degree, antialiased, from_coord, version, 1, (uint8_t *)sb.p, lay.total_bytes,
+                   nullptr);
+  if (rc != SPZ_AMD_OK) return rc;
+  SPZ_HIP_TRY(hipMemcpy(h_stream, sb.p, lay.total_bytes, hipMemcpyDeviceToHost));
+  return SPZ_AMD_OK;
+}
+
+int spz_amd_decode_host(const uint8_t *h_stream, size_t size, int to_coord, const spz_amd_cloud_out *h,
+                        int device) {
+  if (h_stream == nullptr || h == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  spz_amd_header hdr;
+  int rc = spz_amd_peek_header(h_stream, size, &hdr);
+  if (rc != SPZ_AMD_OK) return rc;
+  const uint64_t n = hdr.num_points;
+  if (n == 0) return SPZ_AMD_OK;
+  spz_amd_layout lay;
+  rc = layout_impl(n, hdr.sh_degree, (int)hdr.version, &lay);
+  if (rc != SPZ_AMD_OK) return rc;
+  const int sd = sh_dim_for_degree(hdr.sh_degree);
+  if (!h->positions || !h->scales || !h->rotations || !h->alphas || !h->colors || (sd > 0 && !h->sh)) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  DeviceGuard guard;
+  rc = guard.enter(device);
+  if (rc != SPZ_AMD_OK) return rc;
+  const size_t cnt[6] = {n * 3, n * 3, n * 4, n, n * 3, n * (size_t)sd * 3};
+  float *dst[6] = {h->positions, h->scales, h->rotations, h->alphas, h->colors, h->sh};
+  DevBuf fb[6], sb;
+  rc = sb.alloc(lay.total_bytes);
+  if (rc != SPZ_AMD_OK) return rc;
+  SPZ_HIP_TRY(hipMemcpyAsync(sb.p, h_stream, lay.total_bytes, hipMemcpyHostToDevice, nullptr));
+  for (int i = 0; i < 6; ++i) {
+    rc = fb[i].alloc(cnt[i] * sizeof(float));
+    if (rc != SPZ_AMD_OK) return rc;
+  }
+  spz_amd_cloud_out d = {(float *)fb[0].p, (float *)fb[1].p, (float *)fb[2].p,
+                         (float *)fb[3].p, (float *)fb[4].p, (float *)fb[5].p};
+  rc = decode_impl((const uint8_t *)sb.p, lay.total_bytes, &hdr, 0, n, to_coord, &d, nullptr);
+  if (rc != SPZ_AMD_OK) return rc;
+  for (int i = 0; i < 6; ++i) {
+    if (cnt[i]) SPZ_HIP_TRY(hipMemcpyAsync(dst[i], fb[i].p, cnt[i] * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+  }
+  SPZ_HIP_TRY(hipStreamSynchronize(nullptr));
+  return SPZ_AMD_OK;
+}
+
+int spz_amd_convert_coordinates_host(float *h_positions, float *h_rotations, float *h_sh, uint64_t n,
+                                     int sh_degree, int from_coord, int to_coord, int device) {
+  const int sd = sh_dim_for_degree(sh_degree);
+  if (sd < 0 || !valid_coord(from_coord) || !valid_coord(to_coord)) return SPZ_AMD_ERR_INVALID_ARG;
+  if (n == 0) return SPZ_AMD_OK;
+  DeviceGuard guard;
+  int rc = guard.enter(device);
+  if (rc != SPZ_AMD_OK) return rc;
+  const size_t cnt[3] = {n * 3, n * 4, n * (size_t)sd * 3};
+  float *hp[3] = {h_positions, h_rotations, h_sh};
+  DevBuf b[3];
+  for (int i = 0; i < 3; ++i) {
+    if (!hp[i] || !cnt[i]) continue;
+    rc = b[i].alloc(cnt[i] * sizeof(float));
+    if (rc != SPZ_AMD_OK) return rc;
+    SPZ_HIP_TRY(hipMemcpyAsync(b[i].p, hp[i], cnt[i] * sizeof(float), hipMemcpyHostToDevice, nullptr));
+  }
+  rc = spz_amd_convert_coordinates_device((float *)b[0].p, (float *)b[1].p, (float *)b[2].p, n, sh_degree,
+                                          from_coord, to_coord, nullptr);
+  if (rc != SPZ_AMD_OK) return rc;
+  for (int i = 0; i < 3; ++i) {
+    if (b[i].p) SPZ_HIP_TRY(hipMemcpyAsync(hp[i], b[i].p, cnt[i] * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+  }
+  SPZ_HIP_TRY(hipStreamSynchronize(nullptr));
+  return SPZ_AMD_OK;
+}
+
+int spz_amd_get_tables(float alpha_decode[256], float color_decode[256], float alpha_thresholds[255]) {
+  std::lock_guard<std::mutex> lock(g_tables_mutex);
+  if (!g_tables.host_ready) build_host_tables();
+  if (alpha_decode) std::memcpy(alpha_decode, g_tables.host + kTableAlphaDec, 256 * sizeof(float));
+  if (color_decode) std::memcpy(color_decode, g_tables.host + kTableColorDec, 256 * sizeof(float));
+  if (alpha_thresholds) std::memcpy(alpha_thresholds, g_tables.host + kTableAlphaThr, 255 * sizeof(float));
+  return SPZ_AMD_OK;
+}
+
+}  // extern "C"

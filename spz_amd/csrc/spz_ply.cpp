@@ -1,0 +1,229 @@
+// spz_ply.cpp — binary little-endian .ply reader/writer for 3DGS splats (host side).
+//
+// Mirrors the behaviour of loadSplatFromPly / saveSplatToPly of the reference
+// (/root/reference/src/cc/load-spz.cc:670-934): same header grammar, same field names, same
+// [N,C,S] <-> [N,S,C] spherical-harmonics transpose, same log lines and failure results.  This is
+// the step on the far side of the hot path; it is file parsing plus an
+// AoS<->SoA shuffle and stays on the host in this round.  The coordinate conversion of a loaded
+// cloud goes through GaussianCloud::convertCoordinates, i.e. the GPU flip pass.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "spz_amd_host.hpp"
+
+namespace spz {
+namespace {
+
+void plyLog(const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  std::vprintf(fmt, ap);
+  va_end(ap);
+  std::printf("\n");
+  std::fflush(stdout);
+}
+
+// Next header line that is neither blank nor a comment, with leading whitespace removed
+// (load-spz.cc:670-689).
+bool nextHeaderLine(std::istream &in, std::string *line) {
+  std::string raw;
+  while (std::getline(in, raw)) {
+    const size_t start = raw.find_first_not_of(" \t\n\r\f\v");
+    if (start == std::string::npos) continue;
+    if (raw.compare(start, 7, "comment") == 0) continue;
+    *line = raw.substr(start);
+    return true;
+  }
+  return false;
+}
+
+bool startsWith(const std::string &s, const char *prefix) { return s.rfind(prefix, 0) == 0; }
+
+int degreeForDim(int dim) {  // load-spz.cc:48-56
+  if (dim < 3) return 0;
+  if (dim < 8) return 1;
+  if (dim < 15) return 2;
+  return 3;
+}
+
+}  // namespace
+
+GaussianCloud loadSplatFromPly(const std::string &filename, const UnpackOptions &o) {
+  plyLog("[SPZ] Loading: %s", filename.c_str());
+  std::ifstream in(filename, std::ios::binary);
+  if (!in.good()) {
+    plyLog("[SPZ ERROR] Unable to open: %s", filename.c_str());
+    return {};
+  }
+  std::string line;
+  std::getline(in, line);
+  if (line != "ply") {
+    plyLog("[SPZ ERROR] %s: not a .ply file", filename.c_str());
+    return {};
+  }
+  if (!nextHeaderLine(in, &line) || line != "format binary_little_endian 1.0") {
+    plyLog("[SPZ ERROR] %s: unsupported .ply format", filename.c_str());
+    return {};
+  }
+  static const char kVertex[] = "element vertex ";
+  if (!nextHeaderLine(in, &line) || !startsWith(line, kVertex)) {
+    plyLog("[SPZ ERROR] %s: missing vertex count", filename.c_str());
+    return {};
+  }
+  int32_t numPoints = 0;
+  try {
+    numPoints = std::stoi(line.substr(sizeof(kVertex) - 1));
+  } catch (...) {
+    numPoints = 0;  // the reference lets std::stoi throw here; report it as an invalid count instead
+  }
+  if (numPoints <= 0 || numPoints > 10 * 1024 * 1024) {
+    plyLog("[SPZ ERROR] %s: invalid vertex count: %d", filename.c_str(), numPoints);
+    return {};
+  }
+  plyLog("[SPZ] Loading %d points", numPoints);
+
+  static const char kProp[] = "property float ";
+  std::map<std::string, int> column;  // property name -> column index
+  for (int i = 0;; ++i) {
+    if (!nextHeaderLine(in, &line)) {
+      plyLog("[SPZ ERROR] %s: unexpected EOF while reading header properties.", filename.c_str());
+      return {};
+    }
+    if (line == "end_header") break;
+    if (!startsWith(line, kProp)) {
+      plyLog("[SPZ ERROR] %s: unsupported property data type: %s", filename.c_str(), line.c_str());
+      return {};
+    }
+    column[line.substr(sizeof(kProp) - 1)] = i;
+  }
+  const size_t stride = column.size();
+
+  bool missing = false;
+  auto col = [&](const char *name) {
+    auto it = column.find(name);
+    if (it == column.end()) {
+      plyLog("[SPZ ERROR] Missing field: %s", name);
+      missing = true;
+      return -1;
+    }
+    return it->second;
+  };
+  const int cPos[3] = {col("x"), col("y"), col("z")};
+  const int cScale[3] = {col("scale_0"), col("scale_1"), col("scale_2")};
+  const int cRot[4] = {col("rot_1"), col("rot_2"), col("rot_3"), col("rot_0")};  // file is wxyz, cloud xyzw
+  const int cAlpha = col("opacity");
+  const int cColor[3] = {col("f_dc_0"), col("f_dc_1"), col("f_dc_2")};
+  if (missing) return {};
+
+  std::vector<int> cRest;  // f_rest_0.. consecutive, optional
+  for (int i = 0; i < 45; ++i) {
+    auto it = column.find("f_rest_" + std::to_string(i));
+    if (it == column.end()) break;
+    cRest.push_back(it->second);
+  }
+  const int shDim = static_cast<int>(cRest.size() / 3);
+
+  std::vector<float> rows(static_cast<size_t>(numPoints) * stride);
+  in.read(reinterpret_cast<char *>(rows.data()), static_cast<std::streamsize>(rows.size() * sizeof(float)));
+  if (!in.good()) {
+    plyLog("[SPZ ERROR] Unable to load data from: %s", filename.c_str());
+    return {};
+  }
+
+  GaussianCloud g;
+  g.numPoints = numPoints;
+  g.shDegree = degreeForDim(shDim);
+  const size_t n = static_cast<size_t>(numPoints);
+  g.positions.resize(n * 3);
+  g.scales.resize(n * 3);
+  g.rotations.resize(n * 4);
+  g.alphas.resize(n);
+  g.colors.resize(n * 3);
+  g.sh.resize(n * static_cast<size_t>(shDim) * 3);
+  for (size_t p = 0; p < n; ++p) {
+    const float *row = rows.data() + p * stride;
+    for (int k = 0; k < 3; ++k) {
+      g.positions[p * 3 + k] = row[cPos[k]];
+      g.scales[p * 3 + k] = row[cScale[k]];
+      g.colors[p * 3 + k] = row[cColor[k]];
+    }
+    for (int k = 0; k < 4; ++k) g.rotations[p * 4 + k] = row[cRot[k]];
+    g.alphas[p] = row[cAlpha];
+    // file: [channel][coeff]  ->  cloud: [coeff][channel]
+    float *sh = g.sh.data() + p * static_cast<size_t>(shDim) * 3;
+    for (int j = 0; j < shDim; ++j) {
+      sh[j * 3 + 0] = row[cRest[j]];
+      sh[j * 3 + 1] = row[cRest[j + shDim]];
+      sh[j * 3 + 2] = row[cRest[j + 2 * shDim]];
+    }
+  }
+  g.convertCoordinates(CoordinateSystem::RDF, o.to);
+  return g;
+}
+
+bool saveSplatToPly(const GaussianCloud &data, const PackOptions &o, const std::string &filename) {
+  const int32_t N = data.numPoints;
+  const size_t n = static_cast<size_t>(N < 0 ? 0 : N);
+  auto sizeOk = [&](const std::vector<float> &v, size_t want, const char *what) {
+    if (v.size() == want) return true;
+    plyLog("[SPZ: ERROR] Check failed: %s:%d: %s", __FILE__, __LINE__, what);
+    return false;
+  };
+  if (!sizeOk(data.positions, n * 3, "data.positions.size() == N * 3") ||
+      !sizeOk(data.scales, n * 3, "data.scales.size() == N * 3") ||
+      !sizeOk(data.rotations, n * 4, "data.rotations.size() == N * 4") ||
+      !sizeOk(data.alphas, n, "data.alphas.size() == N") ||
+      !sizeOk(data.colors, n * 3, "data.colors.size() == N * 3")) {
+    return false;
+  }
+  const int shDim = n ? static_cast<int>(data.sh.size() / n / 3) : 0;
+  const size_t D = 17 + static_cast<size_t>(shDim) * 3;
+  const CoordinateConverter c = coordinateConverter(o.from, CoordinateSystem::RDF);
+
+  std::vector<float> rows(n * D, 0.0f);
+  for (size_t p = 0; p < n; ++p) {
+    float *row = rows.data() + p * D;
+    size_t k = 0;
+    for (int a = 0; a < 3; ++a) row[k++] = c.flipP[a] * data.positions[p * 3 + a];
+    k += 3;  // nx, ny, nz stay zero
+    for (int a = 0; a < 3; ++a) row[k++] = data.colors[p * 3 + a];
+    // cloud: [coeff][channel]  ->  file: [channel][coeff]
+    const float *sh = data.sh.data() + p * static_cast<size_t>(shDim) * 3;
+    for (int ch = 0; ch < 3; ++ch) {
+      for (int j = 0; j < shDim; ++j) row[k++] = c.flipSh[j] * sh[j * 3 + ch];
+    }
+    row[k++] = data.alphas[p];
+    for (int a = 0; a < 3; ++a) row[k++] = data.scales[p * 3 + a];
+    row[k++] = data.rotations[p * 4 + 3];  // w first
+    for (int a = 0; a < 3; ++a) row[k++] = c.flipQ[a] * data.rotations[p * 4 + a];
+  }
+
+  std::ofstream out(filename, std::ios::binary);
+  if (!out.good()) {
+    plyLog("[SPZ ERROR] Unable to open for writing: %s", filename.c_str());
+    return false;
+  }
+  out << "ply\nformat binary_little_endian 1.0\nelement vertex " << N << "\n";
+  for (const char *name : {"x", "y", "z", "nx", "ny", "nz", "f_dc_0", "f_dc_1", "f_dc_2"}) {
+    out << "property float " << name << "\n";
+  }
+  for (int i = 0; i < shDim * 3; ++i) out << "property float f_rest_" << i << "\n";
+  for (const char *name : {"opacity", "scale_0", "scale_1", "scale_2", "rot_0", "rot_1", "rot_2", "rot_3"}) {
+    out << "property float " << name << "\n";
+  }
+  out << "end_header\n";
+  out.write(reinterpret_cast<const char *>(rows.data()), static_cast<std::streamsize>(rows.size() * sizeof(float)));
+  out.close();
+  if (!out.good()) {
+    plyLog("[SPZ ERROR] Failed to write to: %s", filename.c_str());
+    return false;
+  }
+  return true;
+}
+
+}  // namespace spz

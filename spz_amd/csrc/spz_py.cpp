@@ -1,0 +1,254 @@
+// spz_py.cpp — Python module `spz` (imported as spz_amd.spz) over the C++ drop-in layer.
+//
+// Same surface as the reference's nanobind shim (/root/reference/src/python/spz/spz.cc:110-362):
+// CoordinateSystem enum with exported values, PackOptions.from_coord, UnpackOptions.to_coord,
+// GaussianCloud with copying float32 array properties and the shim's validation messages,
+// load_spz / save_spz / load_splat_from_ply / save_splat_to_ply.  nanobind is not available in
+// this image; pybind11 is, so the dtype/ndim gate that nanobind's ndarray caster applies
+// (numeric dtypes convert to float32, anything else -> TypeError "incompatible function
+// arguments") is written out by hand in `toFloatVector`.
+#include <pybind11/numpy.h>
+#include <pybind11/pybind11.h>
+
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "spz_amd.h"
+#include "spz_amd_host.hpp"
+
+namespace py = pybind11;
+
+namespace {
+
+// Accepts what nb::ndarray<numpy, float, ndim<1>, c_contig, device::cpu> accepts: a 1-D array (or
+// array-like) of a bool/int/uint/float dtype, converted to float32.  Everything else is the
+// overload-resolution failure nanobind reports.
+std::vector<float> toFloatVector(const py::object &obj, const char *prop) {
+  auto reject = [&]() {
+    throw py::type_error(std::string("__set__(): incompatible function arguments. ") + prop +
+                         " expects a 1-D numeric numpy array convertible to float32");
+  };
+  py::array arr;
+  try {
+    arr = py::array::ensure(obj);
+  } catch (const py::error_already_set &) {
+    PyErr_Clear();
+  }
+  if (!arr) reject();
+  const char kind = arr.dtype().kind();
+  if (!(kind == 'b' || kind == 'i' || kind == 'u' || kind == 'f')) reject();
+  if (arr.ndim() != 1) reject();
+  py::array_t<float, py::array::c_style | py::array::forcecast> f(arr);
+  std::vector<float> out(static_cast<size_t>(f.size()));
+  if (!out.empty()) std::memcpy(out.data(), f.data(), out.size() * sizeof(float));
+  return out;
+}
+
+// New owning float32 1-D copy (spz.cc:47-79).
+py::array_t<float> toArray(const std::vector<float> &v) {
+  py::array_t<float> a(static_cast<py::ssize_t>(v.size()));
+  if (!v.empty()) std::memcpy(a.mutable_data(), v.data(), v.size() * sizeof(float));
+  return a;
+}
+
+void ensureMultiple(const char *name, size_t size, size_t k) {  // spz.cc:27-37
+  if (k == 0) throw py::value_error("internal error: divisor cannot be zero");
+  if (size % k != 0) {
+    throw py::value_error(std::string(name) + " length must be a multiple of " + std::to_string(k) + ", got " +
+                          std::to_string(size));
+  }
+}
+
+// The product has no CPU fallback: an unusable device is raised, not returned as an empty cloud.
+void raiseIfDeviceUnusable() {
+  const int st = spz::lastDeviceStatus();
+  if (st == SPZ_AMD_ERR_NO_DEVICE || st == SPZ_AMD_ERR_HIP) {
+    throw std::runtime_error(std::string("spz_amd: ") + spz_amd_status_string(st) +
+                             " (the SPZ hot path runs on the GPU only)");
+  }
+}
+
+}  // namespace
+
+PYBIND11_MODULE(spz, m) {
+  m.doc() = "MI355X-native drop-in for the `spz` Python bindings (Gaussian splat .spz codec).";
+
+  py::enum_<spz::CoordinateSystem>(m, "CoordinateSystem",
+                                   "Axis conventions: Right/Left, Up/Down, Front/Back (RDF = PLY, RUB = three.js, "
+                                   "LUF = glTF, RUF = Unity).")
+      .value("UNSPECIFIED", spz::CoordinateSystem::UNSPECIFIED)
+      .value("LDB", spz::CoordinateSystem::LDB)
+      .value("RDB", spz::CoordinateSystem::RDB)
+      .value("LUB", spz::CoordinateSystem::LUB)
+      .value("RUB", spz::CoordinateSystem::RUB)
+      .value("LDF", spz::CoordinateSystem::LDF)
+      .value("RDF", spz::CoordinateSystem::RDF)
+      .value("LUF", spz::CoordinateSystem::LUF)
+      .value("RUF", spz::CoordinateSystem::RUF)
+      .export_values();
+
+  py::class_<spz::PackOptions>(m, "PackOptions")
+      .def(py::init<>())
+      .def_readwrite("from_coord", &spz::PackOptions::from, "Coordinate system of the input splat");
+  py::class_<spz::UnpackOptions>(m, "UnpackOptions")
+      .def(py::init<>())
+      .def_readwrite("to_coord", &spz::UnpackOptions::to, "Desired coordinate system of the output splat");
+
+  using Cloud = spz::GaussianCloud;
+  py::class_<Cloud>(m, "GaussianCloud")
+      .def(py::init<>(), "Construct an empty GaussianCloud.")
+      .def_property_readonly("num_points",
+                             [](const Cloud &c) { return static_cast<int32_t>(c.positions.size() / 3); })
+      .def("__len__", [](const Cloud &c) { return static_cast<int32_t>(c.positions.size() / 3); })
+      .def("__repr__",
+           [](const Cloud &c) {
+             return py::str("GaussianCloud(num_points={}, sh_degree={}, antialiased={})")
+                 .format(static_cast<int32_t>(c.positions.size() / 3), c.shDegree, c.antialiased);
+           })
+      .def_property(
+          "sh_degree", [](const Cloud &c) { return c.shDegree; },
+          [](Cloud &c, int32_t deg) {
+            if (deg < 0 || deg > 3) throw py::value_error("sh_degree must be in [0, 3]");
+            c.shDegree = deg;
+          })
+      .def_readwrite("antialiased", &Cloud::antialiased)
+      .def_property(
+          "positions", [](const Cloud &c) { return toArray(c.positions); },
+          [](Cloud &c, const py::object &o) {
+            std::vector<float> v = toFloatVector(o, "positions");
+            ensureMultiple("positions", v.size(), 3);
+            c.positions = std::move(v);
+            c.numPoints = static_cast<int32_t>(c.positions.size() / 3);  // positions define num_points
+          })
+      .def_property(
+          "scales", [](const Cloud &c) { return toArray(c.scales); },
+          [](Cloud &c, const py::object &o) {
+            std::vector<float> v = toFloatVector(o, "scales");
+            ensureMultiple("scales", v.size(), 3);
+            c.scales = std::move(v);
+            if (c.numPoints > 0 && c.scales.size() != static_cast<size_t>(c.numPoints) * 3) {
+              throw py::value_error("scales length must equal num_points * 3");
+            }
+          })
+      .def_property(
+          "rotations", [](const Cloud &c) { return toArray(c.rotations); },
+          [](Cloud &c, const py::object &o) {
+            std::vector<float> v = toFloatVector(o, "rotations");
+            ensureMultiple("rotations", v.size(), 4);
+            c.rotations = std::move(v);
+            if (c.numPoints > 0 && c.rotations.size() != static_cast<size_t>(c.numPoints) * 4) {
+              throw py::value_error("rotations length must equal num_points * 4");
+            }
+          })
+      .def_property(
+          "alphas", [](const Cloud &c) { return toArray(c.alphas); },
+          [](Cloud &c, const py::object &o) {
+            c.alphas = toFloatVector(o, "alphas");
+            if (c.numPoints > 0 && c.alphas.size() != static_cast<size_t>(c.numPoints)) {
+              throw py::value_error("alphas length must equal num_points");
+            }
+          })
+      .def_property(
+          "colors", [](const Cloud &c) { return toArray(c.colors); },
+          [](Cloud &c, const py::object &o) {
+            std::vector<float> v = toFloatVector(o, "colors");
+            ensureMultiple("colors", v.size(), 3);
+            c.colors = std::move(v);
+            if (c.numPoints > 0 && c.colors.size() != static_cast<size_t>(c.numPoints) * 3) {
+              throw py::value_error("colors length must equal num_points * 3");
+            }
+          })
+      .def_property(
+          "sh", [](const Cloud &c) { return toArray(c.sh); },
+          [](Cloud &c, const py::object &o) {
+            std::vector<float> v = toFloatVector(o, "sh");
+            ensureMultiple("sh", v.size(), 3);
+            const int deg = c.shDegree;
+            const size_t perChannel = (deg == 0) ? 0 : static_cast<size_t>((deg + 1) * (deg + 1) - 1);
+            if (perChannel == 0) {
+              if (!v.empty()) throw py::value_error("sh must be empty when sh_degree == 0");
+            } else {
+              ensureMultiple("sh", v.size(), perChannel * 3);
+            }
+            c.sh = std::move(v);
+            if (c.numPoints > 0 && c.sh.size() != static_cast<size_t>(c.numPoints) * perChannel * 3) {
+              throw py::value_error("sh length must equal num_points * ((sh_degree+1)^2 - 1) * 3");
+            }
+          })
+      .def("convert_coordinates",
+           [](Cloud &c, spz::CoordinateSystem from, spz::CoordinateSystem to) {
+             c.convertCoordinates(from, to);
+             if (c.numPoints) raiseIfDeviceUnusable();
+           },
+           py::arg("from_coord"), py::arg("to_coord"), "Convert between two coordinate systems in-place.")
+      .def("rotate_180_deg_about_x",
+           [](Cloud &c) {
+             c.rotate180DegAboutX();
+             if (c.numPoints) raiseIfDeviceUnusable();
+           },
+           "RUB <-> RDF conversion (180 degrees about X).")
+      .def("median_volume", &Cloud::medianVolume, "Return the median Gaussian volume.");
+
+  m.def("load_spz",
+        [](const std::string &filename, const spz::UnpackOptions &o) {
+          spz::GaussianCloud g = spz::loadSpz(filename, o);
+          if (g.numPoints == 0) raiseIfDeviceUnusable();
+          return g;
+        },
+        py::arg("filename"), py::arg("options") = spz::UnpackOptions(), "Load a *.spz* file and return a GaussianCloud.");
+  m.def("save_spz",
+        [](const spz::GaussianCloud &g, const spz::PackOptions &o, const std::string &filename) {
+          const bool ok = spz::saveSpz(g, o, filename);
+          if (!ok) raiseIfDeviceUnusable();
+          return ok;
+        },
+        py::arg("gaussians"), py::arg("options"), py::arg("filename"), "Save a GaussianCloud to a *.spz* file.");
+  // Extras of this implementation (underscore-prefixed: not part of the reference surface).
+  m.def("_compress_gzipped", [](const py::bytes &data) {
+    const std::string in = data;
+    std::vector<uint8_t> out;
+    if (!spz::compressGzipped(reinterpret_cast<const uint8_t *>(in.data()), in.size(), &out)) {
+      throw std::runtime_error("compressGzipped failed");
+    }
+    return py::bytes(reinterpret_cast<const char *>(out.data()), out.size());
+  }, "gzip wrapper of saveSpz (host zlib, parameters of load-spz.cc:190).");
+  m.def("_decompress_gzipped", [](const py::bytes &data) -> py::object {
+    const std::string in = data;
+    std::vector<uint8_t> out;
+    if (!spz::decompressGzipped(reinterpret_cast<const uint8_t *>(in.data()), in.size(), &out)) return py::none();
+    return py::bytes(reinterpret_cast<const char *>(out.data()), out.size());
+  }, "Inverse of _compress_gzipped; None on failure.");
+  m.def("_save_spz_bytes", [](const spz::GaussianCloud &g, const spz::PackOptions &o) -> py::object {
+    std::vector<uint8_t> out;
+    if (!spz::saveSpz(g, o, &out)) {
+      raiseIfDeviceUnusable();
+      return py::none();
+    }
+    return py::bytes(reinterpret_cast<const char *>(out.data()), out.size());
+  }, py::arg("gaussians"), py::arg("options"), "saveSpz(cloud, options, &vector) -> .spz bytes in memory.");
+  m.def("_load_spz_bytes", [](const py::bytes &data, const spz::UnpackOptions &o) {
+    const std::string in = data;
+    spz::GaussianCloud g = spz::loadSpz(reinterpret_cast<const uint8_t *>(in.data()),
+                                        static_cast<int32_t>(in.size()), o);
+    if (g.numPoints == 0) raiseIfDeviceUnusable();
+    return g;
+  }, py::arg("data"), py::arg("options") = spz::UnpackOptions(), "loadSpz(ptr, size, options) from .spz bytes.");
+  m.def("_pack_to_stream", [](const spz::GaussianCloud &g, const spz::PackOptions &o) -> py::object {
+    std::vector<uint8_t> out;
+    if (!spz::packToStream(g, o, &out)) {
+      raiseIfDeviceUnusable();
+      return py::none();
+    }
+    return py::bytes(reinterpret_cast<const char *>(out.data()), out.size());
+  }, py::arg("gaussians"), py::arg("options"), "Raw (pre-gzip) stream of a cloud.");
+
+  m.def("load_splat_from_ply",
+        [](const std::string &filename, const spz::UnpackOptions &o) { return spz::loadSplatFromPly(filename, o); },
+        py::arg("filename"), py::arg("options") = spz::UnpackOptions(), "Read GaussianCloud data from a *.ply* file.");
+  m.def("save_splat_to_ply",
+        [](const spz::GaussianCloud &g, const spz::PackOptions &o, const std::string &filename) {
+          return spz::saveSplatToPly(g, o, filename);
+        },
+        py::arg("gaussians"), py::arg("options"), py::arg("filename"), "Write GaussianCloud data to a *.ply* file.");
+}

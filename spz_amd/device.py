@@ -1,0 +1,128 @@
+"""Device-resident encode / decode over the C ABI, with torch tensors as the memory owner.
+
+torch is plumbing here: it allocates HBM and names the HIP stream; every byte of work is done
+by libspz_amd.so through raw pointers (spz_amd.abi).  Clouds are dicts of flat float32 CUDA
+tensors keyed like the reference's GaussianCloud fields (splat-types.h:101-115):
+positions[3N], scales[3N], rotations[4N], alphas[N], colors[3N], sh[N*shDim*3].
+"""
+import ctypes as C
+
+import torch
+
+from . import abi
+from .synth import FIELDS, SH_DIM, floats_per_point
+
+
+def _stream_handle(stream=None):
+    s = stream if stream is not None else torch.cuda.current_stream()
+    return C.c_void_p(s.cuda_stream)
+
+
+def _ptrs(cloud, sh_degree, n, device):
+    p = abi.CloudPtrs()
+    for k in FIELDS:
+        t = cloud.get(k)
+        need = n * floats_per_point(k, sh_degree)
+        if need == 0:
+            setattr(p, k, None)
+            continue
+        if t is None or t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous() or t.numel() != need:
+            raise ValueError(f"cloud[{k!r}] must be a contiguous float32 CUDA tensor of {need} elements")
+        if t.device != device:
+            raise ValueError(f"cloud[{k!r}] is on {t.device}, expected {device}")
+        setattr(p, k, t.data_ptr())
+    return p
+
+
+def alloc_cloud(n, sh_degree, device):
+    return {k: torch.empty(n * floats_per_point(k, sh_degree), dtype=torch.float32, device=device) for k in FIELDS}
+
+
+def make_header(num_points, sh_degree, version=3, fractional_bits=12, antialiased=False):
+    return abi.Header(int(version), int(num_points), int(sh_degree), int(fractional_bits),
+                      1 if antialiased else 0, 0)
+
+
+def encode(cloud, num_points, sh_degree, antialiased=False, from_coord=0, version=3, out=None, stream=None):
+    """packGaussians + serializePackedGaussians on the GPU -> uint8 CUDA tensor holding the raw
+    (pre-gzip) stream.  Asynchronous on `stream` (default: torch's current stream)."""
+    L = abi.load_library()
+    device = cloud["positions"].device if num_points else (out.device if out is not None else torch.device("cuda"))
+    lay = abi.stream_layout(num_points, sh_degree, version)
+    if out is None:
+        out = torch.empty(lay.total_bytes, dtype=torch.uint8, device=device)
+    p = _ptrs(cloud, sh_degree, num_points, device)
+    with torch.cuda.device(device):
+        rc = L.spz_amd_encode_device(C.byref(p), num_points, sh_degree, int(bool(antialiased)), from_coord, version,
+                                     out.data_ptr(), out.numel(), _stream_handle(stream))
+    abi.check(rc, "spz_amd_encode_device")
+    return out[:lay.total_bytes]
+
+
+def decode(stream_t, header, to_coord=0, out=None, stream=None):
+    """unpackGaussians (+ fused coordinate flip) on the GPU.  `header` is an abi.Header (from
+    abi.peek_header on host bytes, or make_header for a stream this process encoded)."""
+    L = abi.load_library()
+    n, deg = header.num_points, header.sh_degree
+    if out is None:
+        out = alloc_cloud(n, deg, stream_t.device)
+    p = _ptrs(out, deg, n, stream_t.device)
+    with torch.cuda.device(stream_t.device):
+        rc = L.spz_amd_decode_device(stream_t.data_ptr(), stream_t.numel(), C.byref(header), to_coord, C.byref(p),
+                                     _stream_handle(stream))
+    abi.check(rc, "spz_amd_decode_device")
+    return out
+
+
+def encode_shard(cloud, first, count, num_points_total, sh_degree, out, antialiased=False, from_coord=0, version=3,
+                 write_header=False, stream=None):
+    """Encode points [first, first+count) (cloud holds only those) into the FULL stream `out`."""
+    L = abi.load_library()
+    p = _ptrs(cloud, sh_degree, count, out.device)
+    with torch.cuda.device(out.device):
+        rc = L.spz_amd_encode_shard_device(C.byref(p), first, count, num_points_total, sh_degree,
+                                           int(bool(antialiased)), from_coord, version, int(bool(write_header)),
+                                           out.data_ptr(), out.numel(), _stream_handle(stream))
+    abi.check(rc, "spz_amd_encode_shard_device")
+    return out
+
+
+def decode_shard(stream_t, header, first, count, to_coord=0, out=None, stream=None):
+    L = abi.load_library()
+    deg = header.sh_degree
+    if out is None:
+        out = alloc_cloud(count, deg, stream_t.device)
+    p = _ptrs(out, deg, count, stream_t.device)
+    with torch.cuda.device(stream_t.device):
+        rc = L.spz_amd_decode_shard_device(stream_t.data_ptr(), stream_t.numel(), C.byref(header), first, count,
+                                           to_coord, C.byref(p), _stream_handle(stream))
+    abi.check(rc, "spz_amd_decode_shard_device")
+    return out
+
+
+def convert_coordinates(cloud, num_points, sh_degree, from_coord, to_coord, stream=None):
+    """In-place GaussianCloud::convertCoordinates on device tensors (positions, rotations, sh)."""
+    L = abi.load_library()
+    dev = cloud["positions"].device
+
+    def ptr(k):
+        t = cloud.get(k)
+        return t.data_ptr() if t is not None and t.numel() else None
+
+    with torch.cuda.device(dev):
+        rc = L.spz_amd_convert_coordinates_device(ptr("positions"), ptr("rotations"), ptr("sh"), num_points,
+                                                  sh_degree, from_coord, to_coord, _stream_handle(stream))
+    abi.check(rc, "spz_amd_convert_coordinates_device")
+    return cloud
+
+
+def to_device(cloud_np, device):
+    return {k: torch.from_numpy(cloud_np[k]).to(device) for k in FIELDS}
+
+
+def to_numpy(cloud_t):
+    return {k: cloud_t[k].cpu().numpy() for k in FIELDS}
+
+
+__all__ = ["encode", "decode", "encode_shard", "decode_shard", "convert_coordinates", "alloc_cloud",
+           "make_header", "to_device", "to_numpy", "SH_DIM"]

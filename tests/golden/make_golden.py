@@ -1,0 +1,339 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors in tests/golden/ from the REFERENCE's own C++.
+
+Run in the build container (needs oracle/_ref/libspz_ref.so, i.e. /root/reference):
+
+    make -C oracle && python tests/golden/make_golden.py
+
+Everything written here is DATA: inputs and the outputs the reference
+(lanxinger/spz src/cc, compiled unmodified by oracle/Makefile with its own
+Release flags) produced for them.  No reference source text is stored.
+
+Files (all numpy .npz, loaded with allow_pickle=False):
+  kat_small.npz     2-point SH3 cloud of the reference's tests/python/load_spz_test.py:72-100
+                    (streams for every `from`, decodes for every `to`, gz bytes),
+                    SH edge KAT (:180-207), coordinate KATs (:444-512).
+  clouds.npz        seeded 512-point clouds SH0..3 with edge values injected: inputs,
+                    streams for from in {0,6,7}, decodes for to in {0,1,6,7}.
+  quats.npz         quaternion edge/random sets: v3 encode bytes, v3/v2 decode floats
+                    (including streams whose smallest-three sum exceeds 1 -> NaN).
+  legacy.npz        v2 and v1 streams (header patched / float16 positions) and the
+                    reference's decode of them.
+  tables.npz        alpha/colour/scale/sh decode tables (256 entries each, taken from
+                    the reference's decode of all byte values) and the 255 alpha-encode
+                    thresholds (smallest float whose reference alpha byte is >= v).
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from oracle.pyoracle import Reference, stream_size, sh_dim  # noqa: E402
+from spz_amd.synth import make_cloud_numpy  # noqa: E402
+
+R = Reference()
+FIELDS = ("positions", "scales", "rotations", "alphas", "colors", "sh")
+
+
+def f32(x):
+    return np.asarray(x, dtype=np.float64).astype(np.float32)
+
+
+def kat_small():
+    out = {}
+    # --- 2-pt cloud, load_spz_test.py:86-96 -------------------------------------------------
+    c = dict(positions=f32([0, 0.1, -0.2, 0.3, 0.4, 0.5]), scales=f32([-3, -2, -1.5, -1, 0, 0.1]),
+             rotations=f32([-0.5, 0.2, 1, -0.2, 0.1, -0.4, -0.3, 0.5]), alphas=f32([-1.0, 1.0]),
+             colors=f32([-1, 0, 1, -0.5, 0.5, 0.1]), sh=f32([i / 45.0 - 1.0 for i in range(90)]))
+    for k in FIELDS:
+        out[f"two_in_{k}"] = c[k]
+    for frm in range(9):
+        out[f"two_stream_from{frm}"] = R.pack(c, 2, 3, True, frm)
+    s0 = out["two_stream_from0"]
+    for to in range(9):
+        u = R.unpack(s0, 2, 3, to)
+        for k in FIELDS:
+            out[f"two_dec_to{to}_{k}"] = u[k]
+    out["two_gz_from0"] = R.save_spz(c, 2, 3, True, 0)
+    # same cloud without SH (make_test_gaussian_cloud(include_sh=False))
+    c0 = dict(c, sh=np.zeros(0, np.float32))
+    out["two_sh0_stream"] = R.pack(c0, 2, 0, True, 0)
+    out["two_sh0_gz"] = R.save_spz(c0, 2, 0, True, 0)
+    # empty cloud (load_spz_test.py:753-772)
+    e = {k: np.zeros(0, np.float32) for k in FIELDS}
+    out["empty_stream"] = R.pack(e, 0, 0, False, 0)
+    out["empty_gz"] = R.save_spz(e, 0, 0, False, 0)
+
+    # --- SH edge KAT, load_spz_test.py:180-207 ----------------------------------------------
+    c = dict(positions=f32([0, 0, 0]), scales=f32([0, 0, 0]), rotations=f32([0, 0, 0, 1]),
+             alphas=f32([0.0]), colors=f32([0, 0, 0]),
+             sh=f32([-0.01, 0.0, 0.01, -1.0, -0.99, -0.95, 0.95, 0.99, 1.0]))
+    for k in FIELDS:
+        out[f"shedge_in_{k}"] = c[k]
+    out["shedge_stream"] = R.pack(c, 1, 1, False, 0)
+    u = R.unpack(out["shedge_stream"], 1, 1, 0)
+    for k in FIELDS:
+        out[f"shedge_dec_{k}"] = u[k]
+
+    # --- coordinate KAT, load_spz_test.py:444-512 -------------------------------------------
+    c = dict(positions=f32([1, 2, 3]), scales=f32([0.1, 0.2, 0.3]), rotations=f32([0.1, 0.2, 0.3, 0.9]),
+             alphas=f32([0.5]), colors=f32([0.1, 0.2, 0.3]),
+             sh=f32([0.1, 0.2, 0.3, 0.4, 0.5, 0.6, 0.7, 0.8, 0.9]))
+    for k in FIELDS:
+        out[f"coord_in_{k}"] = c[k]
+    out["coord_stream_from4"] = R.pack(c, 1, 1, False, 4)
+    u = R.unpack(out["coord_stream_from4"], 1, 1, 6)
+    for k in FIELDS:
+        out[f"coord_dec_from4_to6_{k}"] = u[k]
+    c2 = dict(c, sh=np.zeros(0, np.float32))
+    out["coord_stream_sh0_from6"] = R.pack(c2, 1, 0, False, 6)
+    u = R.unpack(out["coord_stream_sh0_from6"], 1, 0, 7)
+    for k in FIELDS:
+        out[f"coord_dec_from6_to7_{k}"] = u[k]
+
+    # --- converter tables for every (from, to) ---------------------------------------------
+    conv = np.zeros((9, 9, 21), np.float32)
+    for a in range(9):
+        for b in range(9):
+            p, q, s = R.converter(a, b)
+            conv[a, b] = np.concatenate([p, q, s])
+    out["converter"] = conv
+    np.savez_compressed(os.path.join(HERE, "kat_small.npz"), **out)
+
+
+def inject_edges(c, n, deg):
+    """Overwrite the head of each array with values on rounding / saturation edges that stay
+    inside the reference's defined domain (no NaN, no |x| >= 2^31 after scaling)."""
+    p = c["positions"]
+    edge_p = [0.0, -0.0, 2047.9999, -2048.0, 2048.0, 1e-30, 0.5 / 4096, -0.5 / 4096, 1.5 / 4096,
+              -1.5 / 4096, 2.5 / 4096, 0.49999997 / 4096, 1234.5678, -1234.5678, 4095.75, 1e5, -1e5, 3e-39]
+    p[:len(edge_p)] = f32(edge_p)
+    s = c["scales"]
+    edge_s = [-10.1, 5.93, 6.0, -10.0, 5.9375, -9.96875, -9.96874, -9.96876, 5.90625, 5.9062, 100.0, -100.0,
+              0.03125, -0.03125, -0.0, 1e-30]
+    s[:len(edge_s)] = f32(edge_s)
+    a = c["alphas"]
+    edge_a = [100.0, -100.0, 0.0, -0.0, 1e-7, -3.6e-7, -3.5e-7, 88.0, -88.0, 89.0, -89.0, 17.0, -17.0, 5.5451775,
+              -5.5451775, 1e-30, 1e30, -1e30, 87.33655, -87.33655, 103.0, -104.0]
+    a[:len(edge_a)] = f32(edge_a)
+    col = c["colors"]
+    edge_c = [3.4, -3.4, 0.0, 1e-9, (0.5 - 127.5) / 38.25, (1.5 - 127.5) / 38.25, (254.5 - 127.5) / 38.25,
+              (255.5 - 127.5) / 38.25, 1e30, -1e30, -3.3333333, 3.3333333, 0.013071895, -0.013071895]
+    col[:len(edge_c)] = f32(edge_c)
+    q = c["rotations"].reshape(-1, 4)
+    edge_q = [[0, 0, 0, 1], [0, 0, 0, -1], [1, 1, 1, 1], [.5, -.5, .5, -.5], [1, 0, 0, 0], [-1, 0, 0, 1],
+              [0, 1, 0, 0], [0, 0, -1, 0], [1, 1, 0, 0], [1, -1, 0, 0], [-1, -1, -1, -1], [1e-20, 0, 0, 1e-20],
+              [1e18, 1e18, 0, 1e18], [-0.0, 0.0, -0.0, 1], [0.1, 0.2, 0.3, 0.9], [2, 3, 4, 5],
+              [0.70710677, 0.70710677, 0, 0], [0.5, 0.5, 0.5, 0.50000006]]
+    q[:len(edge_q)] = f32(edge_q)
+    if deg > 0:
+        sh = c["sh"]
+        edge_sh = [-0.01, 0.0, 0.01, -1.0, -0.99, -0.95, 0.95, 0.99, 1.0, -0.0, 2.0, -2.0, 0.99609375, 0.9921875,
+                   3.5 / 128, 4.5 / 128, -3.5 / 128, -4.5 / 128, 11.5 / 128, 12.5 / 128, 7.5 / 128, 8.5 / 128,
+                   -7.5 / 128, -8.5 / 128, 0.5 / 128, -0.5 / 128, 1e6, -1e6, 1e-30, -1e-30, 123.4 / 128, 119.5 / 128,
+                   120.5 / 128, 127.5 / 128, 126.5 / 128, -127.5 / 128, -128.5 / 128, -123.5 / 128, -124.5 / 128]
+        m = min(len(edge_sh), sh.size)
+        # place the edge values on point 1 (so they hit several coefficient slots) and point 0
+        sh[:m] = f32(edge_sh)[:m]
+        d = sh_dim(deg) * 3
+        if sh.size >= 2 * d + m:
+            sh[d + 1:d + 1 + m] = f32(edge_sh)[:m]
+    return c
+
+
+def clouds():
+    out = {}
+    n = 512
+    for deg in range(4):
+        c = inject_edges(make_cloud_numpy(n, deg, 1000 + deg), n, deg)
+        for k in FIELDS:
+            out[f"d{deg}_in_{k}"] = c[k]
+        for frm in (0, 6, 7):
+            out[f"d{deg}_stream_from{frm}"] = R.pack(c, n, deg, bool(deg & 1), frm)
+        s0 = out[f"d{deg}_stream_from0"]
+        for to in (0, 1, 6, 7):
+            u = R.unpack(s0, n, deg, to)
+            for k in FIELDS:
+                out[f"d{deg}_dec_to{to}_{k}"] = u[k]
+    # odd sizes: section bases at every alignment mod 16 (N = 1..19, SH3 and SH1)
+    for nn in list(range(1, 20)) + [63, 64, 65, 255, 257]:
+        for deg in (1, 3):
+            c = make_cloud_numpy(nn, deg, 2000 + nn * 4 + deg)
+            for k in FIELDS:
+                out[f"odd_n{nn}_d{deg}_in_{k}"] = c[k]
+            s = R.pack(c, nn, deg, False, 6)
+            out[f"odd_n{nn}_d{deg}_stream_from6"] = s
+            u = R.unpack(s, nn, deg, 7)
+            for k in FIELDS:
+                out[f"odd_n{nn}_d{deg}_dec_to7_{k}"] = u[k]
+    np.savez_compressed(os.path.join(HERE, "clouds.npz"), **out)
+
+
+def quats():
+    out = {}
+    rng = np.random.default_rng(77)
+    q = rng.standard_normal((2048, 4)).astype(np.float32)
+    # near-ties between components, tiny components, axis aligned
+    q[:256, 1] = q[:256, 0] * np.float32(1.0000001)
+    q[256:512, 3] = -q[256:512, 2]
+    q[512:640] *= np.float32(1e-15)
+    q[640:768] *= np.float32(1e15)
+    q[768:800, :3] = 0
+    out["enc_in"] = q.reshape(-1)
+    for frm in (0, 6, 7, 1):
+        out[f"enc_bytes_from{frm}"] = R.pack_quat(q.reshape(-1), frm)
+    # decode: arbitrary 32-bit patterns (covers sum > 1 -> NaN) and all of the encoder's outputs
+    r = rng.integers(0, 2 ** 32, 4096, dtype=np.uint64).astype(np.uint32)
+    r[:8] = [0, 0xFFFFFFFF, 0xC0000000, 0x3FFFFFFF, 0x1FF7FDFF, 0xDFF7FDFF, 0x200, 0x80000]
+    rb = r.view(np.uint8)
+    out["dec3_bytes"] = rb
+    for to in (0, 6, 7):
+        out[f"dec3_to{to}"] = R.unpack_quat_smallest_three(rb, to)
+    out["dec3_of_enc_from0"] = R.unpack_quat_smallest_three(out["enc_bytes_from0"], 0)
+    # v2 first-three: every byte value in every slot + random
+    r2 = rng.integers(0, 256, (2048, 3), dtype=np.uint16).astype(np.uint8)
+    r2[:256, 0] = np.arange(256)
+    r2[:256, 1] = 127
+    r2[:256, 2] = 128
+    r2[256:512, 0] = 128
+    r2[256:512, 1] = np.arange(256)
+    r2[256:512, 2] = np.arange(255, -1, -1)
+    out["dec2_bytes"] = r2.reshape(-1)
+    for to in (0, 6, 7):
+        out[f"dec2_to{to}"] = R.unpack_quat_first_three(r2.reshape(-1), to)
+    np.savez_compressed(os.path.join(HERE, "quats.npz"), **out)
+
+
+def legacy():
+    out = {}
+    n, deg = 300, 2
+    c = make_cloud_numpy(n, deg, 31337)
+    s3 = R.pack(c, n, deg, True, 0)
+    d = sh_dim(deg) * 3
+    # --- v2: header version := 2, rotations 3 bytes (random), everything else from the v3 stream
+    rng = np.random.default_rng(5)
+    rot2 = rng.integers(0, 256, n * 3, dtype=np.uint16).astype(np.uint8)
+    rot2[:6] = [0x00, 0x80, 0xFF, 0xC8, 0x1E, 0x7F]  # SURVEY appendix C vector
+    o_rot = 16 + 16 * n
+    s2 = np.concatenate([s3[:o_rot], rot2, s3[o_rot + 4 * n:]])
+    s2[4] = 2
+    assert s2.size == stream_size(n, deg, 2)
+    out["v2_stream"] = s2
+    for to in (0, 6, 7):
+        u = R.unpack(s2, n, deg, to)
+        assert u["num_points"] == n
+        for k in FIELDS:
+            out[f"v2_dec_to{to}_{k}"] = u[k]
+    # --- v1: float16 positions (6 B/pt), 3-byte rotations
+    halves = rng.integers(0, 65536, n * 3, dtype=np.uint32).astype(np.uint16)
+    halves[:12] = [0x0000, 0x8000, 0x3C00, 0xBC00, 0x7C00, 0xFC00, 0x7E00, 0xFE01, 0x0001, 0x8001, 0x03FF, 0x7BFF]
+    s1 = np.concatenate([s3[:16], halves.view(np.uint8), s3[16 + 9 * n:o_rot], rot2, s3[o_rot + 4 * n:]])
+    s1[4] = 1
+    assert s1.size == stream_size(n, deg, 1)
+    out["v1_stream"] = s1
+    for to in (0, 6):
+        u = R.unpack(s1, n, deg, to)
+        assert u["num_points"] == n
+        for k in FIELDS:
+            out[f"v1_dec_to{to}_{k}"] = u[k]
+    # --- fractionalBits other than 12 (header byte 13), v3
+    for fb in (0, 8, 16, 23):
+        s = s3.copy()
+        s[13] = fb
+        out[f"fb{fb}_stream"] = s
+        out[f"fb{fb}_dec_positions"] = R.unpack(s, n, deg, 6)["positions"]
+    # --- rejected headers (deserializePackedGaussians load-spz.cc:553-568,591-594): reference
+    #     returns an empty cloud; record numPoints it reported (0)
+    bad = {}
+    b = s3.copy(); b[0] ^= 0xFF; bad["magic"] = b
+    b = s3.copy(); b[4] = 4; bad["version4"] = b
+    b = s3.copy(); b[4] = 0; bad["version0"] = b
+    b = s3.copy(); b[12] = 4; bad["shdeg4"] = b
+    b = s3.copy(); b[8:12] = np.frombuffer(np.uint32(10_000_001).tobytes(), np.uint8); bad["toomany"] = b
+    bad["short"] = s3[:-1].copy()
+    bad["tiny"] = s3[:10].copy()
+    for name, b in bad.items():
+        u = R.unpack(b, n, deg, 0)
+        out[f"bad_{name}_stream"] = b
+        out[f"bad_{name}_numpoints"] = np.int32(u["num_points"])
+    np.savez_compressed(os.path.join(HERE, "legacy.npz"), **out)
+
+
+def float_key(x):
+    """Monotone uint32 key of float32 values (total order, -0 < +0)."""
+    b = x.view(np.uint32)
+    return np.where(b >> 31, ~b, b | np.uint32(0x80000000)).astype(np.uint32)
+
+
+def key_float(k):
+    k = k.astype(np.uint32)
+    b = np.where(k >> 31, k & np.uint32(0x7FFFFFFF), ~k)
+    return b.astype(np.uint32).view(np.float32)
+
+
+def tables():
+    out = {}
+    # decode tables: decode a 256-point SH1 stream whose every byte section runs 0..255
+    n = 256
+    s = np.zeros(stream_size(n, 1, 3), np.uint8)
+    z = {k: np.zeros(m, np.float32) for k, m in
+         (("positions", n * 3), ("scales", n * 3), ("rotations", n * 4), ("alphas", n), ("colors", n * 3), ("sh", n * 9))}
+    z["rotations"][3::4] = 1
+    s[:] = R.pack(z, n, 1, False, 0)
+    ramp = np.arange(256, dtype=np.uint8)
+    s[16 + 9 * n:16 + 10 * n] = ramp
+    s[16 + 10 * n:16 + 13 * n] = np.repeat(ramp, 3)
+    s[16 + 13 * n:16 + 16 * n] = np.repeat(ramp, 3)
+    s[16 + 20 * n:16 + 29 * n] = np.repeat(ramp, 9)
+    u = R.unpack(s, n, 1, 0)
+    out["alpha_decode"] = u["alphas"]
+    out["color_decode"] = u["colors"][::3].copy()
+    out["scale_decode"] = u["scales"][::3].copy()
+    out["sh_decode"] = u["sh"][::9].copy()
+
+    # alpha encode thresholds: T[v-1] = smallest float a (total order) with byte(a) >= v, v=1..255
+    def alpha_bytes(a):
+        m = a.size
+        c = {k: np.zeros(mm, np.float32) for k, mm in
+             (("positions", m * 3), ("scales", m * 3), ("rotations", m * 4), ("colors", m * 3), ("sh", 0))}
+        c["rotations"][3::4] = 1
+        c["alphas"] = a.astype(np.float32)
+        st = R.pack(c, m, 0, False, 0)
+        return st[16 + 9 * m:16 + 10 * m].astype(np.int32)
+
+    v = np.arange(1, 256, dtype=np.int32)
+    lo = np.full(255, float_key(np.array([-np.inf], np.float32))[0], np.uint64)  # byte(lo) = 0 < v
+    hi = np.full(255, float_key(np.array([np.inf], np.float32))[0], np.uint64)   # byte(hi) = 255 >= v
+    assert alpha_bytes(np.array([-np.inf, np.inf], np.float32)).tolist() == [0, 255]
+    while np.any(hi - lo > 1):
+        mid = (lo + hi) // 2
+        b = alpha_bytes(key_float(mid.astype(np.uint32)))
+        ge = b >= v
+        hi = np.where(ge, mid, hi)
+        lo = np.where(ge, lo, mid)
+    T = key_float(hi.astype(np.uint32))
+    # verify the step at each threshold and monotonicity in a +-64 ulp neighbourhood
+    for off in range(-64, 65):
+        a = key_float((hi.astype(np.int64) + off).astype(np.uint32))
+        b = alpha_bytes(a)
+        if off < 0:
+            assert np.all(b < v), off
+        else:
+            assert np.all(b >= v), off
+    out["alpha_thresholds"] = T
+    np.savez_compressed(os.path.join(HERE, "tables.npz"), **out)
+
+
+if __name__ == "__main__":
+    kat_small()
+    clouds()
+    quats()
+    legacy()
+    tables()
+    for f in sorted(os.listdir(HERE)):
+        if f.endswith(".npz"):
+            print(f, os.path.getsize(os.path.join(HERE, f)))

@@ -1,0 +1,161 @@
+"""CPU-only checks of the C-ABI library: it loads, exports every symbol include/spz_amd.h
+declares, and its pure-host entry points (layout, header, tables, status strings) agree with the
+oracle and the golden vectors.  No compute entry point is called with real work here."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_bits_equal, load_golden
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from spz_amd import abi
+    return abi.load_library()
+
+
+def declared_functions():
+    text = open(os.path.join(ROOT, "include", "spz_amd.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(spz_amd_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from spz_amd import abi
+    names = declared_functions()
+    assert len(names) >= 17
+    assert sorted(abi.EXPORTS) == names, "spz_amd/abi.py EXPORTS out of sync with include/spz_amd.h"
+    for n in names:
+        assert hasattr(lib, n), f"libspz_amd.so does not export {n}"
+    assert lib.spz_amd_abi_version() == 1
+
+
+def test_host_library_and_python_module_load():
+    host = C.CDLL(os.path.join(ROOT, "spz_amd", "lib", "libspz_host.so"))
+    assert host is not None
+    import spz_amd.spz as spz
+    for name in ("GaussianCloud", "PackOptions", "UnpackOptions", "CoordinateSystem", "load_spz", "save_spz",
+                 "load_splat_from_ply", "save_splat_to_ply", "UNSPECIFIED", "LDB", "RDB", "LUB", "RUB", "LDF",
+                 "RDF", "LUF", "RUF"):
+        assert hasattr(spz, name), name
+
+
+def test_status_strings(lib):
+    from spz_amd import abi
+    assert abi.status_string(abi.OK) == "ok"
+    assert abi.status_string(abi.ERR_HEADER_NOT_FOUND) == "header not found"
+    assert abi.status_string(abi.ERR_SHORT_STREAM) == "read error"
+    assert abi.status_string(-999) == "unknown status"
+
+
+@pytest.mark.parametrize("version", [1, 2, 3])
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_stream_layout_matches_oracle(lib, oracle, deg, version):
+    from spz_amd import abi
+    for n in (0, 1, 7, 4096, 10_000_000, 80_000_000):
+        lay = abi.stream_layout(n, deg, version)
+        assert lay.total_bytes == oracle.lib.spzo_stream_size(n, deg, version)
+        pos_b = 6 if version == 1 else 9
+        rot_b = 4 if version == 3 else 3
+        d = {0: 0, 1: 9, 2: 24, 3: 45}[deg]
+        assert list(lay.bytes_per_point) == [pos_b, 1, 3, 3, rot_b, d]
+        off = 16
+        for s in range(6):
+            assert lay.offset[s] == off and lay.bytes[s] == n * lay.bytes_per_point[s]
+            off += lay.bytes[s]
+    bad = abi.Layout()
+    assert lib.spz_amd_stream_layout(1, 4, 3, C.byref(bad)) == abi.ERR_INVALID_ARG
+    assert lib.spz_amd_stream_layout(1, 3, 4, C.byref(bad)) == abi.ERR_INVALID_ARG
+    assert lib.spz_amd_stream_layout(1, 3, 0, C.byref(bad)) == abi.ERR_INVALID_ARG
+
+
+def test_header_write_and_peek_round_trip(lib, oracle):
+    from spz_amd import abi
+    g = load_golden("kat_small.npz")
+    # the header the reference wrote for the 2-point cloud
+    assert abi.write_header(3, 2, 3, 12, True) == g["two_stream_from0"][:16].tobytes()
+    assert abi.write_header(3, 0, 0, 12, False) == g["empty_stream"][:16].tobytes()
+    for name in ("two_stream_from0", "empty_stream", "shedge_stream", "two_sh0_stream"):
+        s = g[name]
+        rc, h = abi.peek_header(s.tobytes())
+        orc, oh = oracle.peek(s)
+        assert rc == 0 and orc == 0
+        assert (h.version, h.num_points, h.sh_degree, h.fractional_bits, h.antialiased) == \
+               (oh["version"], oh["num_points"], oh["sh_degree"], oh["fractional_bits"], oh["antialiased"])
+
+
+def test_peek_header_rejections_mirror_the_reference(lib, oracle):
+    """deserializePackedGaussians load-spz.cc:553-568,591-594; golden: the reference returned an
+    empty cloud for each of these streams."""
+    from spz_amd import abi
+    g = load_golden("legacy.npz")
+    want = {"magic": abi.ERR_HEADER_NOT_FOUND, "tiny": abi.ERR_HEADER_NOT_FOUND, "version4": abi.ERR_VERSION,
+            "version0": abi.ERR_VERSION, "toomany": abi.ERR_TOO_MANY_POINTS, "shdeg4": abi.ERR_SH_DEGREE,
+            "short": abi.ERR_SHORT_STREAM}
+    oracle_codes = {abi.ERR_HEADER_NOT_FOUND: -1, abi.ERR_VERSION: -2, abi.ERR_TOO_MANY_POINTS: -3,
+                    abi.ERR_SH_DEGREE: -4, abi.ERR_SHORT_STREAM: -5}
+    for name, code in want.items():
+        s = g[f"bad_{name}_stream"]
+        assert int(g[f"bad_{name}_numpoints"]) == 0
+        rc, h = abi.peek_header(s.tobytes())
+        assert rc == code and h is None, name
+        assert oracle.peek(s)[0] == oracle_codes[code], name
+    # exactly 10 M points passes the reference's limit, 10 M + 1 does not (load-spz.cc:549,561)
+    hdr = abi.write_header(3, 10_000_000, 0)
+    assert abi.peek_header(hdr)[0] == abi.ERR_SHORT_STREAM
+    assert abi.peek_header(abi.write_header(3, 10_000_001, 0))[0] == abi.ERR_TOO_MANY_POINTS
+    # the _ex form lifts the limit for reassembled shard streams
+    assert abi.peek_header(abi.write_header(3, 80_000_000, 3), max_points=0)[0] == abi.ERR_SHORT_STREAM
+    assert abi.peek_header(b"")[0] == abi.ERR_HEADER_NOT_FOUND
+    for ver in ("v1", "v2"):
+        rc, h = abi.peek_header(g[f"{ver}_stream"].tobytes())
+        assert rc == 0 and h.version == int(ver[1])
+
+
+def test_tables_equal_reference_tables(lib):
+    """Host-computed decode tables / alpha thresholds == the reference's (tests/golden/tables.npz)."""
+    from spz_amd import abi
+    g = load_golden("tables.npz")
+    a, c, t = abi.get_tables()
+    assert_bits_equal(a, g["alpha_decode"], "alpha decode table")
+    assert_bits_equal(c, g["color_decode"], "colour decode table")
+    assert_bits_equal(t, g["alpha_thresholds"], "alpha thresholds")
+
+
+def test_compute_entry_points_fail_loudly_without_a_gpu(lib):
+    """No CPU fallback: with no HIP device the host-pointer entry points return ERR_NO_DEVICE."""
+    import torch
+    from spz_amd import abi
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    n = 4
+    arrs = [np.zeros(m, np.float32) for m in (3 * n, 3 * n, 4 * n, n, 3 * n, 0)]
+    arrs[2][3::4] = 1
+    p = abi.CloudPtrs(*[a.ctypes.data if a.size else None for a in arrs])
+    out = np.zeros(abi.stream_layout(n, 0, 3).total_bytes, np.uint8)
+    rc = lib.spz_amd_encode_host(C.byref(p), n, 0, 0, 0, 3, out.ctypes.data, out.size, 0)
+    assert rc == abi.ERR_NO_DEVICE
+    assert not out.any(), "nothing may be written without a device"
+    stream = np.frombuffer(abi.write_header(3, n, 0), np.uint8)
+    stream = np.concatenate([stream, np.zeros(20 * n, np.uint8)])
+    rc = lib.spz_amd_decode_host(stream.ctypes.data, stream.size, 0, C.byref(p), 0)
+    assert rc == abi.ERR_NO_DEVICE
+    assert lib.spz_amd_device_count() == 0
+
+
+def test_python_module_raises_without_a_gpu():
+    import torch
+    import spz_amd.spz as spz
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    c = spz.GaussianCloud()
+    c.positions = np.zeros(3, np.float32)
+    c.scales = np.zeros(3, np.float32)
+    c.rotations = np.array([0, 0, 0, 1], np.float32)
+    c.alphas = np.zeros(1, np.float32)
+    c.colors = np.zeros(3, np.float32)
+    with pytest.raises(RuntimeError, match="no usable HIP device"):
+        spz.save_spz(c, spz.PackOptions(), os.path.join("/tmp", "spz_amd_never_written.spz"))

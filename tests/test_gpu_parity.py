@@ -1,0 +1,405 @@
+"""Parity of the HIP path (through the C ABI, spz_amd.device / spz_amd.abi) against the golden
+vectors and the CPU oracle.  Integer/byte work: bit-exact.  Decoded floats: bit-exact too
+(compared as uint32, so -0.0, infinities and NaN payloads count) — tighter than the 1-ULP
+tolerance BASELINE.json allows."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import FIELDS, assert_bits_equal, assert_bytes_equal, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def dev(cuda):
+    from spz_amd import abi
+    abi.load_library()
+    assert abi.load_library().spz_amd_device_count() >= 1
+    return cuda
+
+
+def cloud_from(g, prefix):
+    return {k: np.ascontiguousarray(g[f"{prefix}_{k}"], dtype=np.float32) for k in FIELDS}
+
+
+def gpu_encode(c, n, deg, aa, frm, dev, version=3):
+    import torch
+    from spz_amd import device as D
+    out = D.encode(D.to_device(c, dev), n, deg, aa, frm, version)
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+def gpu_decode(stream_np, to, dev, max_points=None):
+    import torch
+    from spz_amd import abi, device as D
+    rc, h = abi.peek_header(stream_np.tobytes(), abi.REFERENCE_MAX_POINTS if max_points is None else max_points)
+    assert rc == 0, rc
+    # a deliberately misaligned device copy: streams need no alignment
+    buf = torch.empty(stream_np.size + 3, dtype=torch.uint8, device=dev)
+    view = buf[3:]
+    view.copy_(torch.from_numpy(stream_np))
+    out = D.decode(view, h, to)
+    torch.cuda.synchronize()
+    return h, D.to_numpy(out)
+
+
+def test_tables_match_golden(dev):
+    from spz_amd import abi
+    g = load_golden("tables.npz")
+    a, c, t = abi.get_tables()
+    assert_bits_equal(a, g["alpha_decode"], "alpha decode table")
+    assert_bits_equal(c, g["color_decode"], "colour decode table")
+    assert_bits_equal(t, g["alpha_thresholds"], "alpha thresholds")
+
+
+def test_two_point_cloud_all_coordinate_systems(dev):
+    g = load_golden("kat_small.npz")
+    c = cloud_from(g, "two_in")
+    for frm in range(9):
+        assert_bytes_equal(gpu_encode(c, 2, 3, True, frm, dev), g[f"two_stream_from{frm}"], f"from={frm}")
+    for to in range(9):
+        h, u = gpu_decode(g["two_stream_from0"], to, dev)
+        assert (h.num_points, h.sh_degree, h.antialiased) == (2, 3, True)
+        for k in FIELDS:
+            assert_bits_equal(u[k], g[f"two_dec_to{to}_{k}"], f"to={to} {k}")
+
+
+def test_reference_python_kats(dev):
+    """SH edge KAT and coordinate KATs of the reference's tests/python/load_spz_test.py."""
+    g = load_golden("kat_small.npz")
+    c = cloud_from(g, "shedge_in")
+    s = gpu_encode(c, 1, 1, False, 0, dev)
+    assert_bytes_equal(s, g["shedge_stream"])
+    _, u = gpu_decode(s, 0, dev)
+    np.testing.assert_allclose(u["sh"], [0.0, 0.0, 0.0, -1.0, -1.0, -0.9375, 0.9375, 0.9922, 0.9922], atol=2e-5)
+    c = cloud_from(g, "coord_in")
+    s = gpu_encode(c, 1, 1, False, 4, dev)
+    assert_bytes_equal(s, g["coord_stream_from4"])
+    _, u = gpu_decode(s, 6, dev)
+    for k in FIELDS:
+        assert_bits_equal(u[k], g[f"coord_dec_from4_to6_{k}"], k)
+    c0 = dict(c, sh=np.zeros(0, np.float32))
+    s = gpu_encode(c0, 1, 0, False, 6, dev)
+    assert_bytes_equal(s, g["coord_stream_sh0_from6"])
+    _, u = gpu_decode(s, 7, dev)
+    np.testing.assert_allclose(u["positions"], [-1.0, -2.0, 3.0], atol=1 / 2048.0)
+    for k in FIELDS:
+        assert_bits_equal(u[k], g[f"coord_dec_from6_to7_{k}"], k)
+
+
+def test_empty_cloud(dev):
+    import torch
+    from spz_amd import device as D
+    g = load_golden("kat_small.npz")
+    e = {k: torch.empty(0, dtype=torch.float32, device=dev) for k in FIELDS}
+    out = torch.zeros(16, dtype=torch.uint8, device=dev)
+    s = D.encode(e, 0, 0, False, 0, out=out)
+    torch.cuda.synchronize()
+    assert_bytes_equal(s.cpu().numpy(), g["empty_stream"])
+    h, u = gpu_decode(g["empty_stream"], 6, dev)
+    assert h.num_points == 0 and all(u[k].size == 0 for k in FIELDS)
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_seeded_clouds_with_edges(dev, deg):
+    g = load_golden("clouds.npz")
+    c = cloud_from(g, f"d{deg}_in")
+    n = c["alphas"].size
+    for frm in (0, 6, 7):
+        assert_bytes_equal(gpu_encode(c, n, deg, bool(deg & 1), frm, dev), g[f"d{deg}_stream_from{frm}"],
+                           f"deg={deg} from={frm}")
+    for to in (0, 1, 6, 7):
+        _, u = gpu_decode(g[f"d{deg}_stream_from0"], to, dev)
+        for k in FIELDS:
+            assert_bits_equal(u[k], g[f"d{deg}_dec_to{to}_{k}"], f"deg={deg} to={to} {k}")
+
+
+def test_ragged_sizes_every_alignment(dev):
+    """N = 1..19, 63..65, 255, 257: section bases land on every byte alignment; partial last units."""
+    g = load_golden("clouds.npz")
+    names = sorted({k.split("_in_")[0] for k in g.files if k.startswith("odd_") and "_in_" in k})
+    for nm in names:
+        n = int(nm.split("_")[1][1:])
+        deg = int(nm.split("_")[2][1:])
+        c = cloud_from(g, f"{nm}_in")
+        s = gpu_encode(c, n, deg, False, 6, dev)
+        assert_bytes_equal(s, g[f"{nm}_stream_from6"], nm)
+        _, u = gpu_decode(s, 7, dev)
+        for k in FIELDS:
+            assert_bits_equal(u[k], g[f"{nm}_dec_to7_{k}"], f"{nm} {k}")
+
+
+def test_quaternion_sets(dev):
+    """v3 encode of edge/near-tie/denormal-norm quaternions; v3 decode of arbitrary 32-bit patterns
+    (sum of squares > 1 -> NaN with the reference's sign); v2 decode of every byte value."""
+    import torch
+    from spz_amd import abi, device as D
+    g = load_golden("quats.npz")
+    q = np.ascontiguousarray(g["enc_in"], np.float32)
+    n = q.size // 4
+    z = lambda m: np.zeros(m, np.float32)
+    for frm in (0, 6, 7, 1):
+        c = dict(positions=z(3 * n), scales=z(3 * n), rotations=q, alphas=z(n), colors=z(3 * n), sh=z(0))
+        s = gpu_encode(c, n, 0, False, frm, dev)
+        assert_bytes_equal(s[16 + 16 * n:16 + 20 * n], g[f"enc_bytes_from{frm}"], f"quat encode from={frm}")
+    # decode arbitrary v3 rotation bytes
+    rb = g["dec3_bytes"]
+    n = rb.size // 4
+    base = gpu_encode(dict(positions=z(3 * n), scales=z(3 * n), rotations=np.tile(np.float32([0, 0, 0, 1]), n),
+                           alphas=z(n), colors=z(3 * n), sh=z(0)), n, 0, False, 0, dev)
+    base[16 + 16 * n:16 + 20 * n] = rb
+    for to in (0, 6, 7):
+        _, u = gpu_decode(base, to, dev)
+        assert_bits_equal(u["rotations"], g[f"dec3_to{to}"], f"v3 decode to={to}")
+    # v2 (first-three) decode
+    r2 = g["dec2_bytes"]
+    n = r2.size // 3
+    s2 = np.concatenate([np.frombuffer(abi.write_header(2, n, 0), np.uint8), np.zeros(16 * n, np.uint8), r2])
+    for to in (0, 6, 7):
+        _, u = gpu_decode(s2, to, dev)
+        assert_bits_equal(u["rotations"], g[f"dec2_to{to}"], f"v2 decode to={to}")
+
+
+def test_legacy_v1_v2_streams_and_fractional_bits(dev):
+    g = load_golden("legacy.npz")
+    for ver, tos in (("v2", (0, 6, 7)), ("v1", (0, 6))):
+        for to in tos:
+            _, u = gpu_decode(g[f"{ver}_stream"], to, dev)
+            for k in FIELDS:
+                assert_bits_equal(u[k], g[f"{ver}_dec_to{to}_{k}"], f"{ver} to={to} {k}")
+    for fb in (0, 8, 16, 23):
+        _, u = gpu_decode(g[f"fb{fb}_stream"], 6, dev)
+        assert_bits_equal(u["positions"], g[f"fb{fb}_dec_positions"], f"fractionalBits={fb}")
+
+
+@pytest.mark.parametrize("deg,n,seed", [(3, 300_007, 11), (0, 1_000_003, 12), (1, 200_001, 13), (2, 150_002, 14)])
+def test_large_random_against_oracle(dev, oracle, deg, n, seed):
+    """Sizes the oracle finishes in seconds; N chosen so no section is 4-byte aligned.  The colour
+    and quaternion paths are the FMA-sensitive ones: at these sizes a contracted
+    multiply-add would flip bytes."""
+    from spz_amd.synth import make_cloud_numpy
+    c = make_cloud_numpy(n, deg, seed)
+    for frm, to in ((6, 7), (0, 0)):
+        want = oracle.pack(c, n, deg, True, frm)
+        got = gpu_encode(c, n, deg, True, frm, dev)
+        assert_bytes_equal(got, want, f"deg={deg} from={frm}")
+        _, u = gpu_decode(got, to, dev)
+        rc, w = oracle.unpack(want, to)
+        assert rc == 0
+        for k in FIELDS:
+            assert_bits_equal(u[k], w[k], f"deg={deg} to={to} {k}")
+
+
+def test_fma_sensitive_dense_sweep(dev, oracle):
+    """4M colours and 1M quaternions/alphas drawn densely around rounding boundaries."""
+    rng = np.random.default_rng(99)
+    n = 1_000_000
+    z = lambda m: np.zeros(m, np.float32)
+    # colours near k + 0.5 boundaries of c * 38.25 + 127.5
+    k = rng.integers(0, 256, 3 * n)
+    col = ((k + 0.5 - 127.5) / 38.25 + rng.normal(0, 2e-7, 3 * n)).astype(np.float32)
+    sc = ((rng.integers(0, 256, 3 * n) + 0.5) / 16.0 - 10.0 + rng.normal(0, 1e-6, 3 * n)).astype(np.float32)
+    al = (rng.standard_normal(n) * 4).astype(np.float32)
+    pos = ((rng.integers(-8_000_000, 8_000_000, 3 * n) + 0.5) / 4096.0).astype(np.float32)
+    q = rng.standard_normal((n, 4)).astype(np.float32)
+    q[: n // 4] = np.round(q[: n // 4] * 2) / 2  # many exact ties / equal magnitudes
+    c = dict(positions=pos, scales=sc, rotations=q.reshape(-1), alphas=al, colors=col, sh=z(0))
+    # zero-norm quaternions are outside the reference's defined domain: make them identity
+    bad = ~np.isfinite(1.0 / np.linalg.norm(q, axis=1))
+    c["rotations"].reshape(-1, 4)[bad] = [0, 0, 0, 1]
+    want = oracle.pack(c, n, 0, False, 6)
+    got = gpu_encode(c, n, 0, False, 6, dev)
+    assert_bytes_equal(got, want, "dense sweep")
+
+
+def test_alpha_thresholds_every_step(dev, oracle):
+    """Every alpha byte boundary, +-2 ulp around each of the 255 thresholds."""
+    g = load_golden("tables.npz")
+    t = g["alpha_thresholds"]
+    vals = [t]
+    lo, hi = t.copy(), t.copy()
+    for _ in range(2):
+        lo = np.nextafter(lo, np.float32(-np.inf), dtype=np.float32)
+        hi = np.nextafter(hi, np.float32(np.inf), dtype=np.float32)
+        vals += [lo.copy(), hi.copy()]
+    al = np.concatenate(vals + [np.float32([np.inf, -np.inf, 0.0, -0.0, 3e38, -3e38])]).astype(np.float32)
+    n = al.size
+    z = lambda m: np.zeros(m, np.float32)
+    c = dict(positions=z(3 * n), scales=z(3 * n), rotations=np.tile(np.float32([0, 0, 0, 1]), n), alphas=al,
+             colors=z(3 * n), sh=z(0))
+    assert_bytes_equal(gpu_encode(c, n, 0, False, 0, dev), oracle.pack(c, n, 0, False, 0), "alpha thresholds")
+
+
+def test_v2_encode_round_trip_unpinned(dev, oracle):
+    """v2 ENCODE is 'parity unpinned' (the reference has no v2 encoder).  Checked by: identical
+    bytes to the oracle's restatement of the published upstream formula, decode through the
+    reference-pinned v2 decoder within half an LSB per component, and a fixed point under
+    encode(decode(encode(x)))."""
+    from spz_amd.synth import make_cloud_numpy
+    n, deg = 100_003, 1
+    c = make_cloud_numpy(n, deg, 21)
+    got = gpu_encode(c, n, deg, False, 6, dev, version=2)
+    assert_bytes_equal(got, oracle.pack(c, n, deg, False, 6, version=2), "v2 encode vs restatement")
+    _, u = gpu_decode(got, 6, dev)
+    rc, w = oracle.unpack(got, 6)
+    for k in FIELDS:
+        assert_bits_equal(u[k], w[k], f"v2 decode {k}")
+    q = c["rotations"].reshape(-1, 4).astype(np.float64)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q *= np.where(q[:, 3:4] < 0, -1.0, 1.0)
+    d = u["rotations"].reshape(-1, 4).astype(np.float64)
+    assert np.max(np.abs(d[:, :3] - q[:, :3])) <= 0.5 / 127.5 + 1e-6
+    again = gpu_encode(u, n, deg, False, 6, dev, version=2)
+    o_rot = 16 + 16 * n
+    assert_bytes_equal(again[o_rot:o_rot + 3 * n], got[o_rot:o_rot + 3 * n], "v2 rotation fixed point")
+
+
+def test_fused_flip_equals_two_pass(dev):
+    """BASELINE config 4: decode with `to` fused == decode to RUB followed by the standalone
+    convertCoordinates pass (the reference's own two-pass shape, load-spz.cc:529)."""
+    import torch
+    from spz_amd import abi, device as D
+    from spz_amd.synth import make_cloud_numpy
+    n, deg = 257_003, 3
+    c = make_cloud_numpy(n, deg, 31)
+    s = D.encode(D.to_device(c, dev), n, deg, False, abi.RDF)
+    h = D.make_header(n, deg)
+    for to in (abi.RDF, abi.LUF, abi.LDB, abi.RUF):
+        fused = D.decode(s, h, to)
+        two = D.decode(s, h, abi.UNSPECIFIED)
+        D.convert_coordinates(two, n, deg, abi.RUB, to)
+        torch.cuda.synchronize()
+        for k in FIELDS:
+            assert torch.equal(fused[k].view(torch.int32), two[k].view(torch.int32)), (to, k)
+
+
+def test_convert_coordinates_matches_oracle(dev, oracle):
+    import torch
+    from spz_amd import device as D
+    from spz_amd.synth import make_cloud_numpy
+    for n, deg in ((1, 0), (5, 1), (1001, 2), (65_537, 3)):
+        c = make_cloud_numpy(n, deg, 41 + n % 7)
+        c["positions"][0] = 0.0
+        c["sh"][:1] = -0.0
+        for frm, to in ((4, 6), (6, 7), (1, 8), (0, 5), (3, 3)):
+            t = D.to_device(c, dev)
+            D.convert_coordinates(t, n, deg, frm, to)
+            torch.cuda.synchronize()
+            p, r, s = oracle.convert_coordinates(c["positions"], c["rotations"], c["sh"], n, deg, frm, to)
+            assert_bits_equal(t["positions"].cpu().numpy(), p, "positions")
+            assert_bits_equal(t["rotations"].cpu().numpy(), r, "rotations")
+            assert_bits_equal(t["sh"].cpu().numpy(), s, "sh")
+
+
+def test_shards_reassemble_to_the_single_stream(dev):
+    """Point-range shards written at their global offsets give the same bytes as one encode, and
+    shard decodes concatenate to the full decode."""
+    import torch
+    from spz_amd import device as D
+    from spz_amd.synth import make_cloud_numpy, floats_per_point
+    n, deg = 100_003, 2
+    c = make_cloud_numpy(n, deg, 51)
+    t = D.to_device(c, dev)
+    whole = D.encode(t, n, deg, True, 6)
+    out = torch.zeros_like(whole)
+    cuts = [0, 1, 16, 33_333, 33_334, 70_001, n]
+    for i, (a, b) in enumerate(zip(cuts[:-1], cuts[1:])):
+        sub = {k: t[k][a * floats_per_point(k, deg):b * floats_per_point(k, deg)].contiguous() for k in FIELDS}
+        D.encode_shard(sub, a, b - a, n, deg, out, antialiased=True, from_coord=6, write_header=(i == 0))
+    torch.cuda.synchronize()
+    assert torch.equal(out, whole)
+    h = D.make_header(n, deg, antialiased=True)
+    full = D.decode(whole, h, 7)
+    for a, b in zip(cuts[:-1], cuts[1:]):
+        part = D.decode_shard(whole, h, a, b - a, 7)
+        torch.cuda.synchronize()
+        for k in FIELDS:
+            f = floats_per_point(k, deg)
+            assert torch.equal(part[k].view(torch.int32), full[k][a * f:b * f].view(torch.int32)), (a, b, k)
+
+
+def test_host_pointer_entry_points(dev, oracle):
+    """spz_amd_encode_host / spz_amd_decode_host (what the C++ saveSpz/loadSpz layer calls)."""
+    from spz_amd import abi
+    from spz_amd.synth import make_cloud_numpy
+    L = abi.load_library()
+    n, deg = 12_345, 3
+    c = make_cloud_numpy(n, deg, 61)
+    lay = abi.stream_layout(n, deg, 3)
+    out = np.zeros(lay.total_bytes, np.uint8)
+    p = abi.CloudPtrs(*[c[k].ctypes.data for k in FIELDS])
+    abi.check(L.spz_amd_encode_host(C.byref(p), n, deg, 1, 6, 3, out.ctypes.data, out.size, 0), "encode_host")
+    want = oracle.pack(c, n, deg, True, 6)
+    assert_bytes_equal(out, want, "encode_host")
+    u = {k: np.zeros_like(c[k]) for k in FIELDS}
+    q = abi.CloudPtrs(*[u[k].ctypes.data for k in FIELDS])
+    abi.check(L.spz_amd_decode_host(out.ctypes.data, out.size, 7, C.byref(q), 0), "decode_host")
+    rc, w = oracle.unpack(want, 7)
+    for k in FIELDS:
+        assert_bits_equal(u[k], w[k], f"decode_host {k}")
+
+
+def test_error_codes_on_device_entry_points(dev):
+    import torch
+    from spz_amd import abi, device as D
+    from spz_amd.synth import make_cloud_numpy
+    n, deg = 100, 1
+    t = D.to_device(make_cloud_numpy(n, deg, 71), dev)
+    small = torch.empty(100, dtype=torch.uint8, device=dev)
+    with pytest.raises(abi.SpzAmdError) as e:
+        D.encode(t, n, deg, out=small)
+    assert e.value.status == abi.ERR_CAPACITY
+    with pytest.raises(abi.SpzAmdError) as e:
+        D.encode(t, n, deg, version=1)
+    assert e.value.status == abi.ERR_UNSUPPORTED
+    s = D.encode(t, n, deg)
+    h = D.make_header(n, deg)
+    with pytest.raises(abi.SpzAmdError) as e:
+        D.decode(s[:-1], h)
+    assert e.value.status == abi.ERR_SHORT_STREAM
+    bad = D.make_header(n, deg, version=4)
+    with pytest.raises(abi.SpzAmdError) as e:
+        D.decode(s, bad)
+    assert e.value.status == abi.ERR_VERSION
+
+
+def test_full_size_properties_10m_sh3(dev, oracle):
+    """BASELINE config 3 size (10 M, SH3, v3) through size-independent properties:
+    (1) encode(decode(encode(x))) == encode(x) byte for byte (quantisation is idempotent),
+    (2) a 64 Ki-point window of the stream equals the oracle's encode of that window,
+    (3) fused RDF decode == RUB decode + standalone flip (config 4),
+    (4) the decoded window equals the oracle's decode."""
+    import torch
+    from spz_amd import abi, device as D
+    from spz_amd.synth import make_cloud_torch, floats_per_point
+    n, deg = 10_000_000, 3
+    t = make_cloud_torch(n, deg, 3, dev)
+    s1 = D.encode(t, n, deg, False, abi.RDF)
+    h = D.make_header(n, deg)
+    d1 = D.decode(s1, h, abi.RDF)
+    s2 = D.encode(d1, n, deg, False, abi.RDF)
+    torch.cuda.synchronize()
+    assert torch.equal(s1, s2), "encode∘decode∘encode is not a fixed point"
+    two = D.decode(s1, h, abi.UNSPECIFIED)
+    D.convert_coordinates(two, n, deg, abi.RUB, abi.RDF)
+    torch.cuda.synchronize()
+    for k in FIELDS:
+        assert torch.equal(two[k].view(torch.int32), d1[k].view(torch.int32)), k
+    del two, s2
+    a, w = 7_654_321, 65_536
+    sub = {k: t[k][a * floats_per_point(k, deg):(a + w) * floats_per_point(k, deg)].cpu().numpy() for k in FIELDS}
+    want = oracle.pack(sub, w, deg, False, abi.RDF)
+    lay_w = abi.stream_layout(w, deg, 3)
+    lay = abi.stream_layout(n, deg, 3)
+    s1_np = s1.cpu().numpy()
+    for sec in range(6):
+        bpp = lay.bytes_per_point[sec]
+        got = s1_np[lay.offset[sec] + a * bpp:lay.offset[sec] + (a + w) * bpp]
+        assert_bytes_equal(got, want[lay_w.offset[sec]:lay_w.offset[sec] + w * bpp], f"section {sec} window")
+    rc, uw = oracle.unpack(want, abi.RDF)
+    for k in FIELDS:
+        f = floats_per_point(k, deg)
+        assert_bits_equal(d1[k][a * f:(a + w) * f].cpu().numpy(), uw[k], f"decode window {k}")

@@ -1,0 +1,75 @@
+"""Pins the CPU restatement against the REFERENCE's own compiled C++ (oracle/_ref/libspz_ref.so)
+on fresh random inputs.  Runs wherever that library exists (the build container, and the GPU box
+since the built .so travels); skipped otherwise — the committed golden vectors then carry the pin."""
+import numpy as np
+import pytest
+
+from conftest import FIELDS, assert_bits_equal, assert_bytes_equal
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2, 3])
+def test_random_clouds_all_coordinate_pairs(oracle, reference, deg):
+    from spz_amd.synth import make_cloud_numpy
+    n = 3001
+    for frm in range(9):
+        c = make_cloud_numpy(n, deg, 500 + 10 * deg + frm)
+        so = oracle.pack(c, n, deg, True, frm)
+        sr = reference.pack(c, n, deg, True, frm)
+        assert_bytes_equal(so, sr, f"pack deg={deg} from={frm}")
+        to = (frm * 5 + 3) % 9
+        rc, uo = oracle.unpack(sr, to)
+        ur = reference.unpack(sr, n, deg, to)
+        assert rc == 0 and ur["num_points"] == n
+        for k in FIELDS:
+            assert_bits_equal(uo[k], ur[k], f"unpack deg={deg} to={to} {k}")
+
+
+def test_quaternion_helpers(oracle, reference):
+    import ctypes as C
+    rng = np.random.default_rng(8)
+    q = rng.standard_normal((20000, 4)).astype(np.float32)
+    q[:2000] = np.round(q[:2000])
+    q[np.all(q[:, :] == 0, axis=1)] = [0, 0, 0, 1]
+    want = reference.pack_quat(q.reshape(-1), 6)
+    conv = (C.c_float * 21)()
+    oracle.lib.spzo_coordinate_converter.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    oracle.lib.spzo_coordinate_converter(6, 4, conv)
+    oracle.lib.spzo_pack_quat_smallest_three.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    got = np.zeros(q.shape[0] * 4, np.uint8)
+    for i in range(q.shape[0]):
+        oracle.lib.spzo_pack_quat_smallest_three(got[4 * i:].ctypes.data, q[i].ctypes.data, conv)
+    assert_bytes_equal(got, want, "packQuaternionSmallestThree")
+
+
+def test_gzip_container_bytes(reference):
+    """The host gzip wrapper of the product (spz::compressGzipped in libspz_host.so) emits the same
+    bytes as the reference's (same zlib, same deflateInit2 parameters, load-spz.cc:186-214)."""
+    import spz_amd.spz as spz
+    rng = np.random.default_rng(3)
+    for size in (0, 1, 16, 8191, 8192, 8193, 300_000, 3_000_000):
+        data = (rng.integers(0, 256, size, dtype=np.uint16) >> (size % 3 + 2)).astype(np.uint8)
+        want = reference.compress_gzipped(data).tobytes()
+        assert want[:10] == bytes.fromhex("1f8b0800000000000003")
+        got = spz._compress_gzipped(data.tobytes())
+        assert got == want, f"gzip bytes differ for size {size}"
+        assert spz._decompress_gzipped(got) == data.tobytes()
+    assert spz._decompress_gzipped(b"This is not a valid SPZ file") is None
+    assert spz._decompress_gzipped(want[:-5]) is None  # truncated stream
+
+
+def test_half_to_float_all_values(oracle, reference):
+    hs = np.arange(65536, dtype=np.uint32)
+    a = np.array([oracle.lib.spzo_half_to_float(int(h)) for h in hs], np.float32)
+    b = np.array([reference.half_to_float(int(h)) for h in hs], np.float32)
+    assert_bits_equal(a, b, "halfToFloat")
+
+
+def test_convert_coordinates(oracle, reference):
+    from spz_amd.synth import make_cloud_numpy
+    n, deg = 777, 3
+    c = make_cloud_numpy(n, deg, 9)
+    for frm, to in ((4, 6), (6, 7), (1, 8), (0, 3), (5, 5)):
+        a = oracle.convert_coordinates(c["positions"], c["rotations"], c["sh"], n, deg, frm, to)
+        b = reference.convert_coordinates(c["positions"], c["rotations"], c["sh"], n, deg, frm, to)
+        for x, y, nm in zip(a, b, ("positions", "rotations", "sh")):
+            assert_bits_equal(x, y, nm)
