@@ -186,9 +186,19 @@ def main():
     # sanity inside the bench: the stream decodes back to what a re-encode reproduces
     fixed_point = None
     if frm == to and not (use_coll and rank == 0):
+        # quantisation is idempotent except for smallest-three near-ties (format property): every
+        # section but the rotations must re-encode to identical bytes
         s2 = D.encode(out, n, deg, False, to, ver)
         torch.cuda.synchronize()
-        fixed_point = bool(torch.equal(s2, stream))
+        o_rot = lay.offset[abi.SEC_ROTATIONS]
+        e_rot = o_rot + lay.bytes[abi.SEC_ROTATIONS]
+        rot_w = lay.bytes_per_point[abi.SEC_ROTATIONS]
+        fixed_point = {
+            "non_rotation_sections_identical": bool(torch.equal(s2[:o_rot], stream[:o_rot]) and
+                                                    torch.equal(s2[e_rot:], stream[e_rot:])),
+            "rotations_changed": int((s2[o_rot:e_rot].reshape(-1, rot_w) !=
+                                      stream[o_rot:e_rot].reshape(-1, rot_w)).any(dim=1).sum()),
+        }
 
     if rank == 0:
         bpp = algorithmic_bytes_per_point(deg, ver)

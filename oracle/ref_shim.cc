@@ -184,7 +184,7 @@ void ref_unpack_quat_smallest_three(const uint8_t *r, int32_t n, int to, float *
 void ref_unpack_quat_first_three(const uint8_t *r, int32_t n, int to, float *out) {
   spz::CoordinateConverter c = spz::coordinateConverter(spz::CoordinateSystem::RUB,
                                                         static_cast<spz::CoordinateSystem>(to));
-  for (int32_t i = 0; i < n; i++) spz::unpackQuaternionFirstThree(out + 4 * i, r + 4 * i, c);
+  for (int32_t i = 0; i < n; i++) spz::unpackQuaternionFirstThree(out + 4 * i, r + 3 * i, c);
 }
 
 float ref_half_to_float(uint16_t h) { return spz::halfToFloat(h); }

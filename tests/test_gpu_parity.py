@@ -382,7 +382,23 @@ def test_full_size_properties_10m_sh3(dev, oracle):
     d1 = D.decode(s1, h, abi.RDF)
     s2 = D.encode(d1, n, deg, False, abi.RDF)
     torch.cuda.synchronize()
-    assert torch.equal(s1, s2), "encode∘decode∘encode is not a fixed point"
+    lay = abi.stream_layout(n, deg, 3)
+    o_rot, e_rot = lay.offset[abi.SEC_ROTATIONS], lay.offset[abi.SEC_ROTATIONS] + lay.bytes[abi.SEC_ROTATIONS]
+    assert torch.equal(s1[:o_rot], s2[:o_rot]) and torch.equal(s1[e_rot:], s2[e_rot:]), \
+        "encode(decode(encode(x))) differs outside the rotation section"
+    # Smallest-three is not idempotent at near-ties (the decoded largest component can come out a hair
+    # below a 511-magnitude neighbour, so a re-encode picks the other index): that is the format, the
+    # reference does the same.  Such points must be rare and decode to the same rotation.
+    diff = (s1[o_rot:e_rot].reshape(-1, 4) != s2[o_rot:e_rot].reshape(-1, 4)).any(dim=1)
+    ndiff = int(diff.sum())
+    assert ndiff <= n // 10_000, f"{ndiff} rotations changed on re-encode"
+    if ndiff:
+        d2 = D.decode(s2, h, abi.RDF)
+        torch.cuda.synchronize()
+        qa = d1["rotations"].reshape(-1, 4)[diff].double()
+        qb = d2["rotations"].reshape(-1, 4)[diff].double()
+        assert float((1.0 - (qa * qb).sum(dim=1).abs()).max()) < 2e-5
+        del d2
     two = D.decode(s1, h, abi.UNSPECIFIED)
     D.convert_coordinates(two, n, deg, abi.RUB, abi.RDF)
     torch.cuda.synchronize()

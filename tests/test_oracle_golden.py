@@ -154,3 +154,36 @@ def test_alpha_thresholds_step_exactly(oracle):
     for v in range(1, 256):
         assert oracle.alpha_byte(t[v - 1]) >= v
         assert oracle.alpha_byte(below[v - 1]) < v
+
+
+def test_quaternion_golden_sets(oracle):
+    """Per-quaternion helpers against tests/golden/quats.npz (edge / near-tie encodes, arbitrary
+    32-bit decodes incl. sum-of-squares > 1 -> NaN, every v2 byte value)."""
+    import ctypes as C
+    g = load_golden("quats.npz")
+    L = oracle.lib
+    L.spzo_coordinate_converter.argtypes = [C.c_int, C.c_int, C.c_void_p]
+    for fn in ("spzo_pack_quat_smallest_three", "spzo_unpack_quat_smallest_three", "spzo_unpack_quat_first_three"):
+        getattr(L, fn).argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        getattr(L, fn).restype = None
+    conv = (C.c_float * 21)()
+    q = np.ascontiguousarray(g["enc_in"], np.float32).reshape(-1, 4)
+    for frm in (0, 6, 7, 1):
+        L.spzo_coordinate_converter(frm, 4, conv)
+        got = np.zeros(q.shape[0] * 4, np.uint8)
+        for i in range(q.shape[0]):
+            L.spzo_pack_quat_smallest_three(got[4 * i:].ctypes.data, q[i].ctypes.data, conv)
+        assert_bytes_equal(got, g[f"enc_bytes_from{frm}"], f"encode from={frm}")
+    rb = np.ascontiguousarray(g["dec3_bytes"])
+    r2 = np.ascontiguousarray(g["dec2_bytes"])
+    for to in (0, 6, 7):
+        L.spzo_coordinate_converter(4, to, conv)
+        out = np.zeros(rb.size, np.float32)
+        for i in range(rb.size // 4):
+            L.spzo_unpack_quat_smallest_three(out[4 * i:].ctypes.data, rb[4 * i:].ctypes.data, conv)
+        assert_bits_equal(out, g[f"dec3_to{to}"], f"v3 decode to={to}")
+        out = np.zeros(r2.size // 3 * 4, np.float32)
+        for i in range(r2.size // 3):
+            L.spzo_unpack_quat_first_three(out[4 * i:].ctypes.data, r2[3 * i:].ctypes.data, conv)
+        assert_bits_equal(out, g[f"dec2_to{to}"], f"v2 decode to={to}")
+    assert np.isnan(g["dec3_to0"]).any(), "the set must exercise the NaN (sum > 1) branch"
