@@ -79,7 +79,12 @@ def load_library():
         import torch  # noqa: F401
     except ImportError:
         pass
-    L = C.CDLL(LIB_PATH)
+    _lib = bind(C.CDLL(LIB_PATH))
+    return _lib
+
+
+def bind(L):
+    """Declare the C ABI's argument / result types on a loaded library handle."""
     vp, u64, i32, sz = C.c_void_p, C.c_uint64, C.c_int, C.c_size_t
     L.spz_amd_abi_version.restype = i32
     L.spz_amd_status_string.restype = C.c_char_p
@@ -112,7 +117,6 @@ def load_library():
     L.spz_amd_convert_coordinates_host.argtypes = [vp, vp, vp, u64, i32, i32, i32, i32]
     L.spz_amd_get_tables.restype = i32
     L.spz_amd_get_tables.argtypes = [vp, vp, vp]
-    _lib = L
     return L
 
 

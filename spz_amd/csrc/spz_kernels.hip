@@ -50,11 +50,27 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // Geometry
 // ------------------------------------------------------------------------------------------
-constexpr int kBlock = 256;
-constexpr int kUnroll = 4;
+// Launch geometry.  The defaults are the measured best on MI355X (profiles/); the macros exist so
+// that tools/tune.py can build variants.
+#ifndef SPZ_BLOCK
+#define SPZ_BLOCK 256
+#endif
+#ifndef SPZ_UNROLL
+#define SPZ_UNROLL 4
+#endif
+#ifndef SPZ_BLOCKS_PER_CU
+#define SPZ_BLOCKS_PER_CU 8
+#endif
+#ifndef SPZ_NT_LOAD
+#define SPZ_NT_LOAD 0
+#endif
+#ifndef SPZ_NT_STORE
+#define SPZ_NT_STORE 0
+#endif
+constexpr int kBlock = SPZ_BLOCK;
+constexpr int kUnroll = SPZ_UNROLL;
 constexpr int kTileUnits = kBlock * kUnroll;  // units per tile; one unit = 4 float elements
-static_assert(kTileUnits % 3 == 1, "position phase arithmetic assumes kTileUnits == 1 (mod 3)");
-constexpr int kMaxBlocksPerCU = 8;
+constexpr int kMaxBlocksPerCU = SPZ_BLOCKS_PER_CU;
 
 enum SecKind : uint32_t {
   KIND_POS24 = 0,  // 24-bit fixed point, 12 bytes per unit
@@ -109,6 +125,27 @@ struct __attribute__((packed, aligned(1))) U8x3 { uint8_t a, b, c; };
 
 struct Raw3 { uint32_t a, b, c; };
 
+typedef float v4f_t __attribute__((ext_vector_type(4)));
+typedef v4f_t v4f_a4 __attribute__((aligned(4)));
+typedef uint32_t u32_a1 __attribute__((aligned(1)));
+
+// Streaming accesses: every byte on this path is read once and written once, so the variants built
+// with SPZ_NT_LOAD / SPZ_NT_STORE mark them non-temporal.
+__device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) {
+#if SPZ_NT_LOAD
+  return __builtin_nontemporal_load(reinterpret_cast<const u32_a1 *>(p));
+#else
+  return *reinterpret_cast<const u32_a1 *>(p);
+#endif
+}
+__device__ __forceinline__ void st_u32(uint8_t *p, uint32_t v) {
+#if SPZ_NT_STORE
+  __builtin_nontemporal_store(v, reinterpret_cast<u32_a1 *>(p));
+#else
+  *reinterpret_cast<u32_a1 *>(p) = v;
+#endif
+}
+
 // ------------------------------------------------------------------------------------------
 // Exact scalar helpers
 // ------------------------------------------------------------------------------------------
@@ -133,6 +170,12 @@ __device__ __forceinline__ float mul_pm1(float v, uint32_t neg) {
   uint32_t b = __float_as_uint(v);
   uint32_t flipped = b ^ (neg << 31);
   return __uint_as_float(is_nan_bits(b) ? (b | 0x00400000u) : flipped);
+}
+
+// Same product for operands that cannot be NaN (or whose NaN sign cannot reach the output): a
+// plain sign-bit flip.
+__device__ __forceinline__ float xor_sign(float v, uint32_t neg) {
+  return __uint_as_float(__float_as_uint(v) ^ (neg << 31));
 }
 
 // std::round: half away from zero, exact (load-spz.cc:74,78,284).
@@ -183,9 +226,9 @@ __device__ __forceinline__ uint32_t pack_quat_smallest_three(F32x4 r, uint32_t f
   float n2 = fadd_sep(fadd_sep(fadd_sep(fmul_sep(r.x, r.x), fmul_sep(r.y, r.y)), fmul_sep(r.z, r.z)),
                       fmul_sep(r.w, r.w));
   float norm = __builtin_sqrtf(n2);
-  float q0 = mul_pm1(r.x / norm, flip_q & 1u);
-  float q1 = mul_pm1(r.y / norm, (flip_q >> 1) & 1u);
-  float q2 = mul_pm1(r.z / norm, (flip_q >> 2) & 1u);
+  float q0 = xor_sign(r.x / norm, flip_q & 1u);
+  float q1 = xor_sign(r.y / norm, (flip_q >> 1) & 1u);
+  float q2 = xor_sign(r.z / norm, (flip_q >> 2) & 1u);
   float q3 = r.w / norm;
   // argmax |q|, strict >, first wins
   uint32_t iL = 0;
@@ -214,9 +257,9 @@ __device__ __forceinline__ uint32_t pack_quat_first_three(F32x4 r, uint32_t flip
   float n2 = fadd_sep(fadd_sep(fadd_sep(fmul_sep(r.x, r.x), fmul_sep(r.y, r.y)), fmul_sep(r.z, r.z)),
                       fmul_sep(r.w, r.w));
   float norm = __builtin_sqrtf(n2);
-  float q0 = mul_pm1(r.x / norm, flip_q & 1u);
-  float q1 = mul_pm1(r.y / norm, (flip_q >> 1) & 1u);
-  float q2 = mul_pm1(r.z / norm, (flip_q >> 2) & 1u);
+  float q0 = xor_sign(r.x / norm, flip_q & 1u);
+  float q1 = xor_sign(r.y / norm, (flip_q >> 1) & 1u);
+  float q2 = xor_sign(r.z / norm, (flip_q >> 2) & 1u);
   float q3 = r.w / norm;
   float s = (q3 < 0.0f) ? -127.5f : 127.5f;
   uint32_t b0 = to_uint8(fmul_sep(q0, s) + 127.5f);
@@ -268,9 +311,9 @@ __device__ __forceinline__ F32x4 unpack_quat_first_three(uint32_t r3, uint32_t f
   float d = 1.0f - sq;
   float m = (0.0f < d) ? d : 0.0f;  // std::max(0.0f, d)
   F32x4 o;
-  o.x = mul_pm1(x, flip_q & 1u);
-  o.y = mul_pm1(y, (flip_q >> 1) & 1u);
-  o.z = mul_pm1(z, (flip_q >> 2) & 1u);
+  o.x = xor_sign(x, flip_q & 1u);
+  o.y = xor_sign(y, (flip_q >> 1) & 1u);
+  o.z = xor_sign(z, (flip_q >> 2) & 1u);
   o.w = __builtin_sqrtf(m);
   return o;
 }
@@ -311,8 +354,13 @@ template <int KIND>
 __device__ __forceinline__ Raw3 load_raw(const uint8_t *__restrict__ src, unsigned long long u) {
   Raw3 r = {0u, 0u, 0u};
   if constexpr (KIND == KIND_POS24) {
+#if SPZ_NT_LOAD
+    const uint8_t *q = src + u * 12ull;
+    r.a = ld_u32(q); r.b = ld_u32(q + 4); r.c = ld_u32(q + 8);
+#else
     U32x3 t = *reinterpret_cast<const U32x3 *>(src + u * 12ull);
     r.a = t.a; r.b = t.b; r.c = t.c;
+#endif
   } else if constexpr (KIND == KIND_POS16) {
     U32x2 t = *reinterpret_cast<const U32x2 *>(src + u * 8ull);
     r.a = t.a; r.b = t.b;
@@ -320,7 +368,7 @@ __device__ __forceinline__ Raw3 load_raw(const uint8_t *__restrict__ src, unsign
     U8x3 t = *reinterpret_cast<const U8x3 *>(src + u * 3ull);
     r.a = (uint32_t)t.a | ((uint32_t)t.b << 8) | ((uint32_t)t.c << 16);
   } else {
-    r.a = reinterpret_cast<const U32x1 *>(src + u * 4ull)->a;
+    r.a = ld_u32(src + u * 4ull);
   }
   return r;
 }
@@ -352,10 +400,10 @@ __device__ __forceinline__ F32x4 decode_unit(Raw3 raw, uint32_t phase, const Dec
     uint32_t v2 = (raw.b >> 16) | ((raw.c & 0xffu) << 16);
     uint32_t v3 = raw.c >> 8;
     uint32_t sb = pos_sign_bits(c.flip_p, phase);
-    o.x = mul_pm1((float)((int32_t)(v0 << 8) >> 8) * c.pos_scale, sb & 1u);
-    o.y = mul_pm1((float)((int32_t)(v1 << 8) >> 8) * c.pos_scale, (sb >> 1) & 1u);
-    o.z = mul_pm1((float)((int32_t)(v2 << 8) >> 8) * c.pos_scale, (sb >> 2) & 1u);
-    o.w = mul_pm1((float)((int32_t)(v3 << 8) >> 8) * c.pos_scale, (sb >> 3) & 1u);
+    o.x = xor_sign((float)((int32_t)(v0 << 8) >> 8) * c.pos_scale, sb & 1u);
+    o.y = xor_sign((float)((int32_t)(v1 << 8) >> 8) * c.pos_scale, (sb >> 1) & 1u);
+    o.z = xor_sign((float)((int32_t)(v2 << 8) >> 8) * c.pos_scale, (sb >> 2) & 1u);
+    o.w = xor_sign((float)((int32_t)(v3 << 8) >> 8) * c.pos_scale, (sb >> 3) & 1u);
   } else if constexpr (KIND == KIND_POS16) {
     uint32_t sb = pos_sign_bits(c.flip_p, phase);
     o.x = mul_pm1(half_to_float(raw.a), sb & 1u);
@@ -386,10 +434,10 @@ __device__ __forceinline__ F32x4 decode_unit(Raw3 raw, uint32_t phase, const Dec
     o = unpack_quat_first_three(raw.a, c.flip_q);
   } else {  // KIND_SH: (b - 128) / 128 (load-spz.cc:83), then flipSh of coefficient (e % D) / 3
     uint32_t sb = (uint32_t)(c.sh_mask_ext >> phase) & 0xfu;
-    o.x = mul_pm1(((float)(raw.a & 0xffu) - 128.0f) / 128.0f, sb & 1u);
-    o.y = mul_pm1(((float)((raw.a >> 8) & 0xffu) - 128.0f) / 128.0f, (sb >> 1) & 1u);
-    o.z = mul_pm1(((float)((raw.a >> 16) & 0xffu) - 128.0f) / 128.0f, (sb >> 2) & 1u);
-    o.w = mul_pm1(((float)(raw.a >> 24) - 128.0f) / 128.0f, (sb >> 3) & 1u);
+    o.x = xor_sign(((float)(raw.a & 0xffu) - 128.0f) / 128.0f, sb & 1u);
+    o.y = xor_sign(((float)((raw.a >> 8) & 0xffu) - 128.0f) / 128.0f, (sb >> 1) & 1u);
+    o.z = xor_sign(((float)((raw.a >> 16) & 0xffu) - 128.0f) / 128.0f, (sb >> 2) & 1u);
+    o.w = xor_sign(((float)(raw.a >> 24) - 128.0f) / 128.0f, (sb >> 3) & 1u);
   }
   return o;
 }
@@ -398,7 +446,7 @@ __device__ __forceinline__ F32x4 decode_unit(Raw3 raw, uint32_t phase, const Dec
 template <int KIND, int D>
 __device__ __forceinline__ uint32_t tile_phase_base(uint32_t tile_local) {
   if constexpr (KIND == KIND_POS24 || KIND == KIND_POS16 || KIND == KIND_FLIP_POS) {
-    return tile_local % 3u;  // kTileUnits == 1 (mod 3)
+    return ((tile_local % 3u) * ((uint32_t)kTileUnits % 3u)) % 3u;
   } else if constexpr ((KIND == KIND_SH || KIND == KIND_FLIP_SH) && D > 0) {
     return ((tile_local % (uint32_t)D) * ((4u * kTileUnits) % (uint32_t)D)) % (uint32_t)D;
   } else {
@@ -417,10 +465,22 @@ __device__ __forceinline__ uint32_t unit_phase(uint32_t base, uint32_t local) {
 }
 
 __device__ __forceinline__ void store_f4(float *__restrict__ dst, unsigned long long u, F32x4 v) {
+#if SPZ_NT_STORE
+  v4f_t t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<v4f_a4 *>(dst + u * 4ull));
+#else
   *reinterpret_cast<F32x4 *>(dst + u * 4ull) = v;
+#endif
 }
 __device__ __forceinline__ F32x4 load_f4(const float *__restrict__ src, unsigned long long u) {
+#if SPZ_NT_LOAD
+  v4f_t t = __builtin_nontemporal_load(reinterpret_cast<const v4f_a4 *>(src + u * 4ull));
+  F32x4 v;
+  v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w;
+  return v;
+#else
   return *reinterpret_cast<const F32x4 *>(src + u * 4ull);
+#endif
 }
 
 template <int KIND, int D>
@@ -533,10 +593,10 @@ __device__ __forceinline__ Raw3 encode_unit(F32x4 v, uint32_t phase, const Encod
   if constexpr (KIND == KIND_POS24) {
     // load-spz.cc:282-288: (int32)round(flipP * p * 4096), low 24 bits LE
     uint32_t sb = pos_sign_bits(c.flip_p, phase);
-    uint32_t f0 = (uint32_t)cvt_i32_x86(round_half_away(mul_pm1(v.x, sb & 1u) * 4096.0f)) & 0xffffffu;
-    uint32_t f1 = (uint32_t)cvt_i32_x86(round_half_away(mul_pm1(v.y, (sb >> 1) & 1u) * 4096.0f)) & 0xffffffu;
-    uint32_t f2 = (uint32_t)cvt_i32_x86(round_half_away(mul_pm1(v.z, (sb >> 2) & 1u) * 4096.0f)) & 0xffffffu;
-    uint32_t f3 = (uint32_t)cvt_i32_x86(round_half_away(mul_pm1(v.w, (sb >> 3) & 1u) * 4096.0f)) & 0xffffffu;
+    uint32_t f0 = (uint32_t)cvt_i32_x86(round_half_away(xor_sign(v.x, sb & 1u) * 4096.0f)) & 0xffffffu;
+    uint32_t f1 = (uint32_t)cvt_i32_x86(round_half_away(xor_sign(v.y, (sb >> 1) & 1u) * 4096.0f)) & 0xffffffu;
+    uint32_t f2 = (uint32_t)cvt_i32_x86(round_half_away(xor_sign(v.z, (sb >> 2) & 1u) * 4096.0f)) & 0xffffffu;
+    uint32_t f3 = (uint32_t)cvt_i32_x86(round_half_away(xor_sign(v.w, (sb >> 3) & 1u) * 4096.0f)) & 0xffffffu;
     o.a = f0 | (f1 << 24);
     o.b = (f1 >> 8) | (f2 << 16);
     o.c = (f2 >> 16) | (f3 << 8);
@@ -564,10 +624,10 @@ __device__ __forceinline__ Raw3 encode_unit(F32x4 v, uint32_t phase, const Encod
     j1 -= (j1 >= (uint32_t)D) ? (uint32_t)D : 0u;
     j2 -= (j2 >= (uint32_t)D) ? (uint32_t)D : 0u;
     j3 -= (j3 >= (uint32_t)D) ? (uint32_t)D : 0u;
-    o.a = quantize_sh(mul_pm1(v.x, sb & 1u), (j0 < 9u) ? 3u : 4u) |
-          (quantize_sh(mul_pm1(v.y, (sb >> 1) & 1u), (j1 < 9u) ? 3u : 4u) << 8) |
-          (quantize_sh(mul_pm1(v.z, (sb >> 2) & 1u), (j2 < 9u) ? 3u : 4u) << 16) |
-          (quantize_sh(mul_pm1(v.w, (sb >> 3) & 1u), (j3 < 9u) ? 3u : 4u) << 24);
+    o.a = quantize_sh(xor_sign(v.x, sb & 1u), (j0 < 9u) ? 3u : 4u) |
+          (quantize_sh(xor_sign(v.y, (sb >> 1) & 1u), (j1 < 9u) ? 3u : 4u) << 8) |
+          (quantize_sh(xor_sign(v.z, (sb >> 2) & 1u), (j2 < 9u) ? 3u : 4u) << 16) |
+          (quantize_sh(xor_sign(v.w, (sb >> 3) & 1u), (j3 < 9u) ? 3u : 4u) << 24);
   }
   return o;
 }
@@ -575,15 +635,20 @@ __device__ __forceinline__ Raw3 encode_unit(F32x4 v, uint32_t phase, const Encod
 template <int KIND>
 __device__ __forceinline__ void store_raw(uint8_t *__restrict__ dst, unsigned long long u, Raw3 r) {
   if constexpr (KIND == KIND_POS24) {
+#if SPZ_NT_STORE
+    uint8_t *q = dst + u * 12ull;
+    st_u32(q, r.a); st_u32(q + 4, r.b); st_u32(q + 8, r.c);
+#else
     U32x3 t;
     t.a = r.a; t.b = r.b; t.c = r.c;
     *reinterpret_cast<U32x3 *>(dst + u * 12ull) = t;
+#endif
   } else if constexpr (KIND == KIND_ROT_F3) {
     U8x3 t;
     t.a = (uint8_t)r.a; t.b = (uint8_t)(r.a >> 8); t.c = (uint8_t)(r.a >> 16);
     *reinterpret_cast<U8x3 *>(dst + u * 3ull) = t;
   } else {
-    reinterpret_cast<U32x1 *>(dst + u * 4ull)->a = r.a;
+    st_u32(dst + u * 4ull, r.a);
   }
 }
 

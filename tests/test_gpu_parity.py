@@ -208,7 +208,7 @@ def test_fma_sensitive_dense_sweep(dev, oracle):
     q[: n // 4] = np.round(q[: n // 4] * 2) / 2  # many exact ties / equal magnitudes
     c = dict(positions=pos, scales=sc, rotations=q.reshape(-1), alphas=al, colors=col, sh=z(0))
     # zero-norm quaternions are outside the reference's defined domain: make them identity
-    bad = ~np.isfinite(1.0 / np.linalg.norm(q, axis=1))
+    bad = np.linalg.norm(q, axis=1) == 0
     c["rotations"].reshape(-1, 4)[bad] = [0, 0, 0, 1]
     want = oracle.pack(c, n, 0, False, 6)
     got = gpu_encode(c, n, 0, False, 6, dev)
@@ -252,9 +252,17 @@ def test_v2_encode_round_trip_unpinned(dev, oracle):
     q *= np.where(q[:, 3:4] < 0, -1.0, 1.0)
     d = u["rotations"].reshape(-1, 4).astype(np.float64)
     assert np.max(np.abs(d[:, :3] - q[:, :3])) <= 0.5 / 127.5 + 1e-6
+    # Fixed point of encode(decode(.)): holds wherever the decoded w was not clamped.  When the three
+    # quantised components already have norm >= 1 the decoder clamps w to 0 (load-spz.cc:344), the
+    # re-encode renormalises, and a byte can move by one: a property of the v2 format itself.
     again = gpu_encode(u, n, deg, False, 6, dev, version=2)
     o_rot = 16 + 16 * n
-    assert_bytes_equal(again[o_rot:o_rot + 3 * n], got[o_rot:o_rot + 3 * n], "v2 rotation fixed point")
+    a = again[o_rot:o_rot + 3 * n].reshape(-1, 3)
+    b = got[o_rot:o_rot + 3 * n].reshape(-1, 3)
+    moved = (a != b).any(axis=1)
+    assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
+    assert moved.sum() <= n // 1000
+    assert np.all(d[moved, 3] < 0.13), "a rotation moved on re-encode although w was not near the clamp"
 
 
 def test_fused_flip_equals_two_pass(dev):
@@ -419,3 +427,52 @@ def test_full_size_properties_10m_sh3(dev, oracle):
     for k in FIELDS:
         f = floats_per_point(k, deg)
         assert_bits_equal(d1[k][a * f:(a + w) * f].cpu().numpy(), uw[k], f"decode window {k}")
+
+
+def test_baseline_config2_1m_sh0_v2(dev, oracle):
+    """BASELINE configs[1]: 1 M synthetic Gaussians, SH degree 0, v2 format, encode+decode.
+    v2 decode is pinned (reference decoder via the oracle); v2 encode is 'parity unpinned' and is
+    compared with the oracle's restatement of the published upstream encoder."""
+    from spz_amd.synth import make_cloud_numpy
+    n, deg = 1_000_000, 0
+    c = make_cloud_numpy(n, deg, 2)
+    got = gpu_encode(c, n, deg, False, 0, dev, version=2)
+    want = oracle.pack(c, n, deg, False, 0, version=2)
+    assert got.size == 16 + 19 * n
+    assert_bytes_equal(got, want, "cfg2 v2 encode")
+    # every section except the rotations is the same arithmetic as v3 and therefore pinned:
+    v3 = oracle.pack(c, n, deg, False, 0, version=3)
+    assert_bytes_equal(got[16:16 + 16 * n], v3[16:16 + 16 * n], "cfg2 non-rotation sections vs reference v3")
+    _, u = gpu_decode(got, 0, dev)
+    rc, w = oracle.unpack(got, 0)
+    assert rc == 0
+    for k in FIELDS:
+        assert_bits_equal(u[k], w[k], f"cfg2 decode {k}")
+
+
+def test_baseline_config1_ply_to_spz_60k(dev, reference, tmp_path):
+    """BASELINE configs[0]: a 60 k-point SH3 .ply (synthetic stand-in for the absent
+    samples/mic_60k.ply) -> .spz with the CLI's options (UNSPECIFIED/UNSPECIFIED).
+    The .spz file must be byte-identical to the reference's saveSpz of the same cloud, and load
+    back to the reference's floats."""
+    import spz_amd.spz as spz
+    from spz_amd.synth import make_cloud_numpy
+    n, deg = 60_000, 3
+    c = make_cloud_numpy(n, deg, 60)
+    src = spz.GaussianCloud()
+    src.sh_degree = deg
+    for k in FIELDS:
+        setattr(src, k, c[k])
+    ply = str(tmp_path / "mic_60k_standin.ply")
+    assert spz.save_splat_to_ply(src, spz.PackOptions(), ply) is True
+    loaded = spz.load_splat_from_ply(ply, spz.UnpackOptions())
+    for k in FIELDS:
+        assert np.array_equal(getattr(loaded, k), c[k]), k  # PLY is lossless
+    out = str(tmp_path / "mic_60k_standin.spz")
+    assert spz.save_spz(loaded, spz.PackOptions(), out) is True
+    want = reference.save_spz(c, n, deg, False, 0)
+    assert open(out, "rb").read() == want.tobytes(), ".spz bytes differ from the reference's saveSpz"
+    back = spz.load_spz(out, spz.UnpackOptions())
+    ref_back = reference.load_spz(want, n, deg, 0)
+    for k in FIELDS:
+        assert_bits_equal(getattr(back, k), ref_back[k], f"cfg1 load {k}")

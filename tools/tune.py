@@ -1,0 +1,128 @@
+#!/usr/bin/env python3
+"""Build-variant tuner: times encode / decode of the bench workload for several builds of
+spz_kernels.hip (launch geometry, non-temporal accesses) in ONE process, interleaved rounds,
+HIP-event timing, median + min reported (cdna_hip_programming.md §5.4 rule 24).
+
+  python tools/tune.py build            # in the container: hipcc every variant -> build/variants/
+  python tools/tune.py run [--points N] # on the GPU box: time them
+"""
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+VDIR = os.path.join(ROOT, "build", "variants")
+
+VARIANTS = {
+    "base":      {},
+    "u2":        {"SPZ_UNROLL": 2},
+    "u8":        {"SPZ_UNROLL": 8},
+    "b512":      {"SPZ_BLOCK": 512, "SPZ_BLOCKS_PER_CU": 4},
+    "b512u2":    {"SPZ_BLOCK": 512, "SPZ_UNROLL": 2, "SPZ_BLOCKS_PER_CU": 4},
+    "bpc4":      {"SPZ_BLOCKS_PER_CU": 4},
+    "bpc16":     {"SPZ_BLOCKS_PER_CU": 16},
+    "bpc64":     {"SPZ_BLOCKS_PER_CU": 64},
+    "flat":      {"SPZ_BLOCKS_PER_CU": 100000},   # one tile per block, no persistent loop in effect
+    "nt":        {"SPZ_NT_LOAD": 1, "SPZ_NT_STORE": 1},
+    "nts":       {"SPZ_NT_STORE": 1},
+    "ntl":       {"SPZ_NT_LOAD": 1},
+    "u8nt":      {"SPZ_UNROLL": 8, "SPZ_NT_LOAD": 1, "SPZ_NT_STORE": 1},
+}
+
+
+def build(names):
+    os.makedirs(VDIR, exist_ok=True)
+    for name in names:
+        defs = [f"-D{k}={v}" for k, v in VARIANTS[name].items()]
+        out = os.path.join(VDIR, f"libspz_amd_{name}.so")
+        cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
+               "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", f"-I{ROOT}/include", "-shared",
+               "-o", out, os.path.join(ROOT, "spz_amd", "csrc", "spz_kernels.hip")] + defs
+        print(" ".join(cmd[-4:]), flush=True)
+        subprocess.run(cmd, check=True)
+
+
+def run(points, rounds, names, deg=3):
+    import statistics
+
+    import torch
+
+    from spz_amd import abi
+    from spz_amd.synth import FIELDS, make_cloud_torch
+    dev = torch.device("cuda:0")
+    cloud = make_cloud_torch(points, deg, 3, dev)
+    out = {k: torch.empty_like(cloud[k]) for k in FIELDS}
+    lay = abi.stream_layout(points, deg, 3)
+    stream = torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev)
+    ref_stream = None
+    pin = abi.CloudPtrs(*[cloud[k].data_ptr() for k in FIELDS])
+    pout = abi.CloudPtrs(*[out[k].data_ptr() for k in FIELDS])
+    hdr = abi.Header(3, points, deg, 12, 0, 0)
+    libs = {}
+    for name in names:
+        path = os.path.join(VDIR, f"libspz_amd_{name}.so")
+        if not os.path.exists(path):
+            print(f"skip {name}: {path} missing")
+            continue
+        L = C.CDLL(path)
+        abi.bind(L)
+        libs[name] = L
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def enc(L):
+        rc = L.spz_amd_encode_device(C.byref(pin), points, deg, 0, 6, 3, stream.data_ptr(), stream.numel(), s)
+        assert rc == 0, rc
+
+    def dec(L):
+        rc = L.spz_amd_decode_device(stream.data_ptr(), stream.numel(), C.byref(hdr), 6, C.byref(pout), s)
+        assert rc == 0, rc
+
+    times = {n: {"enc": [], "dec": []} for n in libs}
+    for name, L in libs.items():   # warm-up + cross-variant parity
+        enc(L); dec(L)
+        torch.cuda.synchronize()
+        if ref_stream is None:
+            ref_stream = stream.clone()
+            ref_out = {k: out[k].clone() for k in FIELDS}
+        else:
+            assert torch.equal(stream, ref_stream), f"{name}: stream differs from base"
+            for k in FIELDS:
+                assert torch.equal(out[k].view(torch.int32), ref_out[k].view(torch.int32)), f"{name}: {k} differs"
+    for _ in range(rounds):
+        for name, L in libs.items():
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record(); enc(L); e[1].record(); dec(L); e[2].record()
+            torch.cuda.synchronize()
+            times[name]["enc"].append(e[0].elapsed_time(e[1]))
+            times[name]["dec"].append(e[1].elapsed_time(e[2]))
+    bpp = {0: 76, 1: 121, 2: 196, 3: 301}[deg]
+    gb = points * bpp / 1e9
+    rows = []
+    for name in libs:
+        r = {"variant": name}
+        for k in ("enc", "dec"):
+            med, mn = statistics.median(times[name][k]), min(times[name][k])
+            r[f"{k}_ms_med"] = round(med, 4)
+            r[f"{k}_ms_min"] = round(mn, 4)
+            r[f"{k}_GBps_med"] = round(gb / (med * 1e-3), 1)
+        rows.append(r)
+        print(json.dumps(r), flush=True)
+    return rows
+
+
+if __name__ == "__main__":
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("mode", choices=["build", "run"])
+    ap.add_argument("--points", type=int, default=10_000_000)
+    ap.add_argument("--rounds", type=int, default=15)
+    ap.add_argument("--variants", default=",".join(VARIANTS))
+    a = ap.parse_args()
+    names = [v for v in a.variants.split(",") if v]
+    if a.mode == "build":
+        build(names)
+    else:
+        run(a.points, a.rounds, names)
