@@ -67,6 +67,9 @@ namespace {
 #ifndef SPZ_NT_STORE
 #define SPZ_NT_STORE 0
 #endif
+#ifndef SPZ_WAVE_CONTIG
+#define SPZ_WAVE_CONTIG 0
+#endif
 constexpr int kBlock = SPZ_BLOCK;
 constexpr int kUnroll = SPZ_UNROLL;
 constexpr int kTileUnits = kBlock * kUnroll;  // units per tile; one unit = 4 float elements
@@ -85,6 +88,16 @@ enum SecKind : uint32_t {
   KIND_FLIP_ROT,
   KIND_FLIP_SH,
 };
+
+// Unit handled by thread `tid` in round `r` of a tile.  Default: rounds stride the whole block (a
+// wave touches kUnroll separate 1 KiB spans); SPZ_WAVE_CONTIG: a wave owns one contiguous span.
+__device__ __forceinline__ uint32_t local_unit(int r, uint32_t tid) {
+#if SPZ_WAVE_CONTIG
+  return ((tid >> 6) * (uint32_t)kUnroll + (uint32_t)r) * 64u + (tid & 63u);
+#else
+  return (uint32_t)(r * kBlock) + tid;
+#endif
+}
 
 struct SecDesc {
   uint8_t *bytes;              // stream side (encode writes, decode reads); unused by flip kinds
@@ -494,16 +507,16 @@ __device__ __forceinline__ void decode_tile(const SecDesc &s, uint32_t tile_loca
   if (base + kTileUnits <= full_units) {
     Raw3 raw[kUnroll];
 #pragma unroll
-    for (int r = 0; r < kUnroll; ++r) raw[r] = load_raw<KIND>(src, base + (uint32_t)(r * kBlock) + tid);
+    for (int r = 0; r < kUnroll; ++r) raw[r] = load_raw<KIND>(src, base + local_unit(r, tid));
 #pragma unroll
     for (int r = 0; r < kUnroll; ++r) {
-      const uint32_t local = (uint32_t)(r * kBlock) + tid;
+      const uint32_t local = local_unit(r, tid);
       store_f4(dst, base + local, decode_unit<KIND, D>(raw[r], unit_phase<KIND, D>(pb, local), c));
     }
   } else {
 #pragma unroll
     for (int r = 0; r < kUnroll; ++r) {
-      const uint32_t local = (uint32_t)(r * kBlock) + tid;
+      const uint32_t local = local_unit(r, tid);
       const unsigned long long u = base + local;
       if (u < full_units) {
         store_f4(dst, u, decode_unit<KIND, D>(load_raw<KIND>(src, u), unit_phase<KIND, D>(pb, local), c));
@@ -663,16 +676,16 @@ __device__ __forceinline__ void encode_tile(const SecDesc &s, uint32_t tile_loca
   if (base + kTileUnits <= full_units) {
     F32x4 v[kUnroll];
 #pragma unroll
-    for (int r = 0; r < kUnroll; ++r) v[r] = load_f4(src, base + (uint32_t)(r * kBlock) + tid);
+    for (int r = 0; r < kUnroll; ++r) v[r] = load_f4(src, base + local_unit(r, tid));
 #pragma unroll
     for (int r = 0; r < kUnroll; ++r) {
-      const uint32_t local = (uint32_t)(r * kBlock) + tid;
+      const uint32_t local = local_unit(r, tid);
       store_raw<KIND>(dst, base + local, encode_unit<KIND, D>(v[r], unit_phase<KIND, D>(pb, local), c));
     }
   } else {
 #pragma unroll
     for (int r = 0; r < kUnroll; ++r) {
-      const uint32_t local = (uint32_t)(r * kBlock) + tid;
+      const uint32_t local = local_unit(r, tid);
       const unsigned long long u = base + local;
       if (u < full_units) {
         store_raw<KIND>(dst, u, encode_unit<KIND, D>(load_f4(src, u), unit_phase<KIND, D>(pb, local), c));
@@ -765,7 +778,7 @@ __device__ __forceinline__ void flip_tile(const SecDesc &s, uint32_t tile_local,
   const uint32_t pb = tile_phase_base<KIND, D>(tile_local);
 #pragma unroll
   for (int r = 0; r < kUnroll; ++r) {
-    const uint32_t local = (uint32_t)(r * kBlock) + tid;
+    const uint32_t local = local_unit(r, tid);
     const unsigned long long u = base + local;
     const uint32_t ph = unit_phase<KIND, D>(pb, local);
     if (u < full_units) {

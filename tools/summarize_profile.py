@@ -1,0 +1,106 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 output directories (gpurun_out/prof_*_<tag>) into the small, judged files
+under profiles/: kernel stats of the spz kernels only, and per-launch HBM traffic from the
+FETCH_SIZE / WRITE_SIZE passes (corrected as MI355X_MICROARCH.md §HBM prescribes).
+
+usage: python tools/summarize_profile.py <tag> [--points N --sh-degree D]
+"""
+import argparse
+import csv
+import glob
+import json
+import os
+import statistics
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+csv.field_size_limit(1 << 30)
+
+
+def find(tag, kind, suffix):
+    pats = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{kind}_{tag}", "**", f"*_{suffix}.csv"), recursive=True)
+    return pats[0] if pats else None
+
+
+def short(name):
+    for k in ("spz_decode_kernel", "spz_encode_kernel", "spz_flip_kernel"):
+        if k in name:
+            return k
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("tag")
+    ap.add_argument("--points", type=int, default=10_000_000)
+    ap.add_argument("--sh-degree", type=int, default=3)
+    a = ap.parse_args()
+    out_dir = os.path.join(ROOT, "profiles")
+    os.makedirs(out_dir, exist_ok=True)
+    summary = {"tag": a.tag, "points": a.points, "sh_degree": a.sh_degree}
+
+    ks = find(a.tag, "stats", "kernel_stats")
+    if ks:
+        rows = []
+        with open(ks) as f:
+            for r in csv.DictReader(f):
+                s = short(r["Name"])
+                rows.append({**r, "Name": s if s else (r["Name"][:60] + "...")})
+        with open(os.path.join(out_dir, f"{a.tag}_kernel_stats.csv"), "w", newline="") as f:
+            w = csv.DictWriter(f, fieldnames=list(rows[0].keys()))
+            w.writeheader()
+            w.writerows(rows)
+        for r in rows:
+            if r["Name"] in ("spz_decode_kernel", "spz_encode_kernel"):
+                summary[r["Name"]] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
+                                      "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3}
+
+    d = {0: 0, 1: 9, 2: 24, 3: 45}[a.sh_degree]
+    float_bytes = a.points * (14 + d) * 4
+    packed_bytes = a.points * (20 + d)
+    traffic = {}
+    for kind, counter in (("fetch", "FETCH_SIZE"), ("write", "WRITE_SIZE")):
+        cc = find(a.tag, kind, "counter_collection")
+        if not cc:
+            continue
+        per = {}
+        with open(cc) as f:
+            for r in csv.DictReader(f):
+                s = short(r["Kernel_Name"])
+                if s and r["Counter_Name"] == counter:
+                    per.setdefault(s, []).append(float(r["Counter_Value"]))
+        for s, vals in per.items():
+            traffic.setdefault(s, {})[counter + "_KB_median"] = statistics.median(vals)
+            traffic[s][counter + "_launches"] = len(vals)
+    # corrections (MI355X_MICROARCH.md §HBM): counters are in KiB; FETCH_SIZE reads exactly half the
+    # bytes of a 16-B-per-lane streaming read -> doubled where the kernel reads 16 B per lane (encode's
+    # float reads); WRITE_SIZE is exact for 16-B-per-lane stores (decode's float writes).  The
+    # 4-B-per-lane side of each kernel is an uncalibrated width: reported as counted.
+    for s, t in traffic.items():
+        f = t.get("FETCH_SIZE_KB_median")
+        w = t.get("WRITE_SIZE_KB_median")
+        if f is None or w is None:
+            continue
+        if s == "spz_encode_kernel":
+            fetch_b, note = f * 1024 * 2, "FETCH_SIZE x2 (16 B/lane streaming reads); WRITE_SIZE as counted (4 B/lane stores, uncalibrated width)"
+            alg_r, alg_w = float_bytes, packed_bytes
+        else:
+            fetch_b, note = f * 1024, "FETCH_SIZE as counted (4 B/lane reads, uncalibrated width; x2 would be the 16-B rule); WRITE_SIZE exact (16 B/lane stores)"
+            alg_r, alg_w = packed_bytes, float_bytes
+        t.update({"hbm_read_bytes": fetch_b, "hbm_write_bytes": w * 1024, "hbm_bytes_per_launch": fetch_b + w * 1024,
+                  "algorithmic_read_bytes": alg_r, "algorithmic_write_bytes": alg_w,
+                  "traffic_over_algorithmic": (fetch_b + w * 1024) / (alg_r + alg_w), "correction": note})
+    summary["traffic"] = traffic
+    with open(os.path.join(out_dir, f"{a.tag}_summary.json"), "w") as f:
+        json.dump(summary, f, indent=1)
+    if "spz_decode_kernel" in traffic and "hbm_bytes_per_launch" in traffic["spz_decode_kernel"]:
+        with open(os.path.join(out_dir, "pmc_traffic.json"), "w") as f:
+            json.dump({"tag": a.tag, "points": a.points, "sh_degree": a.sh_degree,
+                       "decode_hbm_bytes_per_launch": traffic["spz_decode_kernel"]["hbm_bytes_per_launch"],
+                       "encode_hbm_bytes_per_launch": traffic.get("spz_encode_kernel", {}).get("hbm_bytes_per_launch"),
+                       "source": f"profiles/{a.tag}_summary.json"}, f, indent=1)
+    print(json.dumps(summary, indent=1))
+
+
+if __name__ == "__main__":
+    main()

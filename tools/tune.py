@@ -16,20 +16,29 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "build", "variants")
 
+F = {"SPZ_BLOCKS_PER_CU": 100000}   # "flat": one tile per block
+
 VARIANTS = {
-    "base":      {},
-    "u2":        {"SPZ_UNROLL": 2},
-    "u8":        {"SPZ_UNROLL": 8},
-    "b512":      {"SPZ_BLOCK": 512, "SPZ_BLOCKS_PER_CU": 4},
-    "b512u2":    {"SPZ_BLOCK": 512, "SPZ_UNROLL": 2, "SPZ_BLOCKS_PER_CU": 4},
-    "bpc4":      {"SPZ_BLOCKS_PER_CU": 4},
-    "bpc16":     {"SPZ_BLOCKS_PER_CU": 16},
-    "bpc64":     {"SPZ_BLOCKS_PER_CU": 64},
-    "flat":      {"SPZ_BLOCKS_PER_CU": 100000},   # one tile per block, no persistent loop in effect
-    "nt":        {"SPZ_NT_LOAD": 1, "SPZ_NT_STORE": 1},
-    "nts":       {"SPZ_NT_STORE": 1},
-    "ntl":       {"SPZ_NT_LOAD": 1},
-    "u8nt":      {"SPZ_UNROLL": 8, "SPZ_NT_LOAD": 1, "SPZ_NT_STORE": 1},
+    "base":       {},
+    "flat":       dict(F),
+    "flat_u1":    dict(F, SPZ_UNROLL=1),
+    "flat_u2":    dict(F, SPZ_UNROLL=2),
+    "flat_u8":    dict(F, SPZ_UNROLL=8),
+    "flat_u16":   dict(F, SPZ_UNROLL=16),
+    "flat_b64":   dict(F, SPZ_BLOCK=64),
+    "flat_b64u8": dict(F, SPZ_BLOCK=64, SPZ_UNROLL=8),
+    "flat_b128":  dict(F, SPZ_BLOCK=128),
+    "flat_b128u8": dict(F, SPZ_BLOCK=128, SPZ_UNROLL=8),
+    "flat_b512":  dict(F, SPZ_BLOCK=512),
+    "flat_b512u2": dict(F, SPZ_BLOCK=512, SPZ_UNROLL=2),
+    "flat_b1024u1": dict(F, SPZ_BLOCK=1024, SPZ_UNROLL=1),
+    "flat_ntl":   dict(F, SPZ_NT_LOAD=1),
+    "flat_nts":   dict(F, SPZ_NT_STORE=1),
+    "flat_nt":    dict(F, SPZ_NT_LOAD=1, SPZ_NT_STORE=1),
+    "flat_wc":    dict(F, SPZ_WAVE_CONTIG=1),
+    "flat_u8wc":  dict(F, SPZ_UNROLL=8, SPZ_WAVE_CONTIG=1),
+    "bpc64":      {"SPZ_BLOCKS_PER_CU": 64},
+    "bpc32u8":    {"SPZ_BLOCKS_PER_CU": 32, "SPZ_UNROLL": 8},
 }
 
 
