@@ -13,7 +13,7 @@
 //
 // Design: this is an HBM-bound byte transform, no MFMA.  ONE
 // launch per direction covers all six sections: the grid is a flat list of
-// tiles (256 threads x kUnroll "units"), a block finds its section with a few
+// tiles (256 threads x UNROLL "units", one tile per block), a block finds its section with a few
 // wave-uniform scalar compares and runs that section's body.  A unit is four
 // consecutive float elements (one 16-byte access on the float side) and the
 // 4 / 12 / 8 / 3 packed bytes they map to, so both sides of every section are
@@ -50,29 +50,63 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // Geometry
 // ------------------------------------------------------------------------------------------
-// Launch geometry.  The defaults are the measured best on MI355X (profiles/); the macros exist so
-// that tools/tune.py can build variants.
-#ifndef SPZ_BLOCK
-#define SPZ_BLOCK 256
+// Launch geometry, per kernel.  A tile is BLOCK threads x UNROLL units.  The defaults are the
+// measured best on MI355X (profiles/README.md); the macros exist so that tools/tune.py can build
+// variants.  WC: a wave owns one contiguous span of its tile instead of UNROLL strided 1 KiB spans.
+// NTL / NTS: non-temporal loads / stores (every byte on this path is touched exactly once).
+#ifndef SPZ_DEC_BLOCK
+#define SPZ_DEC_BLOCK 256
 #endif
-#ifndef SPZ_UNROLL
-#define SPZ_UNROLL 4
+#ifndef SPZ_DEC_UNROLL
+#define SPZ_DEC_UNROLL 8
 #endif
+#ifndef SPZ_DEC_WC
+#define SPZ_DEC_WC 0
+#endif
+#ifndef SPZ_DEC_NTL
+#define SPZ_DEC_NTL 0
+#endif
+#ifndef SPZ_DEC_NTS
+#define SPZ_DEC_NTS 0
+#endif
+#ifndef SPZ_ENC_BLOCK
+#define SPZ_ENC_BLOCK 256
+#endif
+#ifndef SPZ_ENC_UNROLL
+#define SPZ_ENC_UNROLL 4
+#endif
+#ifndef SPZ_ENC_WC
+#define SPZ_ENC_WC 1
+#endif
+#ifndef SPZ_ENC_NTL
+#define SPZ_ENC_NTL 1
+#endif
+#ifndef SPZ_ENC_NTS
+#define SPZ_ENC_NTS 0
+#endif
+// 0: one tile per block ("flat" grid, measured faster than a persistent grid-stride loop: a wave's
+// next loads would queue behind its own stores in the in-order vmcnt).  k > 0: at most k blocks per CU.
 #ifndef SPZ_BLOCKS_PER_CU
-#define SPZ_BLOCKS_PER_CU 8
+#define SPZ_BLOCKS_PER_CU 0
 #endif
-#ifndef SPZ_NT_LOAD
-#define SPZ_NT_LOAD 0
-#endif
-#ifndef SPZ_NT_STORE
-#define SPZ_NT_STORE 0
-#endif
-#ifndef SPZ_WAVE_CONTIG
-#define SPZ_WAVE_CONTIG 0
-#endif
-constexpr int kBlock = SPZ_BLOCK;
-constexpr int kUnroll = SPZ_UNROLL;
-constexpr int kTileUnits = kBlock * kUnroll;  // units per tile; one unit = 4 float elements
+
+template <int BLOCK_, int UNROLL_, bool WC_, bool NTL_, bool NTS_>
+struct Geom {
+  static constexpr int kBlock = BLOCK_;
+  static constexpr int kUnroll = UNROLL_;
+  static constexpr int kTileUnits = BLOCK_ * UNROLL_;  // one unit = 4 float elements
+  static constexpr bool kWaveContig = WC_;
+  static constexpr bool kNtLoad = NTL_;
+  static constexpr bool kNtStore = NTS_;
+  // Unit handled by thread `tid` in round `r` of a tile.
+  __device__ static __forceinline__ uint32_t local_unit(int r, uint32_t tid) {
+    if constexpr (WC_) return ((tid >> 6) * (uint32_t)UNROLL_ + (uint32_t)r) * 64u + (tid & 63u);
+    else return (uint32_t)(r * BLOCK_) + tid;
+  }
+};
+using DecGeom = Geom<SPZ_DEC_BLOCK, SPZ_DEC_UNROLL, SPZ_DEC_WC != 0, SPZ_DEC_NTL != 0, SPZ_DEC_NTS != 0>;
+using EncGeom = Geom<SPZ_ENC_BLOCK, SPZ_ENC_UNROLL, SPZ_ENC_WC != 0, SPZ_ENC_NTL != 0, SPZ_ENC_NTS != 0>;
+using FlipGeom = Geom<256, 4, false, false, false>;
 constexpr int kMaxBlocksPerCU = SPZ_BLOCKS_PER_CU;
 
 enum SecKind : uint32_t {
@@ -88,16 +122,6 @@ enum SecKind : uint32_t {
   KIND_FLIP_ROT,
   KIND_FLIP_SH,
 };
-
-// Unit handled by thread `tid` in round `r` of a tile.  Default: rounds stride the whole block (a
-// wave touches kUnroll separate 1 KiB spans); SPZ_WAVE_CONTIG: a wave owns one contiguous span.
-__device__ __forceinline__ uint32_t local_unit(int r, uint32_t tid) {
-#if SPZ_WAVE_CONTIG
-  return ((tid >> 6) * (uint32_t)kUnroll + (uint32_t)r) * 64u + (tid & 63u);
-#else
-  return (uint32_t)(r * kBlock) + tid;
-#endif
-}
 
 struct SecDesc {
   uint8_t *bytes;              // stream side (encode writes, decode reads); unused by flip kinds
@@ -142,21 +166,15 @@ typedef float v4f_t __attribute__((ext_vector_type(4)));
 typedef v4f_t v4f_a4 __attribute__((aligned(4)));
 typedef uint32_t u32_a1 __attribute__((aligned(1)));
 
-// Streaming accesses: every byte on this path is read once and written once, so the variants built
-// with SPZ_NT_LOAD / SPZ_NT_STORE mark them non-temporal.
+template <bool NT>
 __device__ __forceinline__ uint32_t ld_u32(const uint8_t *p) {
-#if SPZ_NT_LOAD
-  return __builtin_nontemporal_load(reinterpret_cast<const u32_a1 *>(p));
-#else
-  return *reinterpret_cast<const u32_a1 *>(p);
-#endif
+  if constexpr (NT) return __builtin_nontemporal_load(reinterpret_cast<const u32_a1 *>(p));
+  else return *reinterpret_cast<const u32_a1 *>(p);
 }
+template <bool NT>
 __device__ __forceinline__ void st_u32(uint8_t *p, uint32_t v) {
-#if SPZ_NT_STORE
-  __builtin_nontemporal_store(v, reinterpret_cast<u32_a1 *>(p));
-#else
-  *reinterpret_cast<u32_a1 *>(p) = v;
-#endif
+  if constexpr (NT) __builtin_nontemporal_store(v, reinterpret_cast<u32_a1 *>(p));
+  else *reinterpret_cast<u32_a1 *>(p) = v;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -363,17 +381,17 @@ __device__ __forceinline__ uint32_t pos_sign_bits(uint32_t flip_p, uint32_t unit
 // ------------------------------------------------------------------------------------------
 // Decode
 // ------------------------------------------------------------------------------------------
-template <int KIND>
+template <int KIND, class G>
 __device__ __forceinline__ Raw3 load_raw(const uint8_t *__restrict__ src, unsigned long long u) {
   Raw3 r = {0u, 0u, 0u};
   if constexpr (KIND == KIND_POS24) {
-#if SPZ_NT_LOAD
-    const uint8_t *q = src + u * 12ull;
-    r.a = ld_u32(q); r.b = ld_u32(q + 4); r.c = ld_u32(q + 8);
-#else
-    U32x3 t = *reinterpret_cast<const U32x3 *>(src + u * 12ull);
-    r.a = t.a; r.b = t.b; r.c = t.c;
-#endif
+    if constexpr (G::kNtLoad) {
+      const uint8_t *q = src + u * 12ull;
+      r.a = ld_u32<true>(q); r.b = ld_u32<true>(q + 4); r.c = ld_u32<true>(q + 8);
+    } else {
+      U32x3 t = *reinterpret_cast<const U32x3 *>(src + u * 12ull);
+      r.a = t.a; r.b = t.b; r.c = t.c;
+    }
   } else if constexpr (KIND == KIND_POS16) {
     U32x2 t = *reinterpret_cast<const U32x2 *>(src + u * 8ull);
     r.a = t.a; r.b = t.b;
@@ -381,7 +399,7 @@ __device__ __forceinline__ Raw3 load_raw(const uint8_t *__restrict__ src, unsign
     U8x3 t = *reinterpret_cast<const U8x3 *>(src + u * 3ull);
     r.a = (uint32_t)t.a | ((uint32_t)t.b << 8) | ((uint32_t)t.c << 16);
   } else {
-    r.a = ld_u32(src + u * 4ull);
+    r.a = ld_u32<G::kNtLoad>(src + u * 4ull);
   }
   return r;
 }
@@ -456,12 +474,12 @@ __device__ __forceinline__ F32x4 decode_unit(Raw3 raw, uint32_t phase, const Dec
 }
 
 // Phase of a unit inside its tile: positions -> unit % 3, sh -> (4 * unit) % D, else unused.
-template <int KIND, int D>
+template <int KIND, int D, class G>
 __device__ __forceinline__ uint32_t tile_phase_base(uint32_t tile_local) {
   if constexpr (KIND == KIND_POS24 || KIND == KIND_POS16 || KIND == KIND_FLIP_POS) {
-    return ((tile_local % 3u) * ((uint32_t)kTileUnits % 3u)) % 3u;
+    return ((tile_local % 3u) * ((uint32_t)G::kTileUnits % 3u)) % 3u;
   } else if constexpr ((KIND == KIND_SH || KIND == KIND_FLIP_SH) && D > 0) {
-    return ((tile_local % (uint32_t)D) * ((4u * kTileUnits) % (uint32_t)D)) % (uint32_t)D;
+    return ((tile_local % (uint32_t)D) * ((4u * (uint32_t)G::kTileUnits) % (uint32_t)D)) % (uint32_t)D;
   } else {
     return 0u;
   }
@@ -477,49 +495,51 @@ __device__ __forceinline__ uint32_t unit_phase(uint32_t base, uint32_t local) {
   }
 }
 
+template <bool NT>
 __device__ __forceinline__ void store_f4(float *__restrict__ dst, unsigned long long u, F32x4 v) {
-#if SPZ_NT_STORE
-  v4f_t t = {v.x, v.y, v.z, v.w};
-  __builtin_nontemporal_store(t, reinterpret_cast<v4f_a4 *>(dst + u * 4ull));
-#else
-  *reinterpret_cast<F32x4 *>(dst + u * 4ull) = v;
-#endif
+  if constexpr (NT) {
+    v4f_t t = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(t, reinterpret_cast<v4f_a4 *>(dst + u * 4ull));
+  } else {
+    *reinterpret_cast<F32x4 *>(dst + u * 4ull) = v;
+  }
 }
+template <bool NT>
 __device__ __forceinline__ F32x4 load_f4(const float *__restrict__ src, unsigned long long u) {
-#if SPZ_NT_LOAD
-  v4f_t t = __builtin_nontemporal_load(reinterpret_cast<const v4f_a4 *>(src + u * 4ull));
-  F32x4 v;
-  v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w;
-  return v;
-#else
-  return *reinterpret_cast<const F32x4 *>(src + u * 4ull);
-#endif
+  if constexpr (NT) {
+    v4f_t t = __builtin_nontemporal_load(reinterpret_cast<const v4f_a4 *>(src + u * 4ull));
+    F32x4 v;
+    v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w;
+    return v;
+  } else {
+    return *reinterpret_cast<const F32x4 *>(src + u * 4ull);
+  }
 }
 
-template <int KIND, int D>
+template <int KIND, int D, class G>
 __device__ __forceinline__ void decode_tile(const SecDesc &s, uint32_t tile_local, const DecodeCtx &c) {
-  const unsigned long long base = (unsigned long long)tile_local * kTileUnits;
+  const unsigned long long base = (unsigned long long)tile_local * G::kTileUnits;
   const uint32_t tid = threadIdx.x;
   const uint8_t *__restrict__ src = s.bytes;
   float *__restrict__ dst = s.floats;
   const unsigned long long full_units = s.n_elems >> 2;
-  const uint32_t pb = tile_phase_base<KIND, D>(tile_local);
-  if (base + kTileUnits <= full_units) {
-    Raw3 raw[kUnroll];
+  const uint32_t pb = tile_phase_base<KIND, D, G>(tile_local);
+  if (base + G::kTileUnits <= full_units) {
+    Raw3 raw[G::kUnroll];
 #pragma unroll
-    for (int r = 0; r < kUnroll; ++r) raw[r] = load_raw<KIND>(src, base + local_unit(r, tid));
+    for (int r = 0; r < G::kUnroll; ++r) raw[r] = load_raw<KIND, G>(src, base + G::local_unit(r, tid));
 #pragma unroll
-    for (int r = 0; r < kUnroll; ++r) {
-      const uint32_t local = local_unit(r, tid);
-      store_f4(dst, base + local, decode_unit<KIND, D>(raw[r], unit_phase<KIND, D>(pb, local), c));
+    for (int r = 0; r < G::kUnroll; ++r) {
+      const uint32_t local = G::local_unit(r, tid);
+      store_f4<G::kNtStore>(dst, base + local, decode_unit<KIND, D>(raw[r], unit_phase<KIND, D>(pb, local), c));
     }
   } else {
 #pragma unroll
-    for (int r = 0; r < kUnroll; ++r) {
-      const uint32_t local = local_unit(r, tid);
+    for (int r = 0; r < G::kUnroll; ++r) {
+      const uint32_t local = G::local_unit(r, tid);
       const unsigned long long u = base + local;
       if (u < full_units) {
-        store_f4(dst, u, decode_unit<KIND, D>(load_raw<KIND>(src, u), unit_phase<KIND, D>(pb, local), c));
+        store_f4<G::kNtStore>(dst, u, decode_unit<KIND, D>(load_raw<KIND, G>(src, u), unit_phase<KIND, D>(pb, local), c));
       } else if (u < s.n_units) {
         if constexpr (KIND != KIND_ROT_S3 && KIND != KIND_ROT_F3) {
           const uint32_t m = (uint32_t)(s.n_elems - u * 4ull);  // 1..3 valid elements
@@ -537,9 +557,9 @@ __device__ __forceinline__ void decode_tile(const SecDesc &s, uint32_t tile_loca
 template <int KIND>
 __device__ __forceinline__ void decode_tile_sh_dispatch(const SecDesc &s, uint32_t tile_local, const DecodeCtx &c,
                                                         uint32_t sh_d) {
-  if (sh_d == 45u) decode_tile<KIND, 45>(s, tile_local, c);
-  else if (sh_d == 24u) decode_tile<KIND, 24>(s, tile_local, c);
-  else decode_tile<KIND, 9>(s, tile_local, c);
+  if (sh_d == 45u) decode_tile<KIND, 45, DecGeom>(s, tile_local, c);
+  else if (sh_d == 24u) decode_tile<KIND, 24, DecGeom>(s, tile_local, c);
+  else decode_tile<KIND, 9, DecGeom>(s, tile_local, c);
 }
 
 __device__ __forceinline__ uint32_t find_section(const KParams &p, uint32_t tile) {
@@ -551,12 +571,13 @@ __device__ __forceinline__ uint32_t find_section(const KParams &p, uint32_t tile
   return si;
 }
 
+template <class G>
 __device__ __forceinline__ void stage_tables(float *lut, const float *__restrict__ tables) {
-  for (uint32_t i = threadIdx.x; i < kTableFloats; i += kBlock) lut[i] = tables[i];
+  for (uint32_t i = threadIdx.x; i < kTableFloats; i += G::kBlock) lut[i] = tables[i];
   __syncthreads();
 }
 
-__global__ __launch_bounds__(kBlock) void spz_decode_kernel(const KParams p) {
+__global__ __launch_bounds__(DecGeom::kBlock) void spz_decode_kernel(const KParams p) {
   __shared__ float lut[kTableFloats];
   bool lut_ready = false;
   DecodeCtx c;
@@ -570,20 +591,20 @@ __global__ __launch_bounds__(kBlock) void spz_decode_kernel(const KParams p) {
     const SecDesc &s = p.sec[si];
     const uint32_t tl = tile - s.tile_begin;
     switch (s.kind) {
-      case KIND_POS24: decode_tile<KIND_POS24, 0>(s, tl, c); break;
-      case KIND_POS16: decode_tile<KIND_POS16, 0>(s, tl, c); break;
+      case KIND_POS24: decode_tile<KIND_POS24, 0, DecGeom>(s, tl, c); break;
+      case KIND_POS16: decode_tile<KIND_POS16, 0, DecGeom>(s, tl, c); break;
       case KIND_ALPHA:
       case KIND_COLOR:
         if (!lut_ready) {
-          stage_tables(lut, p.tables);
+          stage_tables<DecGeom>(lut, p.tables);
           lut_ready = true;
         }
-        if (s.kind == KIND_ALPHA) decode_tile<KIND_ALPHA, 0>(s, tl, c);
-        else decode_tile<KIND_COLOR, 0>(s, tl, c);
+        if (s.kind == KIND_ALPHA) decode_tile<KIND_ALPHA, 0, DecGeom>(s, tl, c);
+        else decode_tile<KIND_COLOR, 0, DecGeom>(s, tl, c);
         break;
-      case KIND_SCALE: decode_tile<KIND_SCALE, 0>(s, tl, c); break;
-      case KIND_ROT_S3: decode_tile<KIND_ROT_S3, 0>(s, tl, c); break;
-      case KIND_ROT_F3: decode_tile<KIND_ROT_F3, 0>(s, tl, c); break;
+      case KIND_SCALE: decode_tile<KIND_SCALE, 0, DecGeom>(s, tl, c); break;
+      case KIND_ROT_S3: decode_tile<KIND_ROT_S3, 0, DecGeom>(s, tl, c); break;
+      case KIND_ROT_F3: decode_tile<KIND_ROT_F3, 0, DecGeom>(s, tl, c); break;
       case KIND_SH: decode_tile_sh_dispatch<KIND_SH>(s, tl, c, p.sh_d); break;
       default: break;
     }
@@ -645,50 +666,50 @@ __device__ __forceinline__ Raw3 encode_unit(F32x4 v, uint32_t phase, const Encod
   return o;
 }
 
-template <int KIND>
+template <int KIND, class G>
 __device__ __forceinline__ void store_raw(uint8_t *__restrict__ dst, unsigned long long u, Raw3 r) {
   if constexpr (KIND == KIND_POS24) {
-#if SPZ_NT_STORE
-    uint8_t *q = dst + u * 12ull;
-    st_u32(q, r.a); st_u32(q + 4, r.b); st_u32(q + 8, r.c);
-#else
-    U32x3 t;
-    t.a = r.a; t.b = r.b; t.c = r.c;
-    *reinterpret_cast<U32x3 *>(dst + u * 12ull) = t;
-#endif
+    if constexpr (G::kNtStore) {
+      uint8_t *q = dst + u * 12ull;
+      st_u32<true>(q, r.a); st_u32<true>(q + 4, r.b); st_u32<true>(q + 8, r.c);
+    } else {
+      U32x3 t;
+      t.a = r.a; t.b = r.b; t.c = r.c;
+      *reinterpret_cast<U32x3 *>(dst + u * 12ull) = t;
+    }
   } else if constexpr (KIND == KIND_ROT_F3) {
     U8x3 t;
     t.a = (uint8_t)r.a; t.b = (uint8_t)(r.a >> 8); t.c = (uint8_t)(r.a >> 16);
     *reinterpret_cast<U8x3 *>(dst + u * 3ull) = t;
   } else {
-    st_u32(dst + u * 4ull, r.a);
+    st_u32<G::kNtStore>(dst + u * 4ull, r.a);
   }
 }
 
-template <int KIND, int D>
+template <int KIND, int D, class G>
 __device__ __forceinline__ void encode_tile(const SecDesc &s, uint32_t tile_local, const EncodeCtx &c) {
-  const unsigned long long base = (unsigned long long)tile_local * kTileUnits;
+  const unsigned long long base = (unsigned long long)tile_local * G::kTileUnits;
   const uint32_t tid = threadIdx.x;
   const float *__restrict__ src = s.floats;
   uint8_t *__restrict__ dst = s.bytes;
   const unsigned long long full_units = s.n_elems >> 2;
-  const uint32_t pb = tile_phase_base<KIND, D>(tile_local);
-  if (base + kTileUnits <= full_units) {
-    F32x4 v[kUnroll];
+  const uint32_t pb = tile_phase_base<KIND, D, G>(tile_local);
+  if (base + G::kTileUnits <= full_units) {
+    F32x4 v[G::kUnroll];
 #pragma unroll
-    for (int r = 0; r < kUnroll; ++r) v[r] = load_f4(src, base + local_unit(r, tid));
+    for (int r = 0; r < G::kUnroll; ++r) v[r] = load_f4<G::kNtLoad>(src, base + G::local_unit(r, tid));
 #pragma unroll
-    for (int r = 0; r < kUnroll; ++r) {
-      const uint32_t local = local_unit(r, tid);
-      store_raw<KIND>(dst, base + local, encode_unit<KIND, D>(v[r], unit_phase<KIND, D>(pb, local), c));
+    for (int r = 0; r < G::kUnroll; ++r) {
+      const uint32_t local = G::local_unit(r, tid);
+      store_raw<KIND, G>(dst, base + local, encode_unit<KIND, D>(v[r], unit_phase<KIND, D>(pb, local), c));
     }
   } else {
 #pragma unroll
-    for (int r = 0; r < kUnroll; ++r) {
-      const uint32_t local = local_unit(r, tid);
+    for (int r = 0; r < G::kUnroll; ++r) {
+      const uint32_t local = G::local_unit(r, tid);
       const unsigned long long u = base + local;
       if (u < full_units) {
-        store_raw<KIND>(dst, u, encode_unit<KIND, D>(load_f4(src, u), unit_phase<KIND, D>(pb, local), c));
+        store_raw<KIND, G>(dst, u, encode_unit<KIND, D>(load_f4<G::kNtLoad>(src, u), unit_phase<KIND, D>(pb, local), c));
       } else if (u < s.n_units) {
         if constexpr (KIND != KIND_ROT_S3 && KIND != KIND_ROT_F3) {
           const uint32_t m = (uint32_t)(s.n_elems - u * 4ull);  // 1..3 valid elements
@@ -712,12 +733,12 @@ __device__ __forceinline__ void encode_tile(const SecDesc &s, uint32_t tile_loca
 template <int KIND>
 __device__ __forceinline__ void encode_tile_sh_dispatch(const SecDesc &s, uint32_t tile_local, const EncodeCtx &c,
                                                         uint32_t sh_d) {
-  if (sh_d == 45u) encode_tile<KIND, 45>(s, tile_local, c);
-  else if (sh_d == 24u) encode_tile<KIND, 24>(s, tile_local, c);
-  else encode_tile<KIND, 9>(s, tile_local, c);
+  if (sh_d == 45u) encode_tile<KIND, 45, EncGeom>(s, tile_local, c);
+  else if (sh_d == 24u) encode_tile<KIND, 24, EncGeom>(s, tile_local, c);
+  else encode_tile<KIND, 9, EncGeom>(s, tile_local, c);
 }
 
-__global__ __launch_bounds__(kBlock) void spz_encode_kernel(const KParams p) {
+__global__ __launch_bounds__(EncGeom::kBlock) void spz_encode_kernel(const KParams p) {
   __shared__ float lut[kTableFloats];
   bool lut_ready = false;
   EncodeCtx c;
@@ -734,18 +755,18 @@ __global__ __launch_bounds__(kBlock) void spz_encode_kernel(const KParams p) {
     const SecDesc &s = p.sec[si];
     const uint32_t tl = tile - s.tile_begin;
     switch (s.kind) {
-      case KIND_POS24: encode_tile<KIND_POS24, 0>(s, tl, c); break;
+      case KIND_POS24: encode_tile<KIND_POS24, 0, EncGeom>(s, tl, c); break;
       case KIND_ALPHA:
         if (!lut_ready) {
-          stage_tables(lut, p.tables);
+          stage_tables<EncGeom>(lut, p.tables);
           lut_ready = true;
         }
-        encode_tile<KIND_ALPHA, 0>(s, tl, c);
+        encode_tile<KIND_ALPHA, 0, EncGeom>(s, tl, c);
         break;
-      case KIND_COLOR: encode_tile<KIND_COLOR, 0>(s, tl, c); break;
-      case KIND_SCALE: encode_tile<KIND_SCALE, 0>(s, tl, c); break;
-      case KIND_ROT_S3: encode_tile<KIND_ROT_S3, 0>(s, tl, c); break;
-      case KIND_ROT_F3: encode_tile<KIND_ROT_F3, 0>(s, tl, c); break;
+      case KIND_COLOR: encode_tile<KIND_COLOR, 0, EncGeom>(s, tl, c); break;
+      case KIND_SCALE: encode_tile<KIND_SCALE, 0, EncGeom>(s, tl, c); break;
+      case KIND_ROT_S3: encode_tile<KIND_ROT_S3, 0, EncGeom>(s, tl, c); break;
+      case KIND_ROT_F3: encode_tile<KIND_ROT_F3, 0, EncGeom>(s, tl, c); break;
       case KIND_SH: encode_tile_sh_dispatch<KIND_SH>(s, tl, c, p.sh_d); break;
       default: break;
     }
@@ -771,18 +792,18 @@ __device__ __forceinline__ F32x4 flip_unit(F32x4 v, uint32_t phase, const KParam
 
 template <int KIND, int D>
 __device__ __forceinline__ void flip_tile(const SecDesc &s, uint32_t tile_local, const KParams &p) {
-  const unsigned long long base = (unsigned long long)tile_local * kTileUnits;
+  const unsigned long long base = (unsigned long long)tile_local * FlipGeom::kTileUnits;
   const uint32_t tid = threadIdx.x;
   float *buf = s.floats;
   const unsigned long long full_units = s.n_elems >> 2;
-  const uint32_t pb = tile_phase_base<KIND, D>(tile_local);
+  const uint32_t pb = tile_phase_base<KIND, D, FlipGeom>(tile_local);
 #pragma unroll
-  for (int r = 0; r < kUnroll; ++r) {
-    const uint32_t local = local_unit(r, tid);
+  for (int r = 0; r < FlipGeom::kUnroll; ++r) {
+    const uint32_t local = FlipGeom::local_unit(r, tid);
     const unsigned long long u = base + local;
     const uint32_t ph = unit_phase<KIND, D>(pb, local);
     if (u < full_units) {
-      store_f4(buf, u, flip_unit<KIND, D>(load_f4(buf, u), ph, p));
+      store_f4<false>(buf, u, flip_unit<KIND, D>(load_f4<false>(buf, u), ph, p));
     } else if (u < s.n_units) {
       const uint32_t m = (uint32_t)(s.n_elems - u * 4ull);
       float *q = buf + u * 4ull;
@@ -799,7 +820,7 @@ __device__ __forceinline__ void flip_tile(const SecDesc &s, uint32_t tile_local,
   }
 }
 
-__global__ __launch_bounds__(kBlock) void spz_flip_kernel(const KParams p) {
+__global__ __launch_bounds__(FlipGeom::kBlock) void spz_flip_kernel(const KParams p) {
   for (uint32_t tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
     const uint32_t si = find_section(p, tile);
     const SecDesc &s = p.sec[si];
@@ -970,24 +991,24 @@ int current_device(int *device) {
 }
 
 int grid_for(int device, uint32_t total_tiles, uint32_t *grid) {
-  static int cus[kMaxDevices] = {0};
-  if (cus[device] == 0) {
-    int n = 0;
-    SPZ_HIP_TRY(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device));
-    cus[device] = (n > 0) ? n : 256;
+  uint32_t cap = 0x7fffffffu;  // hipGridDim.x limit; the kernels grid-stride beyond it
+  if (kMaxBlocksPerCU > 0) {
+    static int cus[kMaxDevices] = {0};
+    if (cus[device] == 0) {
+      int n = 0;
+      SPZ_HIP_TRY(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, device));
+      cus[device] = (n > 0) ? n : 256;
+    }
+    cap = (uint32_t)cus[device] * (uint32_t)kMaxBlocksPerCU;
   }
-  uint32_t cap = (uint32_t)cus[device] * kMaxBlocksPerCU;
   uint32_t g = total_tiles < cap ? total_tiles : cap;
   *grid = g > 0 ? g : 1;
   return SPZ_AMD_OK;
 }
 
-uint32_t tiles_for_units(unsigned long long units) {
-  return (uint32_t)((units + kTileUnits - 1) / kTileUnits);
-}
-
 // Appends a section to the fused grid (skips empty ones).
-void add_section(KParams *p, uint32_t kind, uint8_t *bytes, float *floats, unsigned long long n_elems) {
+void add_section(KParams *p, uint32_t tile_units, uint32_t kind, uint8_t *bytes, float *floats,
+                 unsigned long long n_elems) {
   if (n_elems == 0) return;
   SecDesc &s = p->sec[p->n_sec++];
   s.bytes = bytes;
@@ -996,7 +1017,7 @@ void add_section(KParams *p, uint32_t kind, uint8_t *bytes, float *floats, unsig
   s.n_units = (n_elems + 3) / 4;
   s.tile_begin = p->total_tiles;
   s.kind = kind;
-  p->total_tiles += tiles_for_units(s.n_units);
+  p->total_tiles += (uint32_t)((s.n_units + tile_units - 1) / tile_units);
 }
 
 bool valid_coord(int c) { return c >= 0 && c <= 8; }
@@ -1048,13 +1069,13 @@ int encode_impl(const spz_amd_cloud_in *cl, uint64_t first, uint64_t count, uint
   auto frag = [&](int s) { return d_stream + lay.offset[s] + first * lay.bytes_per_point[s]; };
   auto fl = [](const float *q) { return const_cast<float *>(q); };
   // Largest sections first so the tail of the grid is made of the small ones.
-  add_section(&p, KIND_SH, frag(SPZ_AMD_SEC_SH), fl(cl->sh), count * (uint64_t)sd * 3u);
-  add_section(&p, KIND_POS24, frag(SPZ_AMD_SEC_POSITIONS), fl(cl->positions), count * 3u);
-  add_section(&p, version >= 3 ? KIND_ROT_S3 : KIND_ROT_F3, frag(SPZ_AMD_SEC_ROTATIONS), fl(cl->rotations),
+  add_section(&p, EncGeom::kTileUnits, KIND_SH, frag(SPZ_AMD_SEC_SH), fl(cl->sh), count * (uint64_t)sd * 3u);
+  add_section(&p, EncGeom::kTileUnits, KIND_POS24, frag(SPZ_AMD_SEC_POSITIONS), fl(cl->positions), count * 3u);
+  add_section(&p, EncGeom::kTileUnits, version >= 3 ? KIND_ROT_S3 : KIND_ROT_F3, frag(SPZ_AMD_SEC_ROTATIONS), fl(cl->rotations),
               count * 4u);
-  add_section(&p, KIND_SCALE, frag(SPZ_AMD_SEC_SCALES), fl(cl->scales), count * 3u);
-  add_section(&p, KIND_COLOR, frag(SPZ_AMD_SEC_COLORS), fl(cl->colors), count * 3u);
-  add_section(&p, KIND_ALPHA, frag(SPZ_AMD_SEC_ALPHAS), fl(cl->alphas), count);
+  add_section(&p, EncGeom::kTileUnits, KIND_SCALE, frag(SPZ_AMD_SEC_SCALES), fl(cl->scales), count * 3u);
+  add_section(&p, EncGeom::kTileUnits, KIND_COLOR, frag(SPZ_AMD_SEC_COLORS), fl(cl->colors), count * 3u);
+  add_section(&p, EncGeom::kTileUnits, KIND_ALPHA, frag(SPZ_AMD_SEC_ALPHAS), fl(cl->alphas), count);
   if (write_header) {
     p.header_dst = d_stream;
     p.header_words[0] = kMagic;
@@ -1066,7 +1087,7 @@ int encode_impl(const spz_amd_cloud_in *cl, uint64_t first, uint64_t count, uint
   uint32_t grid = 1;
   rc = grid_for(device, p.total_tiles, &grid);
   if (rc != SPZ_AMD_OK) return rc;
-  hipLaunchKernelGGL(spz_encode_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(hip_stream), p);
+  hipLaunchKernelGGL(spz_encode_kernel, dim3(grid), dim3(EncGeom::kBlock), 0, static_cast<hipStream_t>(hip_stream), p);
   SPZ_HIP_TRY(hipGetLastError());
   return SPZ_AMD_OK;
 }
@@ -1110,18 +1131,18 @@ int decode_impl(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr,
   // float scale = 1.0 / (1 << fractionalBits) (load-spz.cc:495); x86 masks the shift count to 5 bits
   p.pos_scale = (float)(1.0 / (double)(int32_t)(1u << (hdr->fractional_bits & 31)));
   auto frag = [&](int s) { return const_cast<uint8_t *>(d_stream) + lay.offset[s] + first * lay.bytes_per_point[s]; };
-  add_section(&p, KIND_SH, frag(SPZ_AMD_SEC_SH), cl->sh, count * (uint64_t)sd * 3u);
-  add_section(&p, hdr->version == 1 ? KIND_POS16 : KIND_POS24, frag(SPZ_AMD_SEC_POSITIONS), cl->positions,
+  add_section(&p, DecGeom::kTileUnits, KIND_SH, frag(SPZ_AMD_SEC_SH), cl->sh, count * (uint64_t)sd * 3u);
+  add_section(&p, DecGeom::kTileUnits, hdr->version == 1 ? KIND_POS16 : KIND_POS24, frag(SPZ_AMD_SEC_POSITIONS), cl->positions,
               count * 3u);
-  add_section(&p, hdr->version >= 3 ? KIND_ROT_S3 : KIND_ROT_F3, frag(SPZ_AMD_SEC_ROTATIONS), cl->rotations,
+  add_section(&p, DecGeom::kTileUnits, hdr->version >= 3 ? KIND_ROT_S3 : KIND_ROT_F3, frag(SPZ_AMD_SEC_ROTATIONS), cl->rotations,
               count * 4u);
-  add_section(&p, KIND_SCALE, frag(SPZ_AMD_SEC_SCALES), cl->scales, count * 3u);
-  add_section(&p, KIND_COLOR, frag(SPZ_AMD_SEC_COLORS), cl->colors, count * 3u);
-  add_section(&p, KIND_ALPHA, frag(SPZ_AMD_SEC_ALPHAS), cl->alphas, count);
+  add_section(&p, DecGeom::kTileUnits, KIND_SCALE, frag(SPZ_AMD_SEC_SCALES), cl->scales, count * 3u);
+  add_section(&p, DecGeom::kTileUnits, KIND_COLOR, frag(SPZ_AMD_SEC_COLORS), cl->colors, count * 3u);
+  add_section(&p, DecGeom::kTileUnits, KIND_ALPHA, frag(SPZ_AMD_SEC_ALPHAS), cl->alphas, count);
   uint32_t grid = 1;
   rc = grid_for(device, p.total_tiles, &grid);
   if (rc != SPZ_AMD_OK) return rc;
-  hipLaunchKernelGGL(spz_decode_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(hip_stream), p);
+  hipLaunchKernelGGL(spz_decode_kernel, dim3(grid), dim3(DecGeom::kBlock), 0, static_cast<hipStream_t>(hip_stream), p);
   SPZ_HIP_TRY(hipGetLastError());
   return SPZ_AMD_OK;
 }
@@ -1283,14 +1304,14 @@ int spz_amd_convert_coordinates_device(float *d_positions, float *d_rotations, f
   p.flip_q = fm.q;
   p.sh_mask_ext = sh_elem_mask_ext(fm.sh15, sd);
   p.sh_d = (uint32_t)sd * 3u;
-  if (d_sh) add_section(&p, KIND_FLIP_SH, nullptr, d_sh, num_points * (uint64_t)sd * 3u);
-  if (d_positions) add_section(&p, KIND_FLIP_POS, nullptr, d_positions, num_points * 3u);
-  if (d_rotations) add_section(&p, KIND_FLIP_ROT, nullptr, d_rotations, num_points * 4u);
+  if (d_sh) add_section(&p, FlipGeom::kTileUnits, KIND_FLIP_SH, nullptr, d_sh, num_points * (uint64_t)sd * 3u);
+  if (d_positions) add_section(&p, FlipGeom::kTileUnits, KIND_FLIP_POS, nullptr, d_positions, num_points * 3u);
+  if (d_rotations) add_section(&p, FlipGeom::kTileUnits, KIND_FLIP_ROT, nullptr, d_rotations, num_points * 4u);
   if (p.total_tiles == 0) return SPZ_AMD_OK;
   uint32_t grid = 1;
   rc = grid_for(device, p.total_tiles, &grid);
   if (rc != SPZ_AMD_OK) return rc;
-  hipLaunchKernelGGL(spz_flip_kernel, dim3(grid), dim3(kBlock), 0, static_cast<hipStream_t>(hip_stream), p);
+  hipLaunchKernelGGL(spz_flip_kernel, dim3(grid), dim3(FlipGeom::kBlock), 0, static_cast<hipStream_t>(hip_stream), p);
   SPZ_HIP_TRY(hipGetLastError());
   return SPZ_AMD_OK;
 }

@@ -16,36 +16,57 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 VDIR = os.path.join(ROOT, "build", "variants")
 
-F = {"SPZ_BLOCKS_PER_CU": 100000}   # "flat": one tile per block
+def E(block=256, unroll=4, wc=0, ntl=0, nts=0):
+    return {"SPZ_ENC_BLOCK": block, "SPZ_ENC_UNROLL": unroll, "SPZ_ENC_WC": wc, "SPZ_ENC_NTL": ntl, "SPZ_ENC_NTS": nts}
 
-VARIANTS = {
-    "base":       {},
-    "flat":       dict(F),
-    "flat_u1":    dict(F, SPZ_UNROLL=1),
-    "flat_u2":    dict(F, SPZ_UNROLL=2),
-    "flat_u8":    dict(F, SPZ_UNROLL=8),
-    "flat_u16":   dict(F, SPZ_UNROLL=16),
-    "flat_b64":   dict(F, SPZ_BLOCK=64),
-    "flat_b64u8": dict(F, SPZ_BLOCK=64, SPZ_UNROLL=8),
-    "flat_b128":  dict(F, SPZ_BLOCK=128),
-    "flat_b128u8": dict(F, SPZ_BLOCK=128, SPZ_UNROLL=8),
-    "flat_b512":  dict(F, SPZ_BLOCK=512),
-    "flat_b512u2": dict(F, SPZ_BLOCK=512, SPZ_UNROLL=2),
-    "flat_b1024u1": dict(F, SPZ_BLOCK=1024, SPZ_UNROLL=1),
-    "flat_ntl":   dict(F, SPZ_NT_LOAD=1),
-    "flat_nts":   dict(F, SPZ_NT_STORE=1),
-    "flat_nt":    dict(F, SPZ_NT_LOAD=1, SPZ_NT_STORE=1),
-    "flat_wc":    dict(F, SPZ_WAVE_CONTIG=1),
-    "flat_u8wc":  dict(F, SPZ_UNROLL=8, SPZ_WAVE_CONTIG=1),
-    "bpc64":      {"SPZ_BLOCKS_PER_CU": 64},
-    "bpc32u8":    {"SPZ_BLOCKS_PER_CU": 32, "SPZ_UNROLL": 8},
+
+def D(block=256, unroll=4, wc=0, ntl=0, nts=0):
+    return {"SPZ_DEC_BLOCK": block, "SPZ_DEC_UNROLL": unroll, "SPZ_DEC_WC": wc, "SPZ_DEC_NTL": ntl, "SPZ_DEC_NTS": nts}
+
+
+# Encode and decode geometries are independent; library i carries encode config i and decode config i
+# (the two columns of a row are unrelated experiments).  All are "flat" (one tile per block).
+ENC = {
+    "b256u4":          E(),
+    "b256u4_wc":       E(wc=1),
+    "b256u4_nt":       E(ntl=1, nts=1),
+    "b256u4_wc_nt":    E(wc=1, ntl=1, nts=1),
+    "b256u4_wc_ntl":   E(wc=1, ntl=1),
+    "b256u8_wc_nt":    E(unroll=8, wc=1, ntl=1, nts=1),
+    "b256u2_wc_nt":    E(unroll=2, wc=1, ntl=1, nts=1),
+    "b128u4_wc_nt":    E(block=128, wc=1, ntl=1, nts=1),
+    "b128u8_wc_nt":    E(block=128, unroll=8, wc=1, ntl=1, nts=1),
+    "b64u4_nt":        E(block=64, ntl=1, nts=1),
+    "b64u8_nt":        E(block=64, unroll=8, ntl=1, nts=1),
+    "b512u4_wc_nt":    E(block=512, wc=1, ntl=1, nts=1),
+    "b512u2_wc_nt":    E(block=512, unroll=2, wc=1, ntl=1, nts=1),
+    "b256u4_wc_nts":   E(wc=1, nts=1),
 }
+DEC = {
+    "b256u4":          D(),
+    "b256u8":          D(unroll=8),
+    "b64u8":           D(block=64, unroll=8),
+    "b64u8_nts":       D(block=64, unroll=8, nts=1),
+    "b64u8_ntl":       D(block=64, unroll=8, ntl=1),
+    "b64u4":           D(block=64),
+    "b64u16":          D(block=64, unroll=16),
+    "b128u8_wc":       D(block=128, unroll=8, wc=1),
+    "b128u8_wc_nts":   D(block=128, unroll=8, wc=1, nts=1),
+    "b256u8_wc":       D(unroll=8, wc=1),
+    "b256u8_wc_nts":   D(unroll=8, wc=1, nts=1),
+    "b256u8_nts":      D(unroll=8, nts=1),
+    "b128u4_wc":       D(block=128, wc=1),
+    "b64u6":           D(block=64, unroll=6),
+}
+VARIANTS = {}
+for _i, (_e, _d) in enumerate(zip(ENC.items(), DEC.items())):
+    VARIANTS[f"v{_i:02d}"] = {"enc": _e[0], "dec": _d[0], "defs": {**_e[1], **_d[1]}}
 
 
 def build(names):
     os.makedirs(VDIR, exist_ok=True)
     for name in names:
-        defs = [f"-D{k}={v}" for k, v in VARIANTS[name].items()]
+        defs = [f"-D{k}={v}" for k, v in VARIANTS[name]["defs"].items()]
         out = os.path.join(VDIR, f"libspz_amd_{name}.so")
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", f"-I{ROOT}/include", "-shared",
@@ -111,7 +132,7 @@ def run(points, rounds, names, deg=3):
     gb = points * bpp / 1e9
     rows = []
     for name in libs:
-        r = {"variant": name}
+        r = {"variant": name, "enc_cfg": VARIANTS[name]["enc"], "dec_cfg": VARIANTS[name]["dec"]}
         for k in ("enc", "dec"):
             med, mn = statistics.median(times[name][k]), min(times[name][k])
             r[f"{k}_ms_med"] = round(med, 4)
