@@ -58,7 +58,7 @@ namespace {
 #define SPZ_DEC_BLOCK 256
 #endif
 #ifndef SPZ_DEC_UNROLL
-#define SPZ_DEC_UNROLL 8
+#define SPZ_DEC_UNROLL 4
 #endif
 #ifndef SPZ_DEC_WC
 #define SPZ_DEC_WC 0
@@ -86,6 +86,10 @@ namespace {
 #endif
 // 0: one tile per block ("flat" grid, measured faster than a persistent grid-stride loop: a wave's
 // next loads would queue behind its own stores in the in-order vmcnt).  k > 0: at most k blocks per CU.
+// Optional second __launch_bounds__ argument (minimum waves per SIMD) for the encode kernel.
+#ifndef SPZ_ENC_MIN_WAVES
+#define SPZ_ENC_MIN_WAVES 1
+#endif
 #ifndef SPZ_BLOCKS_PER_CU
 #define SPZ_BLOCKS_PER_CU 0
 #endif
@@ -231,23 +235,39 @@ __device__ __forceinline__ uint32_t cvt_u32_x86(float r) {
   return 0u;
 }
 
-// toUint8 (load-spz.cc:74): static_cast<uint8_t>(clamp(round(x), 0, 255)).
-__device__ __forceinline__ uint32_t to_uint8(float x) {
+// toUint8 (load-spz.cc:74): static_cast<uint8_t>(clamp(round(x), 0, 255)), as a float in
+// [0, 255].  std::clamp lets a NaN through and the x86 cast turns it into 0; fmaxf(NaN, 0) = 0
+// gives the same.
+__device__ __forceinline__ float to_uint8_f(float x) {
   float r = round_half_away(x);
-  r = (r < 0.0f) ? 0.0f : ((255.0f < r) ? 255.0f : r);  // std::clamp; NaN falls through
-  return (uint32_t)cvt_i32_x86(r) & 0xffu;
+  return __builtin_fminf(__builtin_fmaxf(r, 0.0f), 255.0f);
+}
+__device__ __forceinline__ uint32_t to_uint8(float x) { return (uint32_t)to_uint8_f(x); }
+
+// quantizeSH (load-spz.cc:77-81) for bucket b in {8, 16}, as a float in [0, 255]:
+//   q = (int)(round(128 x) + 128);  q = (q + b/2) / b * b;  clamp(q, 0, 255).
+// With r = round(128 x) (an integer-valued float) and 128 a multiple of b,
+//   (q + b/2) / b * b  ==  b * floor((r + b/2) / b) + 128   wherever q + b/2 >= 0,
+// and every negative q + b/2 (C division truncates toward zero) ends <= 0 and clamps to 0, as
+// does the floor form.  All products are by powers of two; the sums are exact below 2^24 and
+// far outside the clamp range above it.  The reference's (int) cast is "integer indefinite"
+// (INT_MIN -> clamps to 0) for NaN and once r + 128.0f reaches 2^31, i.e. from r = 2^31 - 128 up.
+__device__ __forceinline__ float quantize_sh_f(float x, bool degree1) {
+  const float inv_b = degree1 ? 0.125f : 0.0625f;
+  const float b = degree1 ? 8.0f : 16.0f;
+  float r = round_half_away(x * 128.0f);
+  // exact products: a fused multiply-add rounds exactly like the separate operations here
+  float k = __builtin_floorf(__builtin_fmaf(r, inv_b, 0.5f));
+  float v = __builtin_fminf(__builtin_fmaxf(__builtin_fmaf(k, b, 128.0f), 0.0f), 255.0f);
+  return (r < 2147483520.0f) ? v : 0.0f;
 }
 
-// quantizeSH (load-spz.cc:77-81) for bucket = 1 << shift.
-__device__ __forceinline__ uint32_t quantize_sh(float x, uint32_t shift) {
-  float t = round_half_away(x * 128.0f) + 128.0f;
-  int32_t q = cvt_i32_x86(t);
-  int32_t bucket = 1 << shift;
-  int32_t s = q + (bucket >> 1);
-  // (s / bucket * bucket) truncates toward zero: every negative s ends <= 0 and clamps to 0.
-  int32_t v = s & ~(bucket - 1);
-  v = (s < 0) ? 0 : ((v > 255) ? 255 : v);
-  return (uint32_t)v;
+// Four values already in [0, 255] and integral -> one little-endian dword.
+__device__ __forceinline__ uint32_t pack_u8x4(float a, float b, float c, float d) {
+  uint32_t w = __builtin_amdgcn_cvt_pk_u8_f32(a, 0u, 0u);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(b, 1u, w);
+  w = __builtin_amdgcn_cvt_pk_u8_f32(c, 2u, w);
+  return __builtin_amdgcn_cvt_pk_u8_f32(d, 3u, w);
 }
 
 constexpr float kSqrt1_2 = (float)0.707106781186547524401;  // load-spz.cc:46
@@ -642,12 +662,12 @@ __device__ __forceinline__ Raw3 encode_unit(F32x4 v, uint32_t phase, const Encod
     // toUint8(c * (0.15f * 255.0f) + (0.5f * 255.0f)), load-spz.cc:306: mul and add round separately
     constexpr float k = 0.15f * 255.0f;
     constexpr float h = 0.5f * 255.0f;
-    o.a = to_uint8(fmul_sep(v.x, k) + h) | (to_uint8(fmul_sep(v.y, k) + h) << 8) |
-          (to_uint8(fmul_sep(v.z, k) + h) << 16) | (to_uint8(fmul_sep(v.w, k) + h) << 24);
+    o.a = pack_u8x4(to_uint8_f(fmul_sep(v.x, k) + h), to_uint8_f(fmul_sep(v.y, k) + h),
+                    to_uint8_f(fmul_sep(v.z, k) + h), to_uint8_f(fmul_sep(v.w, k) + h));
   } else if constexpr (KIND == KIND_SCALE) {
     // toUint8((s + 10.0f) * 16.0f), load-spz.cc:291
-    o.a = to_uint8(fadd_sep(v.x, 10.0f) * 16.0f) | (to_uint8(fadd_sep(v.y, 10.0f) * 16.0f) << 8) |
-          (to_uint8(fadd_sep(v.z, 10.0f) * 16.0f) << 16) | (to_uint8(fadd_sep(v.w, 10.0f) * 16.0f) << 24);
+    o.a = pack_u8x4(to_uint8_f(fadd_sep(v.x, 10.0f) * 16.0f), to_uint8_f(fadd_sep(v.y, 10.0f) * 16.0f),
+                    to_uint8_f(fadd_sep(v.z, 10.0f) * 16.0f), to_uint8_f(fadd_sep(v.w, 10.0f) * 16.0f));
   } else if constexpr (KIND == KIND_ROT_S3) {
     o.a = pack_quat_smallest_three(v, c.flip_q);
   } else if constexpr (KIND == KIND_ROT_F3) {
@@ -658,10 +678,8 @@ __device__ __forceinline__ Raw3 encode_unit(F32x4 v, uint32_t phase, const Encod
     j1 -= (j1 >= (uint32_t)D) ? (uint32_t)D : 0u;
     j2 -= (j2 >= (uint32_t)D) ? (uint32_t)D : 0u;
     j3 -= (j3 >= (uint32_t)D) ? (uint32_t)D : 0u;
-    o.a = quantize_sh(xor_sign(v.x, sb & 1u), (j0 < 9u) ? 3u : 4u) |
-          (quantize_sh(xor_sign(v.y, (sb >> 1) & 1u), (j1 < 9u) ? 3u : 4u) << 8) |
-          (quantize_sh(xor_sign(v.z, (sb >> 2) & 1u), (j2 < 9u) ? 3u : 4u) << 16) |
-          (quantize_sh(xor_sign(v.w, (sb >> 3) & 1u), (j3 < 9u) ? 3u : 4u) << 24);
+    o.a = pack_u8x4(quantize_sh_f(xor_sign(v.x, sb & 1u), j0 < 9u), quantize_sh_f(xor_sign(v.y, (sb >> 1) & 1u), j1 < 9u),
+                    quantize_sh_f(xor_sign(v.z, (sb >> 2) & 1u), j2 < 9u), quantize_sh_f(xor_sign(v.w, (sb >> 3) & 1u), j3 < 9u));
   }
   return o;
 }
@@ -738,7 +756,7 @@ __device__ __forceinline__ void encode_tile_sh_dispatch(const SecDesc &s, uint32
   else encode_tile<KIND, 9, EncGeom>(s, tile_local, c);
 }
 
-__global__ __launch_bounds__(EncGeom::kBlock) void spz_encode_kernel(const KParams p) {
+__global__ __launch_bounds__(EncGeom::kBlock, SPZ_ENC_MIN_WAVES) void spz_encode_kernel(const KParams p) {
   __shared__ float lut[kTableFloats];
   bool lut_ready = false;
   EncodeCtx c;

@@ -27,36 +27,28 @@ def D(block=256, unroll=4, wc=0, ntl=0, nts=0):
 # Encode and decode geometries are independent; library i carries encode config i and decode config i
 # (the two columns of a row are unrelated experiments).  All are "flat" (one tile per block).
 ENC = {
-    "b256u4":          E(),
-    "b256u4_wc":       E(wc=1),
-    "b256u4_nt":       E(ntl=1, nts=1),
-    "b256u4_wc_nt":    E(wc=1, ntl=1, nts=1),
-    "b256u4_wc_ntl":   E(wc=1, ntl=1),
-    "b256u8_wc_nt":    E(unroll=8, wc=1, ntl=1, nts=1),
-    "b256u2_wc_nt":    E(unroll=2, wc=1, ntl=1, nts=1),
-    "b128u4_wc_nt":    E(block=128, wc=1, ntl=1, nts=1),
-    "b128u8_wc_nt":    E(block=128, unroll=8, wc=1, ntl=1, nts=1),
-    "b64u4_nt":        E(block=64, ntl=1, nts=1),
-    "b64u8_nt":        E(block=64, unroll=8, ntl=1, nts=1),
-    "b512u4_wc_nt":    E(block=512, wc=1, ntl=1, nts=1),
-    "b512u2_wc_nt":    E(block=512, unroll=2, wc=1, ntl=1, nts=1),
-    "b256u4_wc_nts":   E(wc=1, nts=1),
+    "b256u4_wc_ntl":        E(wc=1, ntl=1),
+    "b256u4_wc_ntl_w6":     dict(E(wc=1, ntl=1), SPZ_ENC_MIN_WAVES=6),
+    "b256u4_wc_ntl_w8":     dict(E(wc=1, ntl=1), SPZ_ENC_MIN_WAVES=8),
+    "b256u2_wc_ntl":        E(unroll=2, wc=1, ntl=1),
+    "b256u2_wc_ntl_w8":     dict(E(unroll=2, wc=1, ntl=1), SPZ_ENC_MIN_WAVES=8),
+    "b256u4_ntl":           E(ntl=1),
+    "b256u8_wc_ntl":        E(unroll=8, wc=1, ntl=1),
+    "b128u4_wc_ntl":        E(block=128, wc=1, ntl=1),
+    "b512u4_wc_ntl":        E(block=512, wc=1, ntl=1),
+    "b256u3_wc_ntl":        E(unroll=3, wc=1, ntl=1),
 }
 DEC = {
     "b256u4":          D(),
+    "b256u4_wc":       D(wc=1),
+    "b256u2":          D(unroll=2),
+    "b256u3":          D(unroll=3),
+    "b256u6":          D(unroll=6),
     "b256u8":          D(unroll=8),
-    "b64u8":           D(block=64, unroll=8),
-    "b64u8_nts":       D(block=64, unroll=8, nts=1),
-    "b64u8_ntl":       D(block=64, unroll=8, ntl=1),
-    "b64u4":           D(block=64),
-    "b64u16":          D(block=64, unroll=16),
-    "b128u8_wc":       D(block=128, unroll=8, wc=1),
-    "b128u8_wc_nts":   D(block=128, unroll=8, wc=1, nts=1),
-    "b256u8_wc":       D(unroll=8, wc=1),
-    "b256u8_wc_nts":   D(unroll=8, wc=1, nts=1),
-    "b256u8_nts":      D(unroll=8, nts=1),
-    "b128u4_wc":       D(block=128, wc=1),
-    "b64u6":           D(block=64, unroll=6),
+    "b128u4":          D(block=128),
+    "b512u4":          D(block=512),
+    "b256u4_nts":      D(nts=1),
+    "b256u4_ntl":      D(ntl=1),
 }
 VARIANTS = {}
 for _i, (_e, _d) in enumerate(zip(ENC.items(), DEC.items())):
@@ -92,8 +84,9 @@ def run(points, rounds, names, deg=3):
     pout = abi.CloudPtrs(*[out[k].data_ptr() for k in FIELDS])
     hdr = abi.Header(3, points, deg, 12, 0, 0)
     libs = {}
+    VARIANTS["prod"] = {"enc": "shipped defaults", "dec": "shipped defaults", "defs": {}}
     for name in names:
-        path = os.path.join(VDIR, f"libspz_amd_{name}.so")
+        path = abi.LIB_PATH if name == "prod" else os.path.join(VDIR, f"libspz_amd_{name}.so")
         if not os.path.exists(path):
             print(f"skip {name}: {path} missing")
             continue
