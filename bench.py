@@ -118,7 +118,8 @@ def main():
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        from datetime import timedelta
+        dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=300))
 
     n, deg, ver = args.points, args.sh_degree, args.version
     frm, to = COORD[args.from_coord], COORD[args.to_coord]
@@ -170,6 +171,24 @@ def main():
     for k in range(W):
         step(k, False)
     fence()
+
+    # N>1 parity gate: every fragment that landed in the root's global stream must be the bytes its
+    # rank encoded (per-section byte sums, exchanged with one small all_gather outside the timed region).
+    gather_verified = None
+    if use_coll:
+        if W == 0:
+            step(0, False)
+            fence()
+        src_buf = global_stream if rank == 0 else stream
+        mine = torch.stack([src_buf[(g if rank == 0 else l):(g if rank == 0 else l) + nb].sum(dtype=torch.int64)
+                            for g, l, nb in plan.fragments(rank)])
+        sums = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(sums, mine)
+        if rank == 0:
+            gather_verified = True
+            for r in range(world):
+                got = torch.stack([global_stream[g:g + nb].sum(dtype=torch.int64) for g, _, nb in plan.fragments(r)])
+                gather_verified = gather_verified and bool(torch.equal(got, sums[r]))
     t0 = time.perf_counter()
     for k in range(K):
         step(k, True)
@@ -251,6 +270,7 @@ def main():
             "encode_gaussians_per_s_per_gpu": n / (enc_ms * 1e-3),
             "decode_gaussians_per_s_per_gpu": n / (dec_ms * 1e-3),
             "reencode_fixed_point": fixed_point,
+            "gather_verified": gather_verified,
         }
         if world == 1 and not args.no_cpu_baseline:
             def gpu_stream_fn(m):
