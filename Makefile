@@ -29,9 +29,9 @@ device: $(LIBDIR)/libspz_amd.so
 host:   $(LIBDIR)/libspz_host.so
 python: $(ROOT)spz_amd/spz$(PYEXT)
 
-$(LIBDIR)/libspz_amd.so: $(CSRC)/spz_kernels.hip $(INC)/spz_amd.h
+$(LIBDIR)/libspz_amd.so: $(CSRC)/spz_kernels.hip $(CSRC)/spz_ply_kernels.hip $(CSRC)/spz_common.hpp $(INC)/spz_amd.h
 	mkdir -p $(LIBDIR)
-	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/spz_kernels.hip
+	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/spz_kernels.hip $(CSRC)/spz_ply_kernels.hip
 
 $(LIBDIR)/libspz_host.so: $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp $(INC)/spz_amd_host.hpp $(INC)/spz_amd.h $(LIBDIR)/libspz_amd.so
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp -L$(LIBDIR) -lspz_amd -lz \

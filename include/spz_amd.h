@@ -157,6 +157,37 @@ int spz_amd_convert_coordinates_host(float *h_positions, float *h_rotations, flo
                                      uint64_t num_points, int sh_degree, int from_coord,
                                      int to_coord, int device);
 
+/* ---- .ply vertex rows <-> GaussianCloud arrays (the step on the far side of
+ *      the hot path).  A binary-LE 3DGS .ply stores one row of `property float` columns per
+ *      Gaussian (load-spz.cc:728-740); the column map below is what the header parse yields
+ *      (:742-786).  rows_to_cloud replaces the AoS->SoA loop of loadSplatFromPly incl. the
+ *      [channel][coeff] -> [coeff][channel] sh transpose (:814-839) and the trailing
+ *      convertCoordinates(RDF, to) (:842); cloud_to_rows replaces the row assembly of
+ *      saveSplatToPly with its from->RDF flips (:858-893).  sh_dim is the number of sh
+ *      coefficients per channel actually present (0..15; 0,3,8,15 for degrees 0..3). ------------ */
+typedef struct {
+  int32_t stride;      /* floats per row (= number of properties), 14 + 3*sh_dim .. 256 */
+  int32_t sh_dim;      /* 0..15 */
+  int32_t position[3]; /* x, y, z */
+  int32_t scale[3];    /* scale_0, scale_1, scale_2 */
+  int32_t rotation[4]; /* rot_1, rot_2, rot_3, rot_0  (cloud order x y z w; the file is w x y z) */
+  int32_t alpha;       /* opacity */
+  int32_t color[3];    /* f_dc_0, f_dc_1, f_dc_2 */
+  int32_t sh[45];      /* f_rest_i, i < 3*sh_dim, file order [channel][coeff] */
+} spz_amd_ply_columns;
+
+/* The layout saveSplatToPly writes (load-spz.cc:900-922): x y z nx ny nz f_dc_0..2 f_rest_* opacity
+ * scale_0..2 rot_0..3; stride = 17 + 3*sh_dim. */
+int spz_amd_ply_default_columns(int sh_dim, spz_amd_ply_columns *out);
+int spz_amd_ply_rows_to_cloud_device(const float *d_rows, uint64_t num_points, const spz_amd_ply_columns *cols,
+                                     int to_coord, const spz_amd_cloud_out *d_cloud, void *hip_stream);
+int spz_amd_cloud_to_ply_rows_device(const spz_amd_cloud_in *d_cloud, uint64_t num_points, int sh_dim,
+                                     int from_coord, float *d_rows, void *hip_stream);
+int spz_amd_ply_rows_to_cloud_host(const float *h_rows, uint64_t num_points, const spz_amd_ply_columns *cols,
+                                   int to_coord, const spz_amd_cloud_out *h_cloud, int device);
+int spz_amd_cloud_to_ply_rows_host(const spz_amd_cloud_in *h_cloud, uint64_t num_points, int sh_dim,
+                                   int from_coord, float *h_rows, int device);
+
 /* ---- tables.  The alpha / colour decode tables (invSigmoid(b/255) load-spz.cc:87,518;
  *      ((b/255)-0.5)/0.15 :522) and the 255 alpha-encode thresholds (smallest float whose
  *      toUint8(sigmoid(a)*255) (:85,301) is >= v) are computed once on the host with the

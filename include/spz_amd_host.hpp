@@ -121,5 +121,6 @@ bool packToStream(const GaussianCloud &g, const PackOptions &o, std::vector<uint
 GaussianCloud unpackFromStream(const uint8_t *stream, size_t size, const UnpackOptions &o);
 // Status (spz_amd.h codes) of the last device call made by this thread; 0 = ok.
 int lastDeviceStatus();
+void setLastDeviceStatus(int status);
 
 }  // namespace spz

@@ -116,6 +116,26 @@ class Oracle:
         self.lib.spzo_convert_coordinates(_fp(p), _fp(r), _fp(s), n, sh_dim(deg), from_coord, to_coord)
         return p, r, s
 
+    def ply_rows_to_cloud(self, rows, n, cols, to_coord=0):
+        """cols: a ctypes structure with spz_amd_ply_columns' layout (e.g. spz_amd.abi.PlyColumns)."""
+        rows = _f32(rows)
+        d = cols.sh_dim * 3
+        out = dict(positions=np.zeros(n * 3, np.float32), scales=np.zeros(n * 3, np.float32),
+                   rotations=np.zeros(n * 4, np.float32), alphas=np.zeros(n, np.float32),
+                   colors=np.zeros(n * 3, np.float32), sh=np.zeros(n * d, np.float32))
+        self.lib.spzo_ply_rows_to_cloud.restype = None
+        self.lib.spzo_ply_rows_to_cloud.argtypes = [_f32p, C.c_int32, C.c_void_p, C.c_int] + [_f32p] * 6
+        self.lib.spzo_ply_rows_to_cloud(_fp(rows), n, C.byref(cols), to_coord, *_cloud_ptrs(out))
+        return out
+
+    def cloud_to_ply_rows(self, cloud, n, sh_dim, from_coord=0):
+        arrs = [_f32(cloud[k]) for k in ("positions", "scales", "rotations", "alphas", "colors", "sh")]
+        rows = np.zeros(n * (17 + 3 * sh_dim), np.float32)
+        self.lib.spzo_cloud_to_ply_rows.restype = None
+        self.lib.spzo_cloud_to_ply_rows.argtypes = [_f32p] * 6 + [C.c_int32, C.c_int, C.c_int, _f32p]
+        self.lib.spzo_cloud_to_ply_rows(*[_fp(a) for a in arrs], n, sh_dim, from_coord, _fp(rows))
+        return rows
+
     def alpha_decode_table(self):
         return np.array([self.lib.spzo_alpha_value(b) for b in range(256)], np.float32)
 
@@ -236,6 +256,21 @@ class Reference:
 
     def half_to_float(self, h):
         return self.lib.ref_half_to_float(int(h))
+
+    def save_ply(self, cloud, n, deg, from_coord, filename):
+        arrs = [_f32(cloud[k]) for k in ("positions", "scales", "rotations", "alphas", "colors", "sh")]
+        self.lib.ref_save_ply.restype = C.c_int
+        self.lib.ref_save_ply.argtypes = [_f32p] * 6 + [C.c_int32, C.c_int, C.c_int, C.c_char_p]
+        return self.lib.ref_save_ply(*[_fp(a) for a in arrs], n, deg, from_coord, filename.encode())
+
+    def load_ply(self, filename, n, deg, to_coord=0):
+        out = _alloc_cloud(n, deg)
+        info = (C.c_int32 * 3)()
+        self.lib.ref_load_ply.restype = C.c_int
+        self.lib.ref_load_ply.argtypes = [C.c_char_p, C.c_int] + [_f32p] * 6 + [C.POINTER(C.c_int32)]
+        self.lib.ref_load_ply(filename.encode(), to_coord, *_cloud_ptrs(out), info)
+        out.update(num_points=info[0], sh_degree=info[1], sh_size=info[2])
+        return out
 
     def bench_pack_unpack(self, cloud, n, deg, from_coord=0, to_coord=0, want_stream=False):
         arrs = [_f32(cloud[k]) for k in ("positions", "scales", "rotations", "alphas", "colors", "sh")]

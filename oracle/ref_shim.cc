@@ -189,6 +189,29 @@ void ref_unpack_quat_first_three(const uint8_t *r, int32_t n, int to, float *out
 
 float ref_half_to_float(uint16_t h) { return spz::halfToFloat(h); }
 
+// saveSplatToPly / loadSplatFromPly through real files (the reference has no in-memory form).
+int ref_save_ply(const float *pos, const float *scales, const float *rot, const float *alphas,
+                 const float *colors, const float *sh, int32_t n, int shDegree, int from, const char *filename) {
+  spz::GaussianCloud g = makeCloud(pos, scales, rot, alphas, colors, sh, n, shDegree, 0);
+  spz::PackOptions o;
+  o.from = static_cast<spz::CoordinateSystem>(from);
+  return spz::saveSplatToPly(g, o, filename) ? 0 : -1;
+}
+
+int ref_load_ply(const char *filename, int to, float *pos, float *scales, float *rot, float *alphas, float *colors,
+                 float *sh, int32_t *info) {
+  spz::UnpackOptions o;
+  o.to = static_cast<spz::CoordinateSystem>(to);
+  spz::GaussianCloud g = spz::loadSplatFromPly(filename, o);
+  if (info) {
+    info[0] = g.numPoints;
+    info[1] = g.shDegree;
+    info[2] = static_cast<int32_t>(g.sh.size());
+  }
+  copyOut(g, pos, scales, rot, alphas, colors, sh);
+  return 0;
+}
+
 // CPU baseline: time the reference's packGaussians and unpackGaussians (gzip-free, as SURVEY §8d)
 // on caller-provided arrays.  The vector copies happen outside the timed regions.  Optionally
 // returns the serialized stream (for a parity cross-check of what was timed).

@@ -410,3 +410,65 @@ int spzo_unpack(const uint8_t *stream, size_t size, int to_coord, float *positio
   spzo_convert_coordinates(positions, rotations, sh, (int32_t)n, shDim, 4 /* RUB */, to_coord);
   return 0;
 }
+
+/* ---- loadSplatFromPly value loop, load-spz.cc:814-839, then :842 ------------------------------ */
+void spzo_ply_rows_to_cloud(const float *values, int32_t numPoints, const spzo_ply_columns_t *cols, int to_coord,
+                            float *positions, float *scales, float *rotations, float *alphas, float *colors,
+                            float *sh) {
+  const size_t fields = (size_t)cols->stride;
+  const int shDim = cols->sh_dim;
+  size_t o3 = 0, o4 = 0, o1 = 0, osh = 0;
+  for (size_t p = 0; p < (size_t)numPoints; p++) {
+    const size_t i = p * fields;
+    for (int j = 0; j < 3; j++) positions[o3 + j] = values[i + cols->position[j]];
+    for (int j = 0; j < 3; j++) scales[o3 + j] = values[i + cols->scale[j]];
+    for (int j = 0; j < 4; j++) rotations[o4 + j] = values[i + cols->rotation[j]];
+    alphas[o1] = values[i + cols->alpha];
+    for (int j = 0; j < 3; j++) colors[o3 + j] = values[i + cols->color[j]];
+    /* [N,C,S] -> [N,S,C] */
+    for (int j = 0; j < shDim; j++) {
+      sh[osh++] = values[i + cols->sh[j]];
+      sh[osh++] = values[i + cols->sh[j + shDim]];
+      sh[osh++] = values[i + cols->sh[j + 2 * shDim]];
+    }
+    o3 += 3;
+    o4 += 4;
+    o1 += 1;
+  }
+  spzo_convert_coordinates(positions, rotations, sh, numPoints, shDim, 6 /* RDF */, to_coord);
+}
+
+/* ---- saveSplatToPly row assembly, load-spz.cc:846-893 ------------------------------------------ */
+void spzo_cloud_to_ply_rows(const float *positions, const float *scales, const float *rotations,
+                            const float *alphas, const float *colors, const float *sh, int32_t N, int shDim,
+                            int from_coord, float *values) {
+  const int D = 17 + shDim * 3;
+  spzo_converter_t c;
+  spzo_coordinate_converter(from_coord, 6 /* RDF */, &c);
+  size_t outIdx = 0, i3 = 0, i4 = 0;
+  for (int32_t i = 0; i < N; i++) {
+    values[outIdx++] = c.flipP[0] * positions[i3 + 0];
+    values[outIdx++] = c.flipP[1] * positions[i3 + 1];
+    values[outIdx++] = c.flipP[2] * positions[i3 + 2];
+    values[outIdx++] = 0.0f; /* normals */
+    values[outIdx++] = 0.0f;
+    values[outIdx++] = 0.0f;
+    values[outIdx++] = colors[i3 + 0];
+    values[outIdx++] = colors[i3 + 1];
+    values[outIdx++] = colors[i3 + 2];
+    for (int j = 0; j < shDim; j++) values[outIdx++] = c.flipSh[j] * sh[((size_t)i * shDim + j) * 3];
+    for (int j = 0; j < shDim; j++) values[outIdx++] = c.flipSh[j] * sh[((size_t)i * shDim + j) * 3 + 1];
+    for (int j = 0; j < shDim; j++) values[outIdx++] = c.flipSh[j] * sh[((size_t)i * shDim + j) * 3 + 2];
+    values[outIdx++] = alphas[i];
+    values[outIdx++] = scales[i3 + 0];
+    values[outIdx++] = scales[i3 + 1];
+    values[outIdx++] = scales[i3 + 2];
+    values[outIdx++] = rotations[i4 + 3];
+    values[outIdx++] = c.flipQ[0] * rotations[i4 + 0];
+    values[outIdx++] = c.flipQ[1] * rotations[i4 + 1];
+    values[outIdx++] = c.flipQ[2] * rotations[i4 + 2];
+    i3 += 3;
+    i4 += 4;
+  }
+  (void)D;
+}

@@ -86,6 +86,23 @@ void spzo_unpack_quat_smallest_three(float q[4], const uint8_t r[4],
 void spzo_unpack_quat_first_three(float q[4], const uint8_t r[3],
                                   const spzo_converter_t *c); /* load-spz.cc:333-345 */
 
+/* ---- .ply rows <-> cloud -------------------------------------------------- */
+/* Column map of a vertex row; same field order as spz_amd_ply_columns. */
+typedef struct {
+  int32_t stride, sh_dim;
+  int32_t position[3], scale[3], rotation[4], alpha, color[3], sh[45];
+} spzo_ply_columns_t;
+
+/* The value-shuffling part of loadSplatFromPly (load-spz.cc:814-839) followed by
+ * convertCoordinates(RDF, to) (:842). */
+void spzo_ply_rows_to_cloud(const float *rows, int32_t num_points, const spzo_ply_columns_t *cols, int to_coord,
+                            float *positions, float *scales, float *rotations, float *alphas, float *colors,
+                            float *sh);
+/* The row assembly of saveSplatToPly (load-spz.cc:846-893); rows has num_points*(17+3*sh_dim) floats. */
+void spzo_cloud_to_ply_rows(const float *positions, const float *scales, const float *rotations,
+                            const float *alphas, const float *colors, const float *sh, int32_t num_points,
+                            int sh_dim, int from_coord, float *rows);
+
 #ifdef __cplusplus
 }
 #endif

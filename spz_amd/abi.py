@@ -35,6 +35,8 @@ EXPORTS = (
     "spz_amd_encode_device", "spz_amd_decode_device", "spz_amd_encode_shard_device",
     "spz_amd_decode_shard_device", "spz_amd_convert_coordinates_device", "spz_amd_encode_host",
     "spz_amd_decode_host", "spz_amd_convert_coordinates_host", "spz_amd_get_tables",
+    "spz_amd_ply_default_columns", "spz_amd_ply_rows_to_cloud_device", "spz_amd_cloud_to_ply_rows_device",
+    "spz_amd_ply_rows_to_cloud_host", "spz_amd_cloud_to_ply_rows_host",
 )
 
 
@@ -55,6 +57,12 @@ class Layout(C.Structure):
 class CloudPtrs(C.Structure):
     """spz_amd_cloud_in / spz_amd_cloud_out (same layout: six pointers)."""
     _fields_ = [(k, C.c_void_p) for k in ("positions", "scales", "rotations", "alphas", "colors", "sh")]
+
+
+class PlyColumns(C.Structure):
+    """spz_amd_ply_columns: column map of a .ply vertex row."""
+    _fields_ = [("stride", C.c_int32), ("sh_dim", C.c_int32), ("position", C.c_int32 * 3), ("scale", C.c_int32 * 3),
+                ("rotation", C.c_int32 * 4), ("alpha", C.c_int32), ("color", C.c_int32 * 3), ("sh", C.c_int32 * 45)]
 
 
 class SpzAmdError(RuntimeError):
@@ -117,6 +125,16 @@ def bind(L):
     L.spz_amd_convert_coordinates_host.argtypes = [vp, vp, vp, u64, i32, i32, i32, i32]
     L.spz_amd_get_tables.restype = i32
     L.spz_amd_get_tables.argtypes = [vp, vp, vp]
+    L.spz_amd_ply_default_columns.restype = i32
+    L.spz_amd_ply_default_columns.argtypes = [i32, C.POINTER(PlyColumns)]
+    L.spz_amd_ply_rows_to_cloud_device.restype = i32
+    L.spz_amd_ply_rows_to_cloud_device.argtypes = [vp, u64, C.POINTER(PlyColumns), i32, C.POINTER(CloudPtrs), vp]
+    L.spz_amd_cloud_to_ply_rows_device.restype = i32
+    L.spz_amd_cloud_to_ply_rows_device.argtypes = [C.POINTER(CloudPtrs), u64, i32, i32, vp, vp]
+    L.spz_amd_ply_rows_to_cloud_host.restype = i32
+    L.spz_amd_ply_rows_to_cloud_host.argtypes = [vp, u64, C.POINTER(PlyColumns), i32, C.POINTER(CloudPtrs), i32]
+    L.spz_amd_cloud_to_ply_rows_host.restype = i32
+    L.spz_amd_cloud_to_ply_rows_host.argtypes = [C.POINTER(CloudPtrs), u64, i32, i32, vp, i32]
     return L
 
 

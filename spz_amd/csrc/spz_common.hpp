@@ -1,0 +1,115 @@
+// spz_common.hpp — pieces shared by the HIP translation units of libspz_amd.so
+// (spz_kernels.hip: pack/unpack/flip kernels + C ABI; spz_ply_kernels.hip: .ply row shuffles).
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "spz_amd.h"
+
+namespace spz_amd_detail {
+
+// 16-byte float access that needs only dword alignment.
+struct __attribute__((packed, aligned(4))) F32x4 { float x, y, z, w; };
+
+__device__ __forceinline__ bool is_nan_bits(uint32_t b) { return (b & 0x7fffffffu) > 0x7f800000u; }
+
+
+// v * (neg ? -1.0f : 1.0f) with the x86 mulss result also for NaN (a NaN operand is returned
+// quieted, sign untouched) and for zeros (0 * -1 = -0).
+__device__ __forceinline__ float mul_pm1(float v, uint32_t neg) {
+  uint32_t b = __float_as_uint(v);
+  uint32_t flipped = b ^ (neg << 31);
+  return __uint_as_float(is_nan_bits(b) ? (b | 0x00400000u) : flipped);
+}
+
+
+// ---- host side ---------------------------------------------------------------------------------
+extern thread_local int g_last_hip_error;
+
+#define SPZ_HIP_TRY(expr)                                   \
+  do {                                                      \
+    hipError_t e_ = (expr);                                 \
+    if (e_ != hipSuccess) {                                 \
+      ::spz_amd_detail::g_last_hip_error = (int)e_;         \
+      return SPZ_AMD_ERR_HIP;                               \
+    }                                                       \
+  } while (0)
+
+constexpr int kMaxDevices = 64;
+
+// axesMatch + coordinateConverter (splat-types.h:43-81) reduced to sign masks.
+struct FlipMasks {
+  uint32_t p;           // bit a: axis a negated
+  uint32_t q;           // bit i: quaternion x/y/z negated
+  uint32_t sh15;        // bit k: sh coefficient k negated
+};
+
+inline FlipMasks flip_masks(int from, int to) {
+  FlipMasks m = {0, 0, 0};
+  int a = from - 1, b = to - 1;
+  if (a < 0 || b < 0) return m;
+  const uint32_t x = (((a >> 0) & 1) != ((b >> 0) & 1)) ? 1u : 0u;  // 1 = negative
+  const uint32_t y = (((a >> 1) & 1) != ((b >> 1) & 1)) ? 1u : 0u;
+  const uint32_t z = (((a >> 2) & 1) != ((b >> 2) & 1)) ? 1u : 0u;
+  m.p = x | (y << 1) | (z << 2);
+  m.q = (y ^ z) | ((x ^ z) << 1) | ((x ^ y) << 2);
+  // flipSh = {y, z, x, xy, yz, 1, xz, 1, y, xyz, y, z, x, z, x}
+  const uint32_t sh[15] = {y, z, x, x ^ y, y ^ z, 0, x ^ z, 0, y, x ^ y ^ z, y, z, x, z, x};
+  for (int k = 0; k < 15; ++k) m.sh15 |= sh[k] << k;
+  return m;
+}
+
+
+inline bool valid_coord(int c) { return c >= 0 && c <= 8; }
+
+// Current HIP device, or SPZ_AMD_ERR_NO_DEVICE when the runtime has none.
+inline int current_device(int *device) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess || n <= 0) {
+    g_last_hip_error = (int)e;
+    return SPZ_AMD_ERR_NO_DEVICE;
+  }
+  SPZ_HIP_TRY(hipGetDevice(device));
+  return SPZ_AMD_OK;
+}
+
+
+// RAII device buffer for the *_host entry points.
+struct DevBuf {
+  void *p = nullptr;
+  ~DevBuf() {
+    if (p) (void)hipFree(p);
+  }
+  int alloc(size_t bytes) {
+    if (bytes == 0) return SPZ_AMD_OK;
+    SPZ_HIP_TRY(hipMalloc(&p, bytes));
+    return SPZ_AMD_OK;
+  }
+};
+
+struct DeviceGuard {
+  int prev = -1;
+  bool active = false;
+  int enter(int device) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) {
+      g_last_hip_error = (int)e;
+      return SPZ_AMD_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) return SPZ_AMD_ERR_INVALID_ARG;
+    SPZ_HIP_TRY(hipGetDevice(&prev));
+    SPZ_HIP_TRY(hipSetDevice(device));
+    active = true;
+    return SPZ_AMD_OK;
+  }
+  ~DeviceGuard() {
+    if (active && prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+
+}  // namespace spz_amd_detail

@@ -144,6 +144,7 @@ bool readFile(const std::string &filename, std::vector<uint8_t> *data, bool log)
 }  // namespace
 
 int lastDeviceStatus() { return g_last_status; }
+void setLastDeviceStatus(int status) { g_last_status = status; }
 
 // ---- splat-types.h:43-81 ---------------------------------------------------------------------
 CoordinateConverter coordinateConverter(CoordinateSystem from, CoordinateSystem to) {

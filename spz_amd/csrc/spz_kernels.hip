@@ -42,10 +42,17 @@
 #include <mutex>
 
 #include "spz_amd.h"
+#include "spz_common.hpp"
 
 #pragma clang fp contract(off)
 
+namespace spz_amd_detail {
+thread_local int g_last_hip_error = 0;
+}
+
 namespace {
+
+using namespace spz_amd_detail;
 
 // ------------------------------------------------------------------------------------------
 // Geometry
@@ -158,7 +165,6 @@ constexpr int kTableFloats = 768;
 // ------------------------------------------------------------------------------------------
 // Unaligned access types.  The float side needs dword alignment only; the byte side none.
 // ------------------------------------------------------------------------------------------
-struct __attribute__((packed, aligned(4))) F32x4 { float x, y, z, w; };
 struct __attribute__((packed, aligned(1))) U32x1 { uint32_t a; };
 struct __attribute__((packed, aligned(1))) U32x2 { uint32_t a, b; };
 struct __attribute__((packed, aligned(1))) U32x3 { uint32_t a, b, c; };
@@ -195,16 +201,6 @@ __device__ __forceinline__ float fadd_sep(float a, float b) {
   float r = a + b;
   asm volatile("" : "+v"(r));
   return r;
-}
-
-__device__ __forceinline__ bool is_nan_bits(uint32_t b) { return (b & 0x7fffffffu) > 0x7f800000u; }
-
-// v * (neg ? -1.0f : 1.0f) with the x86 mulss result also for NaN (a NaN operand is returned
-// quieted, sign untouched) and for zeros (0 * -1 = -0).
-__device__ __forceinline__ float mul_pm1(float v, uint32_t neg) {
-  uint32_t b = __float_as_uint(v);
-  uint32_t flipped = b ^ (neg << 31);
-  return __uint_as_float(is_nan_bits(b) ? (b | 0x00400000u) : flipped);
 }
 
 // Same product for operands that cannot be NaN (or whose NaN sign cannot reach the output): a
@@ -859,20 +855,7 @@ __global__ __launch_bounds__(FlipGeom::kBlock) void spz_flip_kernel(const KParam
 // ==========================================================================================
 // Host side
 // ==========================================================================================
-thread_local int g_last_hip_error = 0;
-
-#define SPZ_HIP_TRY(expr)                            \
-  do {                                               \
-    hipError_t e_ = (expr);                          \
-    if (e_ != hipSuccess) {                          \
-      g_last_hip_error = (int)e_;                    \
-      return SPZ_AMD_ERR_HIP;                        \
-    }                                                \
-  } while (0)
-
 constexpr uint32_t kMagic = 0x5053474eu;  // load-spz.cc:132
-constexpr int kMaxDevices = 64;
-
 int sh_dim_for_degree(int d) {  // load-spz.cc:58-72
   switch (d) {
     case 0: return 0;
@@ -881,28 +864,6 @@ int sh_dim_for_degree(int d) {  // load-spz.cc:58-72
     case 3: return 15;
     default: return -1;
   }
-}
-
-// axesMatch + coordinateConverter (splat-types.h:43-81) reduced to sign masks.
-struct FlipMasks {
-  uint32_t p;           // bit a: axis a negated
-  uint32_t q;           // bit i: quaternion x/y/z negated
-  uint32_t sh15;        // bit k: sh coefficient k negated
-};
-
-FlipMasks flip_masks(int from, int to) {
-  FlipMasks m = {0, 0, 0};
-  int a = from - 1, b = to - 1;
-  if (a < 0 || b < 0) return m;
-  const uint32_t x = (((a >> 0) & 1) != ((b >> 0) & 1)) ? 1u : 0u;  // 1 = negative
-  const uint32_t y = (((a >> 1) & 1) != ((b >> 1) & 1)) ? 1u : 0u;
-  const uint32_t z = (((a >> 2) & 1) != ((b >> 2) & 1)) ? 1u : 0u;
-  m.p = x | (y << 1) | (z << 2);
-  m.q = (y ^ z) | ((x ^ z) << 1) | ((x ^ y) << 2);
-  // flipSh = {y, z, x, xy, yz, 1, xz, 1, y, xyz, y, z, x, z, x}
-  const uint32_t sh[15] = {y, z, x, x ^ y, y ^ z, 0, x ^ z, 0, y, x ^ y ^ z, y, z, x, z, x};
-  for (int k = 0; k < 15; ++k) m.sh15 |= sh[k] << k;
-  return m;
 }
 
 // Per-element mask over a point's D = 3*shDim sh floats, with elements 0..2 repeated at D..D+2
@@ -997,17 +958,6 @@ int ensure_tables(int device, const float **dev_tables) {
   return SPZ_AMD_OK;
 }
 
-int current_device(int *device) {
-  int n = 0;
-  hipError_t e = hipGetDeviceCount(&n);
-  if (e != hipSuccess || n <= 0) {
-    g_last_hip_error = (int)e;
-    return SPZ_AMD_ERR_NO_DEVICE;
-  }
-  SPZ_HIP_TRY(hipGetDevice(device));
-  return SPZ_AMD_OK;
-}
-
 int grid_for(int device, uint32_t total_tiles, uint32_t *grid) {
   uint32_t cap = 0x7fffffffu;  // hipGridDim.x limit; the kernels grid-stride beyond it
   if (kMaxBlocksPerCU > 0) {
@@ -1037,8 +987,6 @@ void add_section(KParams *p, uint32_t tile_units, uint32_t kind, uint8_t *bytes,
   s.kind = kind;
   p->total_tiles += (uint32_t)((s.n_units + tile_units - 1) / tile_units);
 }
-
-bool valid_coord(int c) { return c >= 0 && c <= 8; }
 
 int layout_impl(uint64_t n, int sh_degree, int version, spz_amd_layout *out) {
   const int sd = sh_dim_for_degree(sh_degree);
@@ -1164,40 +1112,6 @@ int decode_impl(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr,
   SPZ_HIP_TRY(hipGetLastError());
   return SPZ_AMD_OK;
 }
-
-// RAII device buffer for the *_host entry points.
-struct DevBuf {
-  void *p = nullptr;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
-  }
-  int alloc(size_t bytes) {
-    if (bytes == 0) return SPZ_AMD_OK;
-    SPZ_HIP_TRY(hipMalloc(&p, bytes));
-    return SPZ_AMD_OK;
-  }
-};
-
-struct DeviceGuard {
-  int prev = -1;
-  bool active = false;
-  int enter(int device) {
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    if (e != hipSuccess || n <= 0) {
-      g_last_hip_error = (int)e;
-      return SPZ_AMD_ERR_NO_DEVICE;
-    }
-    if (device < 0 || device >= n) return SPZ_AMD_ERR_INVALID_ARG;
-    SPZ_HIP_TRY(hipGetDevice(&prev));
-    SPZ_HIP_TRY(hipSetDevice(device));
-    active = true;
-    return SPZ_AMD_OK;
-  }
-  ~DeviceGuard() {
-    if (active && prev >= 0) (void)hipSetDevice(prev);
-  }
-};
 
 }  // namespace
 

@@ -3,17 +3,20 @@
 // Mirrors the behaviour of loadSplatFromPly / saveSplatToPly of the reference
 // (/root/reference/src/cc/load-spz.cc:670-934): same header grammar, same field names, same
 // [N,C,S] <-> [N,S,C] spherical-harmonics transpose, same log lines and failure results.  This is
-// the step on the far side of the hot path; it is file parsing plus an
-// AoS<->SoA shuffle and stays on the host in this round.  The coordinate conversion of a loaded
-// cloud goes through GaussianCloud::convertCoordinates, i.e. the GPU flip pass.
+// the step on the far side of the hot path.  Header parsing and file I/O are
+// host work; the AoS<->SoA shuffle of the vertex rows, the sh [channel][coeff]<->[coeff][channel]
+// transpose and the coordinate flips run on the GPU through spz_amd_ply_rows_to_cloud_host /
+// spz_amd_cloud_to_ply_rows_host (spz_ply_kernels.hip).  No CPU fallback.
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
 #include <string>
 #include <vector>
 
+#include "spz_amd.h"
 #include "spz_amd_host.hpp"
 
 namespace spz {
@@ -40,6 +43,11 @@ bool nextHeaderLine(std::istream &in, std::string *line) {
     return true;
   }
   return false;
+}
+
+int plyDevice() {
+  const char *e = std::getenv("SPZ_AMD_DEVICE");
+  return e ? std::atoi(e) : 0;
 }
 
 bool startsWith(const std::string &s, const char *prefix) { return s.rfind(prefix, 0) == 0; }
@@ -135,6 +143,22 @@ GaussianCloud loadSplatFromPly(const std::string &filename, const UnpackOptions 
     return {};
   }
 
+  if (stride > 256) {
+    plyLog("[SPZ ERROR] spz_amd: %s: more than 256 properties per vertex are not supported", filename.c_str());
+    return {};
+  }
+  spz_amd_ply_columns cols = {};
+  cols.stride = static_cast<int32_t>(stride);
+  cols.sh_dim = shDim;
+  for (int k = 0; k < 3; ++k) {
+    cols.position[k] = cPos[k];
+    cols.scale[k] = cScale[k];
+    cols.color[k] = cColor[k];
+  }
+  for (int k = 0; k < 4; ++k) cols.rotation[k] = cRot[k];
+  cols.alpha = cAlpha;
+  for (int k = 0; k < shDim * 3; ++k) cols.sh[k] = cRest[k];
+
   GaussianCloud g;
   g.numPoints = numPoints;
   g.shDegree = degreeForDim(shDim);
@@ -145,24 +169,15 @@ GaussianCloud loadSplatFromPly(const std::string &filename, const UnpackOptions 
   g.alphas.resize(n);
   g.colors.resize(n * 3);
   g.sh.resize(n * static_cast<size_t>(shDim) * 3);
-  for (size_t p = 0; p < n; ++p) {
-    const float *row = rows.data() + p * stride;
-    for (int k = 0; k < 3; ++k) {
-      g.positions[p * 3 + k] = row[cPos[k]];
-      g.scales[p * 3 + k] = row[cScale[k]];
-      g.colors[p * 3 + k] = row[cColor[k]];
-    }
-    for (int k = 0; k < 4; ++k) g.rotations[p * 4 + k] = row[cRot[k]];
-    g.alphas[p] = row[cAlpha];
-    // file: [channel][coeff]  ->  cloud: [coeff][channel]
-    float *sh = g.sh.data() + p * static_cast<size_t>(shDim) * 3;
-    for (int j = 0; j < shDim; ++j) {
-      sh[j * 3 + 0] = row[cRest[j]];
-      sh[j * 3 + 1] = row[cRest[j + shDim]];
-      sh[j * 3 + 2] = row[cRest[j + 2 * shDim]];
-    }
+  spz_amd_cloud_out out = {g.positions.data(), g.scales.data(), g.rotations.data(),
+                           g.alphas.data(),    g.colors.data(), g.sh.empty() ? nullptr : g.sh.data()};
+  // rows -> cloud with convertCoordinates(RDF, o.to) fused (load-spz.cc:814-842)
+  const int rc = spz_amd_ply_rows_to_cloud_host(rows.data(), n, &cols, static_cast<int>(o.to), &out, plyDevice());
+  if (rc != SPZ_AMD_OK) {
+    plyLog("[SPZ ERROR] spz_amd: loadSplatFromPly: %s", spz_amd_status_string(rc));
+    setLastDeviceStatus(rc);
+    return {};
   }
-  g.convertCoordinates(CoordinateSystem::RDF, o.to);
   return g;
 }
 
@@ -183,24 +198,21 @@ bool saveSplatToPly(const GaussianCloud &data, const PackOptions &o, const std::
   }
   const int shDim = n ? static_cast<int>(data.sh.size() / n / 3) : 0;
   const size_t D = 17 + static_cast<size_t>(shDim) * 3;
-  const CoordinateConverter c = coordinateConverter(o.from, CoordinateSystem::RDF);
-
+  if (shDim > 15) {
+    plyLog("[SPZ ERROR] spz_amd: saveSplatToPly: %d sh coefficients per channel (max 15)", shDim);
+    return false;
+  }
   std::vector<float> rows(n * D, 0.0f);
-  for (size_t p = 0; p < n; ++p) {
-    float *row = rows.data() + p * D;
-    size_t k = 0;
-    for (int a = 0; a < 3; ++a) row[k++] = c.flipP[a] * data.positions[p * 3 + a];
-    k += 3;  // nx, ny, nz stay zero
-    for (int a = 0; a < 3; ++a) row[k++] = data.colors[p * 3 + a];
-    // cloud: [coeff][channel]  ->  file: [channel][coeff]
-    const float *sh = data.sh.data() + p * static_cast<size_t>(shDim) * 3;
-    for (int ch = 0; ch < 3; ++ch) {
-      for (int j = 0; j < shDim; ++j) row[k++] = c.flipSh[j] * sh[j * 3 + ch];
+  if (n) {
+    spz_amd_cloud_in in = {data.positions.data(), data.scales.data(), data.rotations.data(),
+                           data.alphas.data(),    data.colors.data(), data.sh.empty() ? nullptr : data.sh.data()};
+    // row assembly with the from -> RDF flips (load-spz.cc:856-893)
+    const int rc = spz_amd_cloud_to_ply_rows_host(&in, n, shDim, static_cast<int>(o.from), rows.data(), plyDevice());
+    if (rc != SPZ_AMD_OK) {
+      plyLog("[SPZ ERROR] spz_amd: saveSplatToPly: %s", spz_amd_status_string(rc));
+      setLastDeviceStatus(rc);
+      return false;
     }
-    row[k++] = data.alphas[p];
-    for (int a = 0; a < 3; ++a) row[k++] = data.scales[p * 3 + a];
-    row[k++] = data.rotations[p * 4 + 3];  // w first
-    for (int a = 0; a < 3; ++a) row[k++] = c.flipQ[a] * data.rotations[p * 4 + a];
   }
 
   std::ofstream out(filename, std::ios::binary);

@@ -1,0 +1,294 @@
+// spz_ply_kernels.hip — .ply vertex rows <-> GaussianCloud arrays on the GPU.
+//
+// Replaces, in the reference (/root/reference/src/cc/load-spz.cc):
+//   rows -> cloud : the AoS->SoA loop of loadSplatFromPly (:814-839, sh [channel][coeff] ->
+//                   [coeff][channel]) and the convertCoordinates(RDF, to) pass that follows (:842)
+//   cloud -> rows : the row assembly of saveSplatToPly with its from->RDF flips (:858-893)
+//
+// Both are pure shuffles (HBM-bound, no arithmetic beyond +-1 products).  A block owns a tile of
+// 64 Gaussians: the tile's source bytes are read with lane-contiguous 16-byte loads into LDS, the
+// permutation happens in LDS, and the destination is written lane-contiguously again, so neither
+// side of the AoS<->SoA transpose touches HBM with a strided pattern.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+
+#include "spz_amd.h"
+#include "spz_common.hpp"
+
+namespace {
+
+using namespace spz_amd_detail;
+
+constexpr int kPlyBlock = 256;
+constexpr int kPlyPoints = 64;  // Gaussians per tile
+constexpr int kMaxStride = 256; // 64 * 256 * 4 B = 64 KiB of LDS
+
+struct PlyParams {
+  const float *rows_in;
+  float *rows_out;
+  const float *in[6];  // positions, scales, rotations, alphas, colors, sh
+  float *out[6];
+  unsigned long long n;
+  spz_amd_ply_columns cols;
+  uint32_t flip_p, flip_q, flip_sh15;
+};
+
+__device__ __forceinline__ void copy_to_lds(float *__restrict__ dst, const float *__restrict__ src, uint32_t count) {
+  const uint32_t vec = count & ~3u;
+  for (uint32_t i = threadIdx.x * 4u; i < vec; i += kPlyBlock * 4u) {
+    F32x4 v = *reinterpret_cast<const F32x4 *>(src + i);
+    dst[i] = v.x; dst[i + 1] = v.y; dst[i + 2] = v.z; dst[i + 3] = v.w;
+  }
+  for (uint32_t i = vec + threadIdx.x; i < count; i += kPlyBlock) dst[i] = src[i];
+}
+
+__global__ __launch_bounds__(kPlyBlock) void spz_ply_rows_to_cloud_kernel(const PlyParams p) {
+  extern __shared__ float tile[];  // [np][stride]
+  const uint32_t stride = (uint32_t)p.cols.stride;
+  const uint32_t shd = (uint32_t)p.cols.sh_dim;
+  const unsigned long long first = (unsigned long long)blockIdx.x * kPlyPoints;
+  const unsigned long long left = p.n - first;
+  const uint32_t np = left < (unsigned long long)kPlyPoints ? (uint32_t)left : (uint32_t)kPlyPoints;
+  copy_to_lds(tile, p.rows_in + first * stride, np * stride);
+  __syncthreads();
+  const uint32_t tid = threadIdx.x;
+  // positions: value * flipP[axis] (convertCoordinates multiplies every element, load-spz.cc:842)
+  for (uint32_t i = tid; i < np * 3u; i += kPlyBlock) {
+    const uint32_t pt = i / 3u, a = i - pt * 3u;
+    p.out[0][first * 3u + i] = mul_pm1(tile[pt * stride + (uint32_t)p.cols.position[a]], (p.flip_p >> a) & 1u);
+  }
+  for (uint32_t i = tid; i < np * 3u; i += kPlyBlock) {
+    const uint32_t pt = i / 3u, a = i - pt * 3u;
+    p.out[1][first * 3u + i] = tile[pt * stride + (uint32_t)p.cols.scale[a]];
+    p.out[4][first * 3u + i] = tile[pt * stride + (uint32_t)p.cols.color[a]];
+  }
+  for (uint32_t i = tid; i < np * 4u; i += kPlyBlock) {
+    const uint32_t pt = i >> 2, c = i & 3u;
+    const float v = tile[pt * stride + (uint32_t)p.cols.rotation[c]];
+    p.out[2][first * 4u + i] = (c < 3u) ? mul_pm1(v, (p.flip_q >> c) & 1u) : v;  // w is never multiplied
+  }
+  for (uint32_t i = tid; i < np; i += kPlyBlock) p.out[3][first + i] = tile[i * stride + (uint32_t)p.cols.alpha];
+  // sh: file [channel][coeff] -> cloud [coeff][channel], times flipSh[coeff]
+  const uint32_t d = shd * 3u;
+  for (uint32_t i = tid; i < np * d; i += kPlyBlock) {
+    const uint32_t pt = i / d, e = i - pt * d;
+    const uint32_t j = e / 3u, ch = e - j * 3u;
+    const float v = tile[pt * stride + (uint32_t)p.cols.sh[j + ch * shd]];
+    p.out[5][first * d + i] = mul_pm1(v, (p.flip_sh15 >> j) & 1u);
+  }
+}
+
+__global__ __launch_bounds__(kPlyBlock) void spz_cloud_to_ply_rows_kernel(const PlyParams p) {
+  extern __shared__ float tile[];  // [pos 3P | scale 3P | rot 4P | alpha P | color 3P | sh dP]
+  const uint32_t shd = (uint32_t)p.cols.sh_dim;
+  const uint32_t d = shd * 3u;
+  const uint32_t D = 17u + d;  // floats per row
+  const unsigned long long first = (unsigned long long)blockIdx.x * kPlyPoints;
+  const unsigned long long left = p.n - first;
+  const uint32_t np = left < (unsigned long long)kPlyPoints ? (uint32_t)left : (uint32_t)kPlyPoints;
+  float *pos = tile, *scl = tile + 3 * kPlyPoints, *rot = tile + 6 * kPlyPoints, *alp = tile + 10 * kPlyPoints,
+        *col = tile + 11 * kPlyPoints, *sh = tile + 14 * kPlyPoints;
+  copy_to_lds(pos, p.in[0] + first * 3u, np * 3u);
+  copy_to_lds(scl, p.in[1] + first * 3u, np * 3u);
+  copy_to_lds(rot, p.in[2] + first * 4u, np * 4u);
+  copy_to_lds(alp, p.in[3] + first, np);
+  copy_to_lds(col, p.in[4] + first * 3u, np * 3u);
+  if (d) copy_to_lds(sh, p.in[5] + first * d, np * d);
+  __syncthreads();
+  float *dst = p.rows_out + first * D;
+  const uint32_t total = np * D;
+  auto element = [&](uint32_t i) -> float {
+    const uint32_t pt = i / D, f = i - pt * D;
+    if (f < 3u) return mul_pm1(pos[pt * 3u + f], (p.flip_p >> f) & 1u);  // load-spz.cc:861-863
+    if (f < 6u) return 0.0f;                                              // normals, :865
+    if (f < 9u) return col[pt * 3u + (f - 6u)];                           // :867-869
+    if (f < 9u + d) {                                                     // :872-880
+      const uint32_t g = f - 9u, ch = g / shd, j = g - ch * shd;
+      return mul_pm1(sh[(pt * shd + j) * 3u + ch], (p.flip_sh15 >> j) & 1u);
+    }
+    const uint32_t t = f - 9u - d;
+    if (t == 0u) return alp[pt];                                          // :882
+    if (t < 4u) return scl[pt * 3u + (t - 1u)];                           // :884-886
+    if (t == 4u) return rot[pt * 4u + 3u];                                // :888 (w first)
+    return mul_pm1(rot[pt * 4u + (t - 5u)], (p.flip_q >> (t - 5u)) & 1u); // :889-891
+  };
+  const uint32_t vec = total & ~3u;
+  for (uint32_t i = threadIdx.x * 4u; i < vec; i += kPlyBlock * 4u) {
+    F32x4 v;
+    v.x = element(i); v.y = element(i + 1); v.z = element(i + 2); v.w = element(i + 3);
+    *reinterpret_cast<F32x4 *>(dst + i) = v;
+  }
+  for (uint32_t i = vec + threadIdx.x; i < total; i += kPlyBlock) dst[i] = element(i);
+}
+
+int check_columns(const spz_amd_ply_columns *c) {
+  if (c == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  if (c->sh_dim < 0 || c->sh_dim > 15 || c->stride < 14 + 3 * c->sh_dim || c->stride > kMaxStride) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  auto ok = [&](int32_t v) { return v >= 0 && v < c->stride; };
+  for (int i = 0; i < 3; ++i) {
+    if (!ok(c->position[i]) || !ok(c->scale[i]) || !ok(c->color[i])) return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  for (int i = 0; i < 4; ++i) {
+    if (!ok(c->rotation[i])) return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  if (!ok(c->alpha)) return SPZ_AMD_ERR_INVALID_ARG;
+  for (int i = 0; i < 3 * c->sh_dim; ++i) {
+    if (!ok(c->sh[i])) return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  return SPZ_AMD_OK;
+}
+
+void set_flips(PlyParams *p, int from, int to) {
+  const FlipMasks fm = flip_masks(from, to);
+  p->flip_p = fm.p;
+  p->flip_q = fm.q;
+  p->flip_sh15 = fm.sh15;
+}
+
+uint32_t tiles(uint64_t n) { return (uint32_t)((n + kPlyPoints - 1) / kPlyPoints); }
+
+}  // namespace
+
+extern "C" {
+
+int spz_amd_ply_default_columns(int sh_dim, spz_amd_ply_columns *out) {
+  if (out == nullptr || sh_dim < 0 || sh_dim > 15) return SPZ_AMD_ERR_INVALID_ARG;
+  std::memset(out, 0, sizeof(*out));
+  out->sh_dim = sh_dim;
+  out->stride = 17 + 3 * sh_dim;
+  for (int i = 0; i < 3; ++i) {
+    out->position[i] = i;
+    out->color[i] = 6 + i;
+  }
+  for (int i = 0; i < 3 * sh_dim; ++i) out->sh[i] = 9 + i;
+  const int t = 9 + 3 * sh_dim;
+  out->alpha = t;
+  for (int i = 0; i < 3; ++i) out->scale[i] = t + 1 + i;
+  out->rotation[3] = t + 4;                                 // rot_0 = w
+  for (int i = 0; i < 3; ++i) out->rotation[i] = t + 5 + i;  // rot_1..3 = x y z
+  return SPZ_AMD_OK;
+}
+
+int spz_amd_ply_rows_to_cloud_device(const float *d_rows, uint64_t n, const spz_amd_ply_columns *cols,
+                                     int to_coord, const spz_amd_cloud_out *cl, void *hip_stream) {
+  int rc = check_columns(cols);
+  if (rc != SPZ_AMD_OK) return rc;
+  if (cl == nullptr || !valid_coord(to_coord)) return SPZ_AMD_ERR_INVALID_ARG;
+  if (n == 0) return SPZ_AMD_OK;
+  if (!d_rows || !cl->positions || !cl->scales || !cl->rotations || !cl->alphas || !cl->colors ||
+      (cols->sh_dim > 0 && !cl->sh) || n > 0xffffffffull * kPlyPoints) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  int device = 0;
+  rc = current_device(&device);
+  if (rc != SPZ_AMD_OK) return rc;
+  PlyParams p = {};
+  p.rows_in = d_rows;
+  float *outs[6] = {cl->positions, cl->scales, cl->rotations, cl->alphas, cl->colors, cl->sh};
+  for (int i = 0; i < 6; ++i) p.out[i] = outs[i];
+  p.n = n;
+  p.cols = *cols;
+  set_flips(&p, SPZ_AMD_RDF, to_coord);  // load-spz.cc:842
+  const size_t lds = (size_t)kPlyPoints * (size_t)cols->stride * sizeof(float);
+  hipLaunchKernelGGL(spz_ply_rows_to_cloud_kernel, dim3(tiles(n)), dim3(kPlyBlock), lds,
+                     static_cast<hipStream_t>(hip_stream), p);
+  SPZ_HIP_TRY(hipGetLastError());
+  return SPZ_AMD_OK;
+}
+
+int spz_amd_cloud_to_ply_rows_device(const spz_amd_cloud_in *cl, uint64_t n, int sh_dim, int from_coord,
+                                     float *d_rows, void *hip_stream) {
+  if (cl == nullptr || sh_dim < 0 || sh_dim > 15 || !valid_coord(from_coord)) return SPZ_AMD_ERR_INVALID_ARG;
+  if (n == 0) return SPZ_AMD_OK;
+  if (!d_rows || !cl->positions || !cl->scales || !cl->rotations || !cl->alphas || !cl->colors ||
+      (sh_dim > 0 && !cl->sh) || n > 0xffffffffull * kPlyPoints) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  int device = 0;
+  int rc = current_device(&device);
+  if (rc != SPZ_AMD_OK) return rc;
+  PlyParams p = {};
+  p.rows_out = d_rows;
+  const float *ins[6] = {cl->positions, cl->scales, cl->rotations, cl->alphas, cl->colors, cl->sh};
+  for (int i = 0; i < 6; ++i) p.in[i] = ins[i];
+  p.n = n;
+  p.cols.sh_dim = sh_dim;
+  p.cols.stride = 17 + 3 * sh_dim;
+  set_flips(&p, from_coord, SPZ_AMD_RDF);  // load-spz.cc:856
+  const size_t lds = (size_t)kPlyPoints * (size_t)(14 + 3 * sh_dim) * sizeof(float);
+  hipLaunchKernelGGL(spz_cloud_to_ply_rows_kernel, dim3(tiles(n)), dim3(kPlyBlock), lds,
+                     static_cast<hipStream_t>(hip_stream), p);
+  SPZ_HIP_TRY(hipGetLastError());
+  return SPZ_AMD_OK;
+}
+
+int spz_amd_ply_rows_to_cloud_host(const float *h_rows, uint64_t n, const spz_amd_ply_columns *cols, int to_coord,
+                                   const spz_amd_cloud_out *h, int device) {
+  int rc = check_columns(cols);
+  if (rc != SPZ_AMD_OK) return rc;
+  if (h == nullptr || !valid_coord(to_coord)) return SPZ_AMD_ERR_INVALID_ARG;
+  if (n == 0) return SPZ_AMD_OK;
+  const size_t d = (size_t)cols->sh_dim * 3;
+  if (!h_rows || !h->positions || !h->scales || !h->rotations || !h->alphas || !h->colors || (d && !h->sh)) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  DeviceGuard guard;
+  rc = guard.enter(device);
+  if (rc != SPZ_AMD_OK) return rc;
+  const size_t cnt[6] = {n * 3, n * 3, n * 4, n, n * 3, n * d};
+  float *dst[6] = {h->positions, h->scales, h->rotations, h->alphas, h->colors, h->sh};
+  DevBuf rows, fb[6];
+  const size_t row_bytes = n * (size_t)cols->stride * sizeof(float);
+  rc = rows.alloc(row_bytes);
+  if (rc != SPZ_AMD_OK) return rc;
+  SPZ_HIP_TRY(hipMemcpyAsync(rows.p, h_rows, row_bytes, hipMemcpyHostToDevice, nullptr));
+  for (int i = 0; i < 6; ++i) {
+    rc = fb[i].alloc(cnt[i] * sizeof(float));
+    if (rc != SPZ_AMD_OK) return rc;
+  }
+  spz_amd_cloud_out dc = {(float *)fb[0].p, (float *)fb[1].p, (float *)fb[2].p,
+                          (float *)fb[3].p, (float *)fb[4].p, (float *)fb[5].p};
+  rc = spz_amd_ply_rows_to_cloud_device((const float *)rows.p, n, cols, to_coord, &dc, nullptr);
+  if (rc != SPZ_AMD_OK) return rc;
+  for (int i = 0; i < 6; ++i) {
+    if (cnt[i]) SPZ_HIP_TRY(hipMemcpyAsync(dst[i], fb[i].p, cnt[i] * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+  }
+  SPZ_HIP_TRY(hipStreamSynchronize(nullptr));
+  return SPZ_AMD_OK;
+}
+
+int spz_amd_cloud_to_ply_rows_host(const spz_amd_cloud_in *h, uint64_t n, int sh_dim, int from_coord, float *h_rows,
+                                   int device) {
+  if (h == nullptr || sh_dim < 0 || sh_dim > 15 || !valid_coord(from_coord)) return SPZ_AMD_ERR_INVALID_ARG;
+  if (n == 0) return SPZ_AMD_OK;
+  const size_t d = (size_t)sh_dim * 3;
+  if (!h_rows || !h->positions || !h->scales || !h->rotations || !h->alphas || !h->colors || (d && !h->sh)) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  DeviceGuard guard;
+  int rc = guard.enter(device);
+  if (rc != SPZ_AMD_OK) return rc;
+  const size_t cnt[6] = {n * 3, n * 3, n * 4, n, n * 3, n * d};
+  const float *src[6] = {h->positions, h->scales, h->rotations, h->alphas, h->colors, h->sh};
+  DevBuf rows, fb[6];
+  for (int i = 0; i < 6; ++i) {
+    rc = fb[i].alloc(cnt[i] * sizeof(float));
+    if (rc != SPZ_AMD_OK) return rc;
+    if (cnt[i]) SPZ_HIP_TRY(hipMemcpyAsync(fb[i].p, src[i], cnt[i] * sizeof(float), hipMemcpyHostToDevice, nullptr));
+  }
+  const size_t row_bytes = n * (size_t)(17 + d) * sizeof(float);
+  rc = rows.alloc(row_bytes);
+  if (rc != SPZ_AMD_OK) return rc;
+  spz_amd_cloud_in dc = {(const float *)fb[0].p, (const float *)fb[1].p, (const float *)fb[2].p,
+                         (const float *)fb[3].p, (const float *)fb[4].p, (const float *)fb[5].p};
+  rc = spz_amd_cloud_to_ply_rows_device(&dc, n, sh_dim, from_coord, (float *)rows.p, nullptr);
+  if (rc != SPZ_AMD_OK) return rc;
+  SPZ_HIP_TRY(hipMemcpy(h_rows, rows.p, row_bytes, hipMemcpyDeviceToHost));
+  return SPZ_AMD_OK;
+}
+
+}  // extern "C"

@@ -244,11 +244,19 @@ PYBIND11_MODULE(spz, m) {
   }, py::arg("gaussians"), py::arg("options"), "Raw (pre-gzip) stream of a cloud.");
 
   m.def("load_splat_from_ply",
-        [](const std::string &filename, const spz::UnpackOptions &o) { return spz::loadSplatFromPly(filename, o); },
+        [](const std::string &filename, const spz::UnpackOptions &o) {
+          spz::setLastDeviceStatus(SPZ_AMD_OK);
+          spz::GaussianCloud g = spz::loadSplatFromPly(filename, o);
+          if (g.numPoints == 0) raiseIfDeviceUnusable();
+          return g;
+        },
         py::arg("filename"), py::arg("options") = spz::UnpackOptions(), "Read GaussianCloud data from a *.ply* file.");
   m.def("save_splat_to_ply",
         [](const spz::GaussianCloud &g, const spz::PackOptions &o, const std::string &filename) {
-          return spz::saveSplatToPly(g, o, filename);
+          spz::setLastDeviceStatus(SPZ_AMD_OK);
+          const bool ok = spz::saveSplatToPly(g, o, filename);
+          if (!ok) raiseIfDeviceUnusable();
+          return ok;
         },
         py::arg("gaussians"), py::arg("options"), py::arg("filename"), "Write GaussianCloud data to a *.ply* file.");
 }

@@ -19,6 +19,9 @@ Files (all numpy .npz, loaded with allow_pickle=False):
                     (including streams whose smallest-three sum exceeds 1 -> NaN).
   legacy.npz        v2 and v1 streams (header patched / float16 positions) and the
                     reference's decode of them.
+  ply.npz           .ply files written by the reference's saveSplatToPly (from 0/4/7) and what its
+                    loadSplatFromPly returned for them (to 0/4/7); a hand-made .ply with comments,
+                    shuffled and extra properties.
   tables.npz        alpha/colour/scale/sh decode tables (256 entries each, taken from
                     the reference's decode of all byte values) and the 255 alpha-encode
                     thresholds (smallest float whose reference alpha byte is >= v).
@@ -328,7 +331,60 @@ def tables():
     np.savez_compressed(os.path.join(HERE, "tables.npz"), **out)
 
 
+def ply():
+    """saveSplatToPly / loadSplatFromPly (load-spz.cc:670-934) through real files."""
+    import tempfile
+    out = {}
+    tmp = tempfile.mkdtemp()
+    two = dict(positions=f32([0, 0.1, -0.2, 0.3, 0.4, 0.5]), scales=f32([-3, -2, -1.5, -1, 0, 0.1]),
+               rotations=f32([-0.5, 0.2, 1, -0.2, 0.1, -0.4, -0.3, 0.5]), alphas=f32([-1.0, 1.0]),
+               colors=f32([-1, 0, 1, -0.5, 0.5, 0.1]), sh=f32([i / 45.0 - 1.0 for i in range(90)]))
+    clouds_ = {"two_sh3": (two, 2, 3), "two_sh0": (dict(two, sh=np.zeros(0, np.float32)), 2, 0)}
+    for deg in (1, 2, 3):
+        n = 131  # two full 64-point tiles + a 3-point tail
+        c = make_cloud_numpy(n, deg, 4200 + deg)
+        c["positions"][:3] = f32([0.0, -0.0, 1e-40])
+        c["sh"][:2] = f32([-0.0, 0.0])
+        clouds_[f"n131_sh{deg}"] = (c, n, deg)
+    for name, (c, n, deg) in clouds_.items():
+        for k in FIELDS:
+            out[f"{name}_in_{k}"] = c[k]
+        for frm in (0, 4, 7):
+            f = os.path.join(tmp, f"{name}_{frm}.ply")
+            assert R.save_ply(c, n, deg, frm, f) == 0
+            out[f"{name}_file_from{frm}"] = np.frombuffer(open(f, "rb").read(), np.uint8)
+        f = os.path.join(tmp, f"{name}_0.ply")
+        for to in (0, 4, 7):
+            u = R.load_ply(f, n, deg, to)
+            assert u["num_points"] == n and u["sh_degree"] == deg
+            for k in FIELDS:
+                out[f"{name}_load_to{to}_{k}"] = u[k]
+    # a hand-made file: comments, blank lines, shuffled property order, extra properties, 2 sh
+    # coefficients per channel (not a whole degree: the reference reports degree 0 but keeps 6 floats)
+    props = ["opacity", "nx", "rot_3", "f_dc_2", "x", "extra_a", "scale_1", "f_rest_3", "rot_0", "y", "f_rest_0",
+             "f_dc_0", "scale_0", "f_rest_5", "z", "rot_1", "f_rest_1", "scale_2", "f_dc_1", "f_rest_4", "rot_2",
+             "f_rest_2", "extra_b"]
+    n = 70
+    rng = np.random.default_rng(9)
+    rows = rng.standard_normal((n, len(props))).astype(np.float32)
+    header = "ply\n  \ncomment made by make_golden.py\nformat binary_little_endian 1.0\n   comment indented\nelement vertex %d\n" % n
+    header += "".join(("\t" if i % 5 == 0 else "") + f"property float {p}\n" + ("\n" if i == 7 else "") for i, p in enumerate(props))
+    header += "end_header\n"
+    blob = header.encode() + rows.tobytes()
+    f = os.path.join(tmp, "odd.ply")
+    open(f, "wb").write(blob)
+    out["odd_file"] = np.frombuffer(blob, np.uint8)
+    for to in (0, 4, 7):
+        u = R.load_ply(f, n, 3, to)  # over-allocate; only sh_size floats of sh are written
+        assert u["num_points"] == n
+        out[f"odd_load_to{to}_info"] = np.int32([u["num_points"], u["sh_degree"], u["sh_size"]])
+        for k in FIELDS:
+            out[f"odd_load_to{to}_{k}"] = u[k][:u["sh_size"]] if k == "sh" else u[k]
+    np.savez_compressed(os.path.join(HERE, "ply.npz"), **out)
+
+
 if __name__ == "__main__":
+    ply()
     kat_small()
     clouds()
     quats()
