@@ -166,7 +166,7 @@ int spz_amd_convert_coordinates_host(float *h_positions, float *h_rotations, flo
  *      saveSplatToPly with its from->RDF flips (:858-893).  sh_dim is the number of sh
  *      coefficients per channel actually present (0..15; 0,3,8,15 for degrees 0..3). ------------ */
 typedef struct {
-  int32_t stride;      /* floats per row (= number of properties), 14 + 3*sh_dim .. 256 */
+  int32_t stride;      /* floats per row (= number of properties), 14 + 3*sh_dim .. 255 */
   int32_t sh_dim;      /* 0..15 */
   int32_t position[3]; /* x, y, z */
   int32_t scale[3];    /* scale_0, scale_1, scale_2 */

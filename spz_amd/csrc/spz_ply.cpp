@@ -143,8 +143,8 @@ GaussianCloud loadSplatFromPly(const std::string &filename, const UnpackOptions 
     return {};
   }
 
-  if (stride > 256) {
-    plyLog("[SPZ ERROR] spz_amd: %s: more than 256 properties per vertex are not supported", filename.c_str());
+  if (stride > 255) {
+    plyLog("[SPZ ERROR] spz_amd: %s: more than 255 properties per vertex are not supported", filename.c_str());
     return {};
   }
   spz_amd_ply_columns cols = {};

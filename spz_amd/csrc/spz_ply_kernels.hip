@@ -21,9 +21,12 @@ namespace {
 
 using namespace spz_amd_detail;
 
+#ifndef SPZ_PLY_LANE_IS_FIELD
+#define SPZ_PLY_LANE_IS_FIELD 1
+#endif
 constexpr int kPlyBlock = 256;
 constexpr int kPlyPoints = 64;  // Gaussians per tile
-constexpr int kMaxStride = 256; // 64 * 256 * 4 B = 64 KiB of LDS
+constexpr int kMaxStride = 255; // (64 * 255 + 45) * 4 B < 64 KiB of LDS
 
 struct PlyParams {
   const float *rows_in;
@@ -44,16 +47,23 @@ __device__ __forceinline__ void copy_to_lds(float *__restrict__ dst, const float
   for (uint32_t i = vec + threadIdx.x; i < count; i += kPlyBlock) dst[i] = src[i];
 }
 
-__global__ __launch_bounds__(kPlyBlock) void spz_ply_rows_to_cloud_kernel(const PlyParams p) {
-  extern __shared__ float tile[];  // [np][stride]
+__global__ __launch_bounds__(kPlyBlock) void spz_ply_rows_to_cloud_kernel(const PlyParams p, uint32_t inv_d_magic) {
+  extern __shared__ float tile[];  // [np][stride] rows, then d words: sh element e -> column | flip << 16
   const uint32_t stride = (uint32_t)p.cols.stride;
   const uint32_t shd = (uint32_t)p.cols.sh_dim;
+  const uint32_t d = shd * 3u;
   const unsigned long long first = (unsigned long long)blockIdx.x * kPlyPoints;
   const unsigned long long left = p.n - first;
   const uint32_t np = left < (unsigned long long)kPlyPoints ? (uint32_t)left : (uint32_t)kPlyPoints;
+  uint32_t *shtab = reinterpret_cast<uint32_t *>(tile + (size_t)kPlyPoints * stride);
+  const uint32_t tid = threadIdx.x;
+  if (tid < d) {
+    // cloud element e = coeff j, channel ch  <-  file column sh[j + ch * shDim]  (load-spz.cc:834-838)
+    const uint32_t j = tid / 3u, ch = tid - j * 3u;
+    shtab[tid] = (uint32_t)p.cols.sh[j + ch * shd] | (((p.flip_sh15 >> j) & 1u) << 16);
+  }
   copy_to_lds(tile, p.rows_in + first * stride, np * stride);
   __syncthreads();
-  const uint32_t tid = threadIdx.x;
   // positions: value * flipP[axis] (convertCoordinates multiplies every element, load-spz.cc:842)
   for (uint32_t i = tid; i < np * 3u; i += kPlyBlock) {
     const uint32_t pt = i / 3u, a = i - pt * 3u;
@@ -70,18 +80,51 @@ __global__ __launch_bounds__(kPlyBlock) void spz_ply_rows_to_cloud_kernel(const 
     p.out[2][first * 4u + i] = (c < 3u) ? mul_pm1(v, (p.flip_q >> c) & 1u) : v;  // w is never multiplied
   }
   for (uint32_t i = tid; i < np; i += kPlyBlock) p.out[3][first + i] = tile[i * stride + (uint32_t)p.cols.alpha];
-  // sh: file [channel][coeff] -> cloud [coeff][channel], times flipSh[coeff]
-  const uint32_t d = shd * 3u;
-  for (uint32_t i = tid; i < np * d; i += kPlyBlock) {
-    const uint32_t pt = i / d, e = i - pt * d;
-    const uint32_t j = e / 3u, ch = e - j * 3u;
-    const float v = tile[pt * stride + (uint32_t)p.cols.sh[j + ch * shd]];
-    p.out[5][first * d + i] = mul_pm1(v, (p.flip_sh15 >> j) & 1u);
+  // sh: file [channel][coeff] -> cloud [coeff][channel], times flipSh[coeff]; 76 % of the output bytes
+  if (d) {
+    auto element = [&](uint32_t i) -> float {
+      const uint32_t pt = __umulhi(i, inv_d_magic);  // i / d, exact for i < 2^16
+      const uint32_t w = shtab[i - pt * d];
+      return mul_pm1(tile[pt * stride + (w & 0xffffu)], w >> 16);
+    };
+    float *dst = p.out[5] + first * d;
+    const uint32_t total = np * d, vec = total & ~3u;
+    for (uint32_t i = tid * 4u; i < vec; i += kPlyBlock * 4u) {
+      F32x4 v;
+      v.x = element(i); v.y = element(i + 1); v.z = element(i + 2); v.w = element(i + 3);
+      *reinterpret_cast<F32x4 *>(dst + i) = v;
+    }
+    for (uint32_t i = vec + tid; i < total; i += kPlyBlock) dst[i] = element(i);
   }
 }
 
-__global__ __launch_bounds__(kPlyBlock) void spz_cloud_to_ply_rows_kernel(const PlyParams p) {
-  extern __shared__ float tile[];  // [pos 3P | scale 3P | rot 4P | alpha P | color 3P | sh dP]
+// Row field f -> where its value sits in the staged SoA tile: one packed word per field, built once
+// per block, so that the per-element work is a multiply-shift, two LDS reads and a sign flip instead
+// of divisions by the runtime row length.
+//   bits  0..15  LDS float offset of point 0's value
+//   bits 16..23  floats between consecutive points
+//   bits 24..25  0 = copy bits, 1 = times +1, 2 = times -1 (both multiply like the reference: NaNs are
+//                quieted), 3 = constant 0.0f (normals)
+__device__ __forceinline__ uint32_t ply_field_word(uint32_t f, uint32_t shd, uint32_t flip_p, uint32_t flip_q,
+                                                   uint32_t flip_sh15) {
+  const uint32_t P = kPlyPoints, d = shd * 3u;
+  auto word = [](uint32_t off, uint32_t step, uint32_t mode) { return off | (step << 16) | (mode << 24); };
+  if (f < 3u) return word(f, 3u, 1u + ((flip_p >> f) & 1u));                    // load-spz.cc:861-863
+  if (f < 6u) return word(0u, 0u, 3u);                                           // normals, :865
+  if (f < 9u) return word(11u * P + (f - 6u), 3u, 0u);                           // colours, :867-869
+  if (f < 9u + d) {                                                              // sh, :872-880
+    const uint32_t g = f - 9u, ch = g / shd, j = g - ch * shd;
+    return word(14u * P + j * 3u + ch, d, 1u + ((flip_sh15 >> j) & 1u));
+  }
+  const uint32_t t = f - 9u - d;
+  if (t == 0u) return word(10u * P, 1u, 0u);                                     // alpha, :882
+  if (t < 4u) return word(3u * P + (t - 1u), 3u, 0u);                            // scales, :884-886
+  if (t == 4u) return word(6u * P + 3u, 4u, 0u);                                 // rot w, :888
+  return word(6u * P + (t - 5u), 4u, 1u + ((flip_q >> (t - 5u)) & 1u));          // rot xyz, :889-891
+}
+
+__global__ __launch_bounds__(kPlyBlock) void spz_cloud_to_ply_rows_kernel(const PlyParams p, uint32_t inv_d_magic) {
+  extern __shared__ float tile[];  // [pos 3P | scale 3P | rot 4P | alpha P | color 3P | sh dP | field words D]
   const uint32_t shd = (uint32_t)p.cols.sh_dim;
   const uint32_t d = shd * 3u;
   const uint32_t D = 17u + d;  // floats per row
@@ -90,6 +133,8 @@ __global__ __launch_bounds__(kPlyBlock) void spz_cloud_to_ply_rows_kernel(const 
   const uint32_t np = left < (unsigned long long)kPlyPoints ? (uint32_t)left : (uint32_t)kPlyPoints;
   float *pos = tile, *scl = tile + 3 * kPlyPoints, *rot = tile + 6 * kPlyPoints, *alp = tile + 10 * kPlyPoints,
         *col = tile + 11 * kPlyPoints, *sh = tile + 14 * kPlyPoints;
+  uint32_t *words = reinterpret_cast<uint32_t *>(tile + (14u + d) * kPlyPoints);
+  if (threadIdx.x < D) words[threadIdx.x] = ply_field_word(threadIdx.x, shd, p.flip_p, p.flip_q, p.flip_sh15);
   copy_to_lds(pos, p.in[0] + first * 3u, np * 3u);
   copy_to_lds(scl, p.in[1] + first * 3u, np * 3u);
   copy_to_lds(rot, p.in[2] + first * 4u, np * 4u);
@@ -99,20 +144,31 @@ __global__ __launch_bounds__(kPlyBlock) void spz_cloud_to_ply_rows_kernel(const 
   __syncthreads();
   float *dst = p.rows_out + first * D;
   const uint32_t total = np * D;
-  auto element = [&](uint32_t i) -> float {
-    const uint32_t pt = i / D, f = i - pt * D;
-    if (f < 3u) return mul_pm1(pos[pt * 3u + f], (p.flip_p >> f) & 1u);  // load-spz.cc:861-863
-    if (f < 6u) return 0.0f;                                              // normals, :865
-    if (f < 9u) return col[pt * 3u + (f - 6u)];                           // :867-869
-    if (f < 9u + d) {                                                     // :872-880
-      const uint32_t g = f - 9u, ch = g / shd, j = g - ch * shd;
-      return mul_pm1(sh[(pt * shd + j) * 3u + ch], (p.flip_sh15 >> j) & 1u);
+#if SPZ_PLY_LANE_IS_FIELD
+  {
+    // lane = (point within the wave's group, field): the field word is loop-invariant per lane
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    const uint32_t ppw = 64u / D;  // points per wave per step (D <= 62)
+    const uint32_t sub = __umulhi(lane, inv_d_magic), f = lane - sub * D;
+    if (sub < ppw) {
+      const uint32_t w = words[f];
+      const uint32_t mode = w >> 24, off = w & 0xffffu, step = (w >> 16) & 0xffu;
+      for (uint32_t pt = wave * ppw + sub; pt < np; pt += (kPlyBlock / 64) * ppw) {
+        const uint32_t b = __float_as_uint(tile[off + pt * step]);
+        const uint32_t mul = is_nan_bits(b) ? (b | 0x00400000u) : (b ^ ((mode & 2u) << 30));
+        dst[pt * D + f] = __uint_as_float(mode == 0u ? b : (mode == 3u ? 0u : mul));
+      }
     }
-    const uint32_t t = f - 9u - d;
-    if (t == 0u) return alp[pt];                                          // :882
-    if (t < 4u) return scl[pt * 3u + (t - 1u)];                           // :884-886
-    if (t == 4u) return rot[pt * 4u + 3u];                                // :888 (w first)
-    return mul_pm1(rot[pt * 4u + (t - 5u)], (p.flip_q >> (t - 5u)) & 1u); // :889-891
+    return;
+  }
+#endif
+  auto element = [&](uint32_t i) -> float {
+    const uint32_t pt = __umulhi(i, inv_d_magic);  // i / D, exact for i < 2^16 (i < 64 * 62)
+    const uint32_t w = words[i - pt * D];
+    const uint32_t mode = w >> 24;
+    const uint32_t b = __float_as_uint(tile[(w & 0xffffu) + pt * ((w >> 16) & 0xffu)]);
+    const uint32_t mul = is_nan_bits(b) ? (b | 0x00400000u) : (b ^ ((mode & 2u) << 30));
+    return __uint_as_float(mode == 0u ? b : (mode == 3u ? 0u : mul));
   };
   const uint32_t vec = total & ~3u;
   for (uint32_t i = threadIdx.x * 4u; i < vec; i += kPlyBlock * 4u) {
@@ -193,9 +249,11 @@ int spz_amd_ply_rows_to_cloud_device(const float *d_rows, uint64_t n, const spz_
   p.n = n;
   p.cols = *cols;
   set_flips(&p, SPZ_AMD_RDF, to_coord);  // load-spz.cc:842
-  const size_t lds = (size_t)kPlyPoints * (size_t)cols->stride * sizeof(float);
+  const uint32_t d = 3u * (uint32_t)cols->sh_dim;
+  const size_t lds = ((size_t)kPlyPoints * (size_t)cols->stride + d) * sizeof(float);
+  const uint32_t magic = d ? (uint32_t)(0x100000000ull / d) + 1u : 0u;  // umulhi(i, magic) == i / d for i < 65536
   hipLaunchKernelGGL(spz_ply_rows_to_cloud_kernel, dim3(tiles(n)), dim3(kPlyBlock), lds,
-                     static_cast<hipStream_t>(hip_stream), p);
+                     static_cast<hipStream_t>(hip_stream), p, magic);
   SPZ_HIP_TRY(hipGetLastError());
   return SPZ_AMD_OK;
 }
@@ -219,9 +277,11 @@ int spz_amd_cloud_to_ply_rows_device(const spz_amd_cloud_in *cl, uint64_t n, int
   p.cols.sh_dim = sh_dim;
   p.cols.stride = 17 + 3 * sh_dim;
   set_flips(&p, from_coord, SPZ_AMD_RDF);  // load-spz.cc:856
-  const size_t lds = (size_t)kPlyPoints * (size_t)(14 + 3 * sh_dim) * sizeof(float);
+  const uint32_t D = 17u + 3u * (uint32_t)sh_dim;
+  const size_t lds = ((size_t)kPlyPoints * (size_t)(14 + 3 * sh_dim) + D) * sizeof(float);
+  const uint32_t magic = (uint32_t)(0x100000000ull / D) + 1u;  // umulhi(i, magic) == i / D for i < 65536
   hipLaunchKernelGGL(spz_cloud_to_ply_rows_kernel, dim3(tiles(n)), dim3(kPlyBlock), lds,
-                     static_cast<hipStream_t>(hip_stream), p);
+                     static_cast<hipStream_t>(hip_stream), p, magic);
   SPZ_HIP_TRY(hipGetLastError());
   return SPZ_AMD_OK;
 }

@@ -20,6 +20,8 @@ def main():
     deg, shd = 3, 15
     dev = torch.device("cuda:0")
     L = abi.load_library()
+    if os.environ.get('SPZ_PLY_LIB'):
+        L = abi.bind(C.CDLL(os.environ['SPZ_PLY_LIB']))
     cloud = make_cloud_torch(n, deg, 3, dev)
     out = {k: torch.empty_like(cloud[k]) for k in FIELDS}
     D = 17 + 3 * shd
