@@ -43,6 +43,9 @@ def parse():
     ap.add_argument("--from-coord", default="RDF")
     ap.add_argument("--to-coord", default="RDF")
     ap.add_argument("--no-collective", action="store_true", help="N>1: skip the gatherv (kernels only)")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl = RCCL over xGMI (the measured configuration); gloo = rehearsal of the N>1 code path "
+                         "on a box with fewer GPUs than ranks (host-staged exchange, ranks may share a GPU)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-points", type=int, default=0, help="0 = the whole per-GPU workload")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
@@ -113,13 +116,18 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
+    if args.backend == "gloo":
+        local_rank %= torch.cuda.device_count()   # rehearsal: ranks may share a card
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     distributed = world > 1
     if distributed:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         from datetime import timedelta
-        dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=300))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev, timeout=timedelta(seconds=300))
+        else:
+            dist.init_process_group("gloo", timeout=timedelta(seconds=300))
 
     n, deg, ver = args.points, args.sh_degree, args.version
     frm, to = COORD[args.from_coord], COORD[args.to_coord]
@@ -182,20 +190,22 @@ def main():
         src_buf = global_stream if rank == 0 else stream
         mine = torch.stack([src_buf[(g if rank == 0 else l):(g if rank == 0 else l) + nb].sum(dtype=torch.int64)
                             for g, l, nb in plan.fragments(rank)])
+        if args.backend != "nccl":
+            mine = mine.cpu()
         sums = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(sums, mine)
         if rank == 0:
             gather_verified = True
             for r in range(world):
                 got = torch.stack([global_stream[g:g + nb].sum(dtype=torch.int64) for g, _, nb in plan.fragments(r)])
-                gather_verified = gather_verified and bool(torch.equal(got, sums[r]))
+                gather_verified = gather_verified and bool(torch.equal(got.cpu(), sums[r].cpu()))
     t0 = time.perf_counter()
     for k in range(K):
         step(k, True)
     fence()
     elapsed = time.perf_counter() - t0
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -252,7 +262,8 @@ def main():
                 "parallelism": ("single GPU" if world == 1 else
                                 f"point-range shards x{world}" + (", one grouped RCCL gatherv of the byte stream to "
                                                                    "rank 0 per step, overlapped with decode"
-                                                                   if use_coll else ", no collective")),
+                                                                   if use_coll else ", no collective") +
+                                ("" if args.backend == "nccl" else " [REHEARSAL: gloo backend, host-staged, not a measurement]")),
             },
             "roofline": {
                 "bound": "hbm", "kernel": "spz_decode_kernel",

@@ -75,6 +75,25 @@ def plan_from_counts(counts, sh_degree, version=3):
     return ShardPlan(acc, sh_degree, version, len(counts), first, list(counts))
 
 
+def _needs_host_staging(t, group):
+    """gloo has no CUDA point-to-point: with that backend CUDA fragments go through host copies
+    (used to rehearse the N>1 path on a box without RCCL peers; RCCL sends device memory directly)."""
+    return t is not None and t.is_cuda and dist.get_backend(group) == "gloo"
+
+
+class _StagedWork:
+    """Work handle of a host-staged receive: wait() finishes the transfer, then copies to the device."""
+
+    def __init__(self, works, copies):
+        self.works, self.copies = works, copies
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+        for dst, src in self.copies:
+            dst.copy_(src)
+
+
 def gather_stream(local_stream, plan, rank, global_stream=None, dst=0, group=None, async_op=False):
     """Gatherv of the ranks' fragments into the root's global stream.
 
@@ -85,7 +104,8 @@ def gather_stream(local_stream, plan, rank, global_stream=None, dst=0, group=Non
                    final offsets, the header is written by the root.
     Returns the list of outstanding work handles when async_op, else waits for them.
     """
-    ops = []
+    ops, copies = [], []
+    staged = _needs_host_staging(global_stream if rank == dst else local_stream, group)
     if rank == dst:
         assert global_stream is not None and global_stream.numel() >= plan.layout.total_bytes
         for r in range(plan.world_size):
@@ -97,12 +117,20 @@ def gather_stream(local_stream, plan, rank, global_stream=None, dst=0, group=Non
                 continue
             for goff, _, nb in plan.fragments(r):
                 if nb:
-                    ops.append(dist.P2POp(dist.irecv, global_stream[goff:goff + nb], r, group))
+                    target = global_stream[goff:goff + nb]
+                    if staged:
+                        host = torch.empty(nb, dtype=torch.uint8)
+                        copies.append((target, host))
+                        target = host
+                    ops.append(dist.P2POp(dist.irecv, target, r, group))
     else:
         for _, loff, nb in plan.fragments(rank):
             if nb:
-                ops.append(dist.P2POp(dist.isend, local_stream[loff:loff + nb], dst, group))
+                src = local_stream[loff:loff + nb]
+                ops.append(dist.P2POp(dist.isend, src.cpu() if staged else src, dst, group))
     works = dist.batch_isend_irecv(ops) if ops else []
+    if staged and works:
+        works = [_StagedWork(works, copies)]
     if async_op:
         return works
     for w in works:
