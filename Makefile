@@ -4,6 +4,7 @@
 #   spz_amd/lib/libspz_amd.so    HIP kernels + C ABI            (hipcc, gfx950)
 #   spz_amd/lib/libspz_host.so   C++ drop-in layer spz::saveSpz/loadSpz + gzip (g++, zlib)
 #   spz_amd/spz*.so              Python module `spz` (pybind11) over the C++ layer
+#   spz_amd/bin/{ply_to_spz,spz_to_ply,spz_info}   the reference's three CLI tools over the C++ layer
 #   oracle/liboracle.so, oracle/_ref/libspz_ref.so   CPU checkers (tests only)
 
 ROOT    := $(dir $(abspath $(lastword $(MAKEFILE_LIST))))
@@ -23,11 +24,12 @@ CXXFLAGS := -O2 -std=c++17 -fPIC -ffp-contract=off -Wall -I$(INC)
 PYEXT   := $(shell $(PYTHON) -c "import sysconfig; print(sysconfig.get_config_var('EXT_SUFFIX'))")
 PYINC   := $(shell $(PYTHON) -c "import sysconfig, pybind11; print('-I' + sysconfig.get_paths()['include'] + ' -I' + pybind11.get_include())")
 
-all: device host python oracle
+all: device host python cli oracle
 
 device: $(LIBDIR)/libspz_amd.so
 host:   $(LIBDIR)/libspz_host.so
 python: $(ROOT)spz_amd/spz$(PYEXT)
+cli:    $(ROOT)spz_amd/bin/spz_tool
 
 $(LIBDIR)/libspz_amd.so: $(CSRC)/spz_kernels.hip $(CSRC)/spz_ply_kernels.hip $(CSRC)/spz_common.hpp $(INC)/spz_amd.h
 	mkdir -p $(LIBDIR)
@@ -41,6 +43,12 @@ $(ROOT)spz_amd/spz$(PYEXT): $(CSRC)/spz_py.cpp $(INC)/spz_amd_host.hpp $(LIBDIR)
 	$(CXX) $(CXXFLAGS) $(PYINC) -fvisibility=hidden -shared -o $@ $(CSRC)/spz_py.cpp \
 	    -L$(LIBDIR) -lspz_host -lspz_amd -Wl,-rpath,'$$ORIGIN/lib' -Wl,-rpath,/opt/rocm/lib
 
+$(ROOT)spz_amd/bin/spz_tool: $(CSRC)/spz_cli.cpp $(INC)/spz_amd_host.hpp $(LIBDIR)/libspz_host.so
+	mkdir -p $(ROOT)spz_amd/bin
+	$(CXX) $(CXXFLAGS) -o $@ $(CSRC)/spz_cli.cpp -L$(LIBDIR) -lspz_host -lspz_amd \
+	    -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
+	for t in ply_to_spz spz_to_ply spz_info; do ln -sf spz_tool $(ROOT)spz_amd/bin/$$t; done
+
 oracle:
 	$(MAKE) -C $(ROOT)oracle
 
@@ -51,7 +59,7 @@ asm: $(CSRC)/spz_kernels.hip
 	    -o $(ROOT)build/spz_kernels.s $(CSRC)/spz_kernels.hip
 
 clean:
-	rm -rf $(LIBDIR) $(ROOT)build $(ROOT)spz_amd/spz*.so
+	rm -rf $(LIBDIR) $(ROOT)build $(ROOT)spz_amd/spz*.so $(ROOT)spz_amd/bin
 	$(MAKE) -C $(ROOT)oracle clean
 
-.PHONY: all device host python oracle asm clean
+.PHONY: all device host python cli oracle asm clean

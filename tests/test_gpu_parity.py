@@ -478,3 +478,38 @@ def test_baseline_config1_ply_to_spz_60k(dev, reference, tmp_path):
     ref_back = reference.load_spz(want, n, deg, 0)
     for k in FIELDS:
         assert_bits_equal(getattr(back, k), ref_back[k], f"cfg1 load {k}")
+
+
+def test_cli_tools_round_trip(dev, reference, tmp_path):
+    """The reference's three CLI tools (cli_tools/src/*.cpp) rebuilt over the drop-in layer:
+    ply_to_spz produces the reference's .spz bytes, spz_to_ply the reference's .ply bytes,
+    spz_info the reference's report."""
+    import subprocess
+    from conftest import ROOT
+    from spz_amd.synth import make_cloud_numpy
+    import os
+    bin_dir = os.path.join(ROOT, "spz_amd", "bin")
+    n, deg = 4321, 2
+    c = make_cloud_numpy(n, deg, 77)
+    ply = str(tmp_path / "in.ply")
+    assert reference.save_ply(c, n, deg, 0, ply) == 0          # a .ply written by the reference
+    spz_out, ply_out = str(tmp_path / "out.spz"), str(tmp_path / "back.ply")
+    r = subprocess.run([os.path.join(bin_dir, "ply_to_spz"), ply, spz_out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    want = reference.save_spz(c, n, deg, False, 0)
+    assert open(spz_out, "rb").read() == want.tobytes()
+    r = subprocess.run([os.path.join(bin_dir, "spz_to_ply"), spz_out, ply_out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    back = reference.load_spz(want, n, deg, 0)
+    ref_ply = str(tmp_path / "ref_back.ply")
+    assert reference.save_ply(back, n, deg, 0, ref_ply) == 0
+    assert open(ply_out, "rb").read() == open(ref_ply, "rb").read()
+    r = subprocess.run([os.path.join(bin_dir, "spz_info"), spz_out], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and f"Number of points: {n}" in r.stdout and "Bounding box:" in r.stdout
+    p = back["positions"].reshape(-1, 3)
+    import io
+    want_lines = [f"  {a}: {lo:g} to {hi:g}" for a, lo, hi in zip("XYZ", p.min(0), p.max(0))]
+    for line in want_lines:
+        assert line in r.stdout, (line, r.stdout)
+    r = subprocess.run([os.path.join(bin_dir, "spz_info")], capture_output=True, text=True, timeout=60)
+    assert r.returncode == 1 and "Usage: spz_info" in r.stderr
