@@ -36,7 +36,7 @@ $(LIBDIR)/libspz_amd.so: $(CSRC)/spz_kernels.hip $(CSRC)/spz_ply_kernels.hip $(C
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(CSRC)/spz_kernels.hip $(CSRC)/spz_ply_kernels.hip
 
 $(LIBDIR)/libspz_host.so: $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp $(INC)/spz_amd_host.hpp $(INC)/spz_amd.h $(LIBDIR)/libspz_amd.so
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp -L$(LIBDIR) -lspz_amd -lz \
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp -L$(LIBDIR) -lspz_amd -lz -lpthread \
 	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 $(ROOT)spz_amd/spz$(PYEXT): $(CSRC)/spz_py.cpp $(INC)/spz_amd_host.hpp $(LIBDIR)/libspz_host.so

@@ -116,6 +116,10 @@ PackedGaussians deserializePackedGaussians(std::istream &in);
 // Extras of this implementation -------------------------------------------------------------
 // Inverse of compressGzipped (the reference keeps it file-local, load-spz.cc:141-182).
 bool decompressGzipped(const uint8_t *compressed, size_t size, std::vector<uint8_t> *out);
+// Opt-in multi-threaded gzip (pigz construction: independent deflate blocks in one gzip member).
+// Readable by every gzip reader including the reference's loadSpz, NOT byte-identical to
+// compressGzipped.  saveSpz uses it when the environment sets SPZ_AMD_GZIP_THREADS > 1.
+bool compressGzippedParallel(const uint8_t *data, size_t size, std::vector<uint8_t> *out, int threads);
 // Raw (pre-gzip) stream <-> cloud, i.e. saveSpz / loadSpz without the zlib step.
 bool packToStream(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream);
 GaussianCloud unpackFromStream(const uint8_t *stream, size_t size, const UnpackOptions &o);

@@ -9,6 +9,7 @@
 #include <zlib.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -17,6 +18,7 @@
 #include <fstream>
 #include <istream>
 #include <ostream>
+#include <thread>
 
 #include "spz_amd.h"
 
@@ -255,6 +257,72 @@ bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out
   return success;
 }
 
+// ---- opt-in parallel gzip ---------------------------------------------------------
+// zlib is ~87 % of an end-to-end saveSpz.  This is the pigz construction: the input is
+// cut into blocks, every block is deflated independently (raw deflate, primed with the last 32 KiB of
+// the previous block as dictionary, ended on a byte boundary with Z_SYNC_FLUSH; the last one with
+// Z_FINISH), and the pieces are concatenated inside ONE gzip member whose CRC-32 is folded together
+// with crc32_combine.  Any gzip reader, the reference's loadSpz included, reads the result; the bytes
+// differ from single-stream deflate, so it is used only when asked for (threads > 1).
+bool compressGzippedParallel(const uint8_t *data, size_t size, std::vector<uint8_t> *out, int threads) {
+  if (threads <= 1 || size < (1u << 20)) return compressGzipped(data, size, out);
+  constexpr size_t kBlock = size_t(1) << 20;  // 1 MiB of input per deflate job
+  constexpr size_t kDict = 32768;
+  const size_t nblocks = (size + kBlock - 1) / kBlock;
+  std::vector<std::vector<uint8_t>> pieces(nblocks);
+  std::vector<uLong> crcs(nblocks);
+  std::atomic<size_t> next{0};
+  std::atomic<bool> failed{false};
+  auto worker = [&]() {
+    std::vector<uint8_t> buf;
+    for (;;) {
+      const size_t b = next.fetch_add(1);
+      if (b >= nblocks || failed.load()) return;
+      const size_t off = b * kBlock, len = std::min(kBlock, size - off);
+      z_stream zs = {};
+      if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, -MAX_WBITS, 9, Z_DEFAULT_STRATEGY) != Z_OK) {
+        failed = true;
+        return;
+      }
+      if (b > 0) deflateSetDictionary(&zs, data + off - kDict, static_cast<uInt>(kDict));  // kBlock > kDict
+      buf.resize(deflateBound(&zs, static_cast<uLong>(len)) + 16);
+      zs.next_in = const_cast<Bytef *>(data + off);
+      zs.avail_in = static_cast<uInt>(len);
+      zs.next_out = buf.data();
+      zs.avail_out = static_cast<uInt>(buf.size());
+      const bool last = (b + 1 == nblocks);
+      const int rc = deflate(&zs, last ? Z_FINISH : Z_SYNC_FLUSH);
+      const bool ok = last ? (rc == Z_STREAM_END) : (rc == Z_OK && zs.avail_in == 0 && zs.avail_out > 0);
+      if (!ok) failed = true;
+      pieces[b].assign(buf.data(), buf.data() + (buf.size() - zs.avail_out));
+      deflateEnd(&zs);
+      crcs[b] = crc32(crc32(0L, Z_NULL, 0), data + off, static_cast<uInt>(len));
+    }
+  };
+  std::vector<std::thread> pool;
+  const int nt = static_cast<int>(std::min<size_t>(static_cast<size_t>(threads), nblocks));
+  for (int t = 0; t < nt; ++t) pool.emplace_back(worker);
+  for (auto &t : pool) t.join();
+  if (failed) return false;
+  size_t total = 10 + 8;
+  for (const auto &p : pieces) total += p.size();
+  out->clear();
+  out->reserve(total);
+  // the 10-byte gzip header zlib itself writes: magic, deflate, no flags, mtime 0, xfl 0, OS 3 (Unix)
+  const uint8_t header[10] = {0x1f, 0x8b, 0x08, 0x00, 0, 0, 0, 0, 0x00, 0x03};
+  out->insert(out->end(), header, header + 10);
+  uLong crc = crc32(0L, Z_NULL, 0);
+  for (size_t b = 0; b < nblocks; ++b) {
+    out->insert(out->end(), pieces[b].begin(), pieces[b].end());
+    crc = crc32_combine(crc, crcs[b], static_cast<z_off_t>(std::min(kBlock, size - b * kBlock)));
+  }
+  const uint32_t tail[2] = {static_cast<uint32_t>(crc), static_cast<uint32_t>(size & 0xffffffffu)};
+  for (uint32_t w : tail) {
+    for (int k = 0; k < 4; ++k) out->push_back(static_cast<uint8_t>(w >> (8 * k)));
+  }
+  return true;
+}
+
 bool decompressGzipped(const uint8_t *compressed, size_t size, std::vector<uint8_t> *out) {
   z_stream stream = {};
   // 16 | MAX_WBITS: gzip wrapper only (load-spz.cc:172).
@@ -439,7 +507,11 @@ GaussianCloud unpackGaussians(const PackedGaussians &packed, const UnpackOptions
 bool saveSpz(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *out) {
   std::vector<uint8_t> stream;
   if (!packToStream(g, o, &stream)) return false;
-  return compressGzipped(stream.data(), stream.size(), out);
+  // Default: the reference's single deflate stream (byte-identical files).  SPZ_AMD_GZIP_THREADS=n>1
+  // opts into the parallel container (same content, different bytes, n x faster).
+  const char *e = std::getenv("SPZ_AMD_GZIP_THREADS");
+  const int threads = e ? std::atoi(e) : 1;
+  return compressGzippedParallel(stream.data(), stream.size(), out, threads);
 }
 
 bool saveSpz(const GaussianCloud &g, const PackOptions &o, const std::string &filename) {

@@ -213,6 +213,17 @@ PYBIND11_MODULE(spz, m) {
     }
     return py::bytes(reinterpret_cast<const char *>(out.data()), out.size());
   }, "gzip wrapper of saveSpz (host zlib, parameters of load-spz.cc:190).");
+  m.def("_compress_gzipped_parallel", [](const py::bytes &data, int threads) {
+    const std::string in = data;
+    std::vector<uint8_t> out;
+    bool ok;
+    {
+      py::gil_scoped_release release;
+      ok = spz::compressGzippedParallel(reinterpret_cast<const uint8_t *>(in.data()), in.size(), &out, threads);
+    }
+    if (!ok) throw std::runtime_error("compressGzippedParallel failed");
+    return py::bytes(reinterpret_cast<const char *>(out.data()), out.size());
+  }, py::arg("data"), py::arg("threads"), "Opt-in multi-threaded gzip (one member, independent deflate blocks).");
   m.def("_decompress_gzipped", [](const py::bytes &data) -> py::object {
     const std::string in = data;
     std::vector<uint8_t> out;

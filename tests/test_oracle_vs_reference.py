@@ -73,3 +73,26 @@ def test_convert_coordinates(oracle, reference):
         b = reference.convert_coordinates(c["positions"], c["rotations"], c["sh"], n, deg, frm, to)
         for x, y, nm in zip(a, b, ("positions", "rotations", "sh")):
             assert_bits_equal(x, y, nm)
+
+
+def test_parallel_gzip_is_read_by_the_reference(reference):
+    """Opt-in multi-threaded gzip: not byte-identical to the reference's single
+    deflate stream, but the reference's own loadSpz must read it to the same floats."""
+    import gzip
+    import spz_amd.spz as spz
+    from spz_amd.synth import make_cloud_numpy
+    n, deg = 40_000, 3   # 2.6 MB stream -> three 1 MiB deflate blocks
+    c = make_cloud_numpy(n, deg, 99)
+    stream = reference.pack(c, n, deg, True, 6).tobytes()
+    par = spz._compress_gzipped_parallel(stream, 4)
+    one = spz._compress_gzipped(stream)
+    assert par != one and par[:10] == one[:10]
+    assert gzip.decompress(par) == stream and spz._decompress_gzipped(par) == stream
+    a = reference.load_spz(np.frombuffer(par, np.uint8), n, deg, 7)
+    b = reference.load_spz(np.frombuffer(one, np.uint8), n, deg, 7)
+    assert a["num_points"] == n
+    for k in FIELDS:
+        assert_bits_equal(a[k], b[k], k)
+    # threads <= 1 and small inputs fall back to the reference-identical single stream
+    assert spz._compress_gzipped_parallel(stream, 1) == one
+    assert spz._compress_gzipped_parallel(stream[:1000], 8) == spz._compress_gzipped(stream[:1000])
