@@ -29,7 +29,7 @@ all: device host python cli oracle
 device: $(LIBDIR)/libspz_amd.so
 host:   $(LIBDIR)/libspz_host.so
 python: $(ROOT)spz_amd/spz$(PYEXT)
-cli:    $(ROOT)spz_amd/bin/spz_tool
+cli:    $(ROOT)spz_amd/bin/spz_tool $(ROOT)spz_amd/bin/dropin_user_test
 
 $(LIBDIR)/libspz_amd.so: $(CSRC)/spz_kernels.hip $(CSRC)/spz_ply_kernels.hip $(CSRC)/spz_common.hpp $(INC)/spz_amd.h
 	mkdir -p $(LIBDIR)
@@ -48,6 +48,13 @@ $(ROOT)spz_amd/bin/spz_tool: $(CSRC)/spz_cli.cpp $(INC)/spz_amd_host.hpp $(LIBDI
 	$(CXX) $(CXXFLAGS) -o $@ $(CSRC)/spz_cli.cpp -L$(LIBDIR) -lspz_host -lspz_amd \
 	    -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
 	for t in ply_to_spz spz_to_ply spz_info; do ln -sf spz_tool $(ROOT)spz_amd/bin/$$t; done
+
+# A user program written against the reference's C++ API, built against the compat headers
+# (tests/cpp/dropin_user.cpp; its expected output comes from the same source built against the reference).
+$(ROOT)spz_amd/bin/dropin_user_test: $(ROOT)tests/cpp/dropin_user.cpp $(INC)/compat/load-spz.h $(LIBDIR)/libspz_host.so
+	mkdir -p $(ROOT)spz_amd/bin
+	$(CXX) $(CXXFLAGS) -I$(INC)/compat -o $@ $(ROOT)tests/cpp/dropin_user.cpp -L$(LIBDIR) -lspz_host -lspz_amd \
+	    -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
 
 oracle:
 	$(MAKE) -C $(ROOT)oracle

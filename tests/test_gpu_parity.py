@@ -513,3 +513,18 @@ def test_cli_tools_round_trip(dev, reference, tmp_path):
         assert line in r.stdout, (line, r.stdout)
     r = subprocess.run([os.path.join(bin_dir, "spz_info")], capture_output=True, text=True, timeout=60)
     assert r.returncode == 1 and "Usage: spz_info" in r.stderr
+
+
+def test_cpp_user_program_is_a_drop_in(dev):
+    """tests/cpp/dropin_user.cpp uses only the reference's public C++ API.  Built against the
+    reference it printed tests/golden/dropin_user_expected.txt (hashes of .spz bytes and decoded
+    floats); built against include/compat + libspz_host.so it must print the same lines."""
+    import os
+    import subprocess
+    from conftest import GOLDEN, ROOT
+    exe = os.path.join(ROOT, "spz_amd", "bin", "dropin_user_test")
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    got = [l for l in r.stdout.splitlines() if l.startswith("degree ")]
+    want = open(os.path.join(GOLDEN, "dropin_user_expected.txt")).read().splitlines()
+    assert got == want
