@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <cstddef>
 #include <cstdint>
 
 #include "spz_amd.h"
@@ -77,17 +78,39 @@ inline int current_device(int *device) {
 }
 
 
-// RAII device buffer for the *_host entry points.
-struct DevBuf {
-  void *p = nullptr;
-  ~DevBuf() {
-    if (p) (void)hipFree(p);
+// Device scratch for the *_host entry points.  Small requests are served from one cached
+// allocation per device (grow-only up to kWorkspaceKeep, guarded by a per-device mutex that is held
+// for the duration of the host call), so that the many tiny save/load calls of a typical session do
+// not pay seven hipMalloc/hipFree pairs each; larger requests get a temporary allocation.
+constexpr size_t kWorkspaceKeep = size_t(256) << 20;
+int workspace_acquire(int device, size_t bytes, void **base, bool *temporary);  // locks `device`
+void workspace_release(int device, void *base, bool temporary);                 // unlocks
+
+class Workspace {
+ public:
+  ~Workspace() {
+    if (open_) workspace_release(device_, base_, temporary_);
   }
-  int alloc(size_t bytes) {
-    if (bytes == 0) return SPZ_AMD_OK;
-    SPZ_HIP_TRY(hipMalloc(&p, bytes));
+  // Reserves `bytes` (already a sum of aligned() sizes) on the CURRENT device `device`.
+  int open(int device, size_t bytes) {
+    int rc = workspace_acquire(device, bytes, &base_, &temporary_);
+    if (rc != SPZ_AMD_OK) return rc;
+    device_ = device;
+    open_ = true;
     return SPZ_AMD_OK;
   }
+  static size_t aligned(size_t bytes) { return (bytes + 255) & ~size_t(255); }
+  void *take(size_t bytes) {
+    void *p = bytes ? static_cast<char *>(base_) + used_ : nullptr;
+    used_ += aligned(bytes);
+    return p;
+  }
+
+ private:
+  void *base_ = nullptr;
+  size_t used_ = 0;
+  int device_ = 0;
+  bool temporary_ = false, open_ = false;
 };
 
 struct DeviceGuard {

@@ -48,7 +48,47 @@
 
 namespace spz_amd_detail {
 thread_local int g_last_hip_error = 0;
+
+namespace {
+std::mutex g_ws_mutex[kMaxDevices];
+void *g_ws_ptr[kMaxDevices] = {};
+size_t g_ws_cap[kMaxDevices] = {};
+}  // namespace
+
+int workspace_acquire(int device, size_t bytes, void **base, bool *temporary) {
+  if (device < 0 || device >= kMaxDevices) return SPZ_AMD_ERR_INVALID_ARG;
+  g_ws_mutex[device].lock();
+  *base = nullptr;
+  *temporary = false;
+  if (bytes == 0) return SPZ_AMD_OK;
+  hipError_t e = hipSuccess;
+  if (bytes > kWorkspaceKeep) {
+    e = hipMalloc(base, bytes);
+    *temporary = true;
+  } else {
+    if (g_ws_cap[device] < bytes) {
+      if (g_ws_ptr[device]) (void)hipFree(g_ws_ptr[device]);
+      g_ws_ptr[device] = nullptr;
+      g_ws_cap[device] = 0;
+      size_t want = bytes < (size_t(1) << 20) ? (size_t(1) << 20) : bytes;
+      e = hipMalloc(&g_ws_ptr[device], want);
+      if (e == hipSuccess) g_ws_cap[device] = want;
+    }
+    *base = g_ws_ptr[device];
+  }
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    g_ws_mutex[device].unlock();
+    return SPZ_AMD_ERR_HIP;
+  }
+  return SPZ_AMD_OK;
 }
+
+void workspace_release(int device, void *base, bool temporary) {
+  if (temporary && base) (void)hipFree(base);
+  g_ws_mutex[device].unlock();
+}
+}  // namespace spz_amd_detail
 
 namespace {
 
@@ -1265,20 +1305,23 @@ int spz_amd_encode_host(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, in
   if (rc != SPZ_AMD_OK) return rc;
   const size_t cnt[6] = {n * 3, n * 3, n * 4, n, n * 3, n * (size_t)sd * 3};
   const float *src[6] = {h->positions, h->scales, h->rotations, h->alphas, h->colors, h->sh};
-  DevBuf fb[6], sb;
-  for (int i = 0; i < 6; ++i) {
-    rc = fb[i].alloc(cnt[i] * sizeof(float));
-    if (rc != SPZ_AMD_OK) return rc;
-    if (cnt[i]) SPZ_HIP_TRY(hipMemcpyAsync(fb[i].p, src[i], cnt[i] * sizeof(float), hipMemcpyHostToDevice, nullptr));
-  }
-  rc = sb.alloc(lay.total_bytes);
+  size_t total = Workspace::aligned(lay.total_bytes);
+  for (int i = 0; i < 6; ++i) total += Workspace::aligned(cnt[i] * sizeof(float));
+  Workspace ws;
+  rc = ws.open(device, total);
   if (rc != SPZ_AMD_OK) return rc;
-  spz_amd_cloud_in d = {(const float *)fb[0].p, (const float *)fb[1].p, (const float *)fb[2].p,
-                        (const float *)fb[3].p, (const float *)fb[4].p, (const float *)fb[5].p};
-  rc = encode_impl(&d, 0, n, n, sh_degree, antialiased, from_coord, version, 1, (uint8_t *)sb.p, lay.total_bytes,
+  void *fb[6];
+  for (int i = 0; i < 6; ++i) {
+    fb[i] = ws.take(cnt[i] * sizeof(float));
+    if (cnt[i]) SPZ_HIP_TRY(hipMemcpyAsync(fb[i], src[i], cnt[i] * sizeof(float), hipMemcpyHostToDevice, nullptr));
+  }
+  void *sb = ws.take(lay.total_bytes);
+  spz_amd_cloud_in d = {(const float *)fb[0], (const float *)fb[1], (const float *)fb[2],
+                        (const float *)fb[3], (const float *)fb[4], (const float *)fb[5]};
+  rc = encode_impl(&d, 0, n, n, sh_degree, antialiased, from_coord, version, 1, (uint8_t *)sb, lay.total_bytes,
                    nullptr);
   if (rc != SPZ_AMD_OK) return rc;
-  SPZ_HIP_TRY(hipMemcpy(h_stream, sb.p, lay.total_bytes, hipMemcpyDeviceToHost));
+  SPZ_HIP_TRY(hipMemcpy(h_stream, sb, lay.total_bytes, hipMemcpyDeviceToHost));
   return SPZ_AMD_OK;
 }
 
@@ -1302,20 +1345,20 @@ int spz_amd_decode_host(const uint8_t *h_stream, size_t size, int to_coord, cons
   if (rc != SPZ_AMD_OK) return rc;
   const size_t cnt[6] = {n * 3, n * 3, n * 4, n, n * 3, n * (size_t)sd * 3};
   float *dst[6] = {h->positions, h->scales, h->rotations, h->alphas, h->colors, h->sh};
-  DevBuf fb[6], sb;
-  rc = sb.alloc(lay.total_bytes);
+  size_t total = Workspace::aligned(lay.total_bytes);
+  for (int i = 0; i < 6; ++i) total += Workspace::aligned(cnt[i] * sizeof(float));
+  Workspace ws;
+  rc = ws.open(device, total);
   if (rc != SPZ_AMD_OK) return rc;
-  SPZ_HIP_TRY(hipMemcpyAsync(sb.p, h_stream, lay.total_bytes, hipMemcpyHostToDevice, nullptr));
-  for (int i = 0; i < 6; ++i) {
-    rc = fb[i].alloc(cnt[i] * sizeof(float));
-    if (rc != SPZ_AMD_OK) return rc;
-  }
-  spz_amd_cloud_out d = {(float *)fb[0].p, (float *)fb[1].p, (float *)fb[2].p,
-                         (float *)fb[3].p, (float *)fb[4].p, (float *)fb[5].p};
-  rc = decode_impl((const uint8_t *)sb.p, lay.total_bytes, &hdr, 0, n, to_coord, &d, nullptr);
+  void *sb = ws.take(lay.total_bytes);
+  SPZ_HIP_TRY(hipMemcpyAsync(sb, h_stream, lay.total_bytes, hipMemcpyHostToDevice, nullptr));
+  void *fb[6];
+  for (int i = 0; i < 6; ++i) fb[i] = ws.take(cnt[i] * sizeof(float));
+  spz_amd_cloud_out d = {(float *)fb[0], (float *)fb[1], (float *)fb[2], (float *)fb[3], (float *)fb[4], (float *)fb[5]};
+  rc = decode_impl((const uint8_t *)sb, lay.total_bytes, &hdr, 0, n, to_coord, &d, nullptr);
   if (rc != SPZ_AMD_OK) return rc;
   for (int i = 0; i < 6; ++i) {
-    if (cnt[i]) SPZ_HIP_TRY(hipMemcpyAsync(dst[i], fb[i].p, cnt[i] * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    if (cnt[i]) SPZ_HIP_TRY(hipMemcpyAsync(dst[i], fb[i], cnt[i] * sizeof(float), hipMemcpyDeviceToHost, nullptr));
   }
   SPZ_HIP_TRY(hipStreamSynchronize(nullptr));
   return SPZ_AMD_OK;
@@ -1331,18 +1374,22 @@ int spz_amd_convert_coordinates_host(float *h_positions, float *h_rotations, flo
   if (rc != SPZ_AMD_OK) return rc;
   const size_t cnt[3] = {n * 3, n * 4, n * (size_t)sd * 3};
   float *hp[3] = {h_positions, h_rotations, h_sh};
-  DevBuf b[3];
+  size_t total = 0;
+  for (int i = 0; i < 3; ++i) total += (hp[i] && cnt[i]) ? Workspace::aligned(cnt[i] * sizeof(float)) : 0;
+  Workspace ws;
+  rc = ws.open(device, total);
+  if (rc != SPZ_AMD_OK) return rc;
+  void *b[3] = {nullptr, nullptr, nullptr};
   for (int i = 0; i < 3; ++i) {
     if (!hp[i] || !cnt[i]) continue;
-    rc = b[i].alloc(cnt[i] * sizeof(float));
-    if (rc != SPZ_AMD_OK) return rc;
-    SPZ_HIP_TRY(hipMemcpyAsync(b[i].p, hp[i], cnt[i] * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    b[i] = ws.take(cnt[i] * sizeof(float));
+    SPZ_HIP_TRY(hipMemcpyAsync(b[i], hp[i], cnt[i] * sizeof(float), hipMemcpyHostToDevice, nullptr));
   }
-  rc = spz_amd_convert_coordinates_device((float *)b[0].p, (float *)b[1].p, (float *)b[2].p, n, sh_degree,
-                                          from_coord, to_coord, nullptr);
+  rc = spz_amd_convert_coordinates_device((float *)b[0], (float *)b[1], (float *)b[2], n, sh_degree, from_coord,
+                                          to_coord, nullptr);
   if (rc != SPZ_AMD_OK) return rc;
   for (int i = 0; i < 3; ++i) {
-    if (b[i].p) SPZ_HIP_TRY(hipMemcpyAsync(hp[i], b[i].p, cnt[i] * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    if (b[i]) SPZ_HIP_TRY(hipMemcpyAsync(hp[i], b[i], cnt[i] * sizeof(float), hipMemcpyDeviceToHost, nullptr));
   }
   SPZ_HIP_TRY(hipStreamSynchronize(nullptr));
   return SPZ_AMD_OK;

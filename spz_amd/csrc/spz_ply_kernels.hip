@@ -301,21 +301,21 @@ int spz_amd_ply_rows_to_cloud_host(const float *h_rows, uint64_t n, const spz_am
   if (rc != SPZ_AMD_OK) return rc;
   const size_t cnt[6] = {n * 3, n * 3, n * 4, n, n * 3, n * d};
   float *dst[6] = {h->positions, h->scales, h->rotations, h->alphas, h->colors, h->sh};
-  DevBuf rows, fb[6];
   const size_t row_bytes = n * (size_t)cols->stride * sizeof(float);
-  rc = rows.alloc(row_bytes);
+  size_t total = Workspace::aligned(row_bytes);
+  for (int i = 0; i < 6; ++i) total += Workspace::aligned(cnt[i] * sizeof(float));
+  Workspace ws;
+  rc = ws.open(device, total);
   if (rc != SPZ_AMD_OK) return rc;
-  SPZ_HIP_TRY(hipMemcpyAsync(rows.p, h_rows, row_bytes, hipMemcpyHostToDevice, nullptr));
-  for (int i = 0; i < 6; ++i) {
-    rc = fb[i].alloc(cnt[i] * sizeof(float));
-    if (rc != SPZ_AMD_OK) return rc;
-  }
-  spz_amd_cloud_out dc = {(float *)fb[0].p, (float *)fb[1].p, (float *)fb[2].p,
-                          (float *)fb[3].p, (float *)fb[4].p, (float *)fb[5].p};
-  rc = spz_amd_ply_rows_to_cloud_device((const float *)rows.p, n, cols, to_coord, &dc, nullptr);
+  void *rows = ws.take(row_bytes);
+  SPZ_HIP_TRY(hipMemcpyAsync(rows, h_rows, row_bytes, hipMemcpyHostToDevice, nullptr));
+  void *fb[6];
+  for (int i = 0; i < 6; ++i) fb[i] = ws.take(cnt[i] * sizeof(float));
+  spz_amd_cloud_out dc = {(float *)fb[0], (float *)fb[1], (float *)fb[2], (float *)fb[3], (float *)fb[4], (float *)fb[5]};
+  rc = spz_amd_ply_rows_to_cloud_device((const float *)rows, n, cols, to_coord, &dc, nullptr);
   if (rc != SPZ_AMD_OK) return rc;
   for (int i = 0; i < 6; ++i) {
-    if (cnt[i]) SPZ_HIP_TRY(hipMemcpyAsync(dst[i], fb[i].p, cnt[i] * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+    if (cnt[i]) SPZ_HIP_TRY(hipMemcpyAsync(dst[i], fb[i], cnt[i] * sizeof(float), hipMemcpyDeviceToHost, nullptr));
   }
   SPZ_HIP_TRY(hipStreamSynchronize(nullptr));
   return SPZ_AMD_OK;
@@ -334,20 +334,23 @@ int spz_amd_cloud_to_ply_rows_host(const spz_amd_cloud_in *h, uint64_t n, int sh
   if (rc != SPZ_AMD_OK) return rc;
   const size_t cnt[6] = {n * 3, n * 3, n * 4, n, n * 3, n * d};
   const float *src[6] = {h->positions, h->scales, h->rotations, h->alphas, h->colors, h->sh};
-  DevBuf rows, fb[6];
-  for (int i = 0; i < 6; ++i) {
-    rc = fb[i].alloc(cnt[i] * sizeof(float));
-    if (rc != SPZ_AMD_OK) return rc;
-    if (cnt[i]) SPZ_HIP_TRY(hipMemcpyAsync(fb[i].p, src[i], cnt[i] * sizeof(float), hipMemcpyHostToDevice, nullptr));
-  }
   const size_t row_bytes = n * (size_t)(17 + d) * sizeof(float);
-  rc = rows.alloc(row_bytes);
+  size_t total = Workspace::aligned(row_bytes);
+  for (int i = 0; i < 6; ++i) total += Workspace::aligned(cnt[i] * sizeof(float));
+  Workspace ws;
+  rc = ws.open(device, total);
   if (rc != SPZ_AMD_OK) return rc;
-  spz_amd_cloud_in dc = {(const float *)fb[0].p, (const float *)fb[1].p, (const float *)fb[2].p,
-                         (const float *)fb[3].p, (const float *)fb[4].p, (const float *)fb[5].p};
-  rc = spz_amd_cloud_to_ply_rows_device(&dc, n, sh_dim, from_coord, (float *)rows.p, nullptr);
+  void *fb[6];
+  for (int i = 0; i < 6; ++i) {
+    fb[i] = ws.take(cnt[i] * sizeof(float));
+    if (cnt[i]) SPZ_HIP_TRY(hipMemcpyAsync(fb[i], src[i], cnt[i] * sizeof(float), hipMemcpyHostToDevice, nullptr));
+  }
+  void *rows = ws.take(row_bytes);
+  spz_amd_cloud_in dc = {(const float *)fb[0], (const float *)fb[1], (const float *)fb[2],
+                         (const float *)fb[3], (const float *)fb[4], (const float *)fb[5]};
+  rc = spz_amd_cloud_to_ply_rows_device(&dc, n, sh_dim, from_coord, (float *)rows, nullptr);
   if (rc != SPZ_AMD_OK) return rc;
-  SPZ_HIP_TRY(hipMemcpy(h_rows, rows.p, row_bytes, hipMemcpyDeviceToHost));
+  SPZ_HIP_TRY(hipMemcpy(h_rows, rows, row_bytes, hipMemcpyDeviceToHost));
   return SPZ_AMD_OK;
 }
 

@@ -528,3 +528,46 @@ def test_cpp_user_program_is_a_drop_in(dev):
     got = [l for l in r.stdout.splitlines() if l.startswith("degree ")]
     want = open(os.path.join(GOLDEN, "dropin_user_expected.txt")).read().splitlines()
     assert got == want
+
+
+def test_host_entry_points_from_several_threads(dev, oracle):
+    """The host-pointer entry points share one cached device workspace per device behind a mutex:
+    concurrent callers (ctypes releases the GIL) must each get their own correct result, for sizes on
+    both sides of the cached / temporary-allocation split."""
+    import threading
+    from spz_amd import abi
+    from spz_amd.synth import make_cloud_numpy
+    L = abi.load_library()
+    jobs = [(2, 3, 1), (1000, 3, 2), (50_000, 1, 3), (1_200_000, 3, 4), (7, 0, 5), (300_000, 2, 6)]
+    clouds = {j: make_cloud_numpy(j[0], j[1], j[2]) for j in jobs}
+    want = {j: oracle.pack(clouds[j], j[0], j[1], False, 6) for j in jobs}
+    errors = []
+
+    def work(j, reps):
+        n, deg, _ = j
+        c = clouds[j]
+        p = abi.CloudPtrs(*[c[k].ctypes.data if c[k].size else None for k in FIELDS])
+        out = np.zeros(want[j].size, np.uint8)
+        back = {k: np.zeros_like(c[k]) for k in FIELDS}
+        q = abi.CloudPtrs(*[back[k].ctypes.data if back[k].size else None for k in FIELDS])
+        for _ in range(reps):
+            out[:] = 0
+            rc = L.spz_amd_encode_host(C.byref(p), n, deg, 0, 6, 3, out.ctypes.data, out.size, 0)
+            if rc != 0 or not np.array_equal(out, want[j]):
+                errors.append((j, "encode", rc))
+                return
+            rc = L.spz_amd_decode_host(out.ctypes.data, out.size, 6, C.byref(q), 0)
+            if rc != 0:
+                errors.append((j, "decode", rc))
+                return
+        rc2, w = oracle.unpack(want[j], 6)
+        for k in FIELDS:
+            if not np.array_equal(back[k].view(np.uint32), w[k].view(np.uint32)):
+                errors.append((j, "decode mismatch", k))
+
+    threads = [threading.Thread(target=work, args=(j, 6 if j[0] < 100_000 else 2)) for j in jobs]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors

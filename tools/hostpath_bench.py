@@ -43,6 +43,17 @@ def main():
         best = min(ts[1:])
         res[name] = {"first_s": round(ts[0], 4), "best_s": round(best, 4), "gaussians_per_s": n / best,
                      "GBps_over_pcie": (res["float_bytes"] + res["stream_bytes"]) / best / 1e9}
+    # latency of a tiny call (2 Gaussians): what a session of many small saves/loads pays per call
+    c2 = make_cloud_numpy(2, deg, 4)
+    lay2 = abi.stream_layout(2, deg, 3)
+    s2 = np.zeros(lay2.total_bytes, np.uint8)
+    p2 = abi.CloudPtrs(*[c2[k].ctypes.data for k in FIELDS])
+    for _ in range(20):
+        L.spz_amd_encode_host(C.byref(p2), 2, deg, 0, 6, 3, s2.ctypes.data, s2.size, 0)
+    t0 = time.perf_counter()
+    for _ in range(500):
+        L.spz_amd_encode_host(C.byref(p2), 2, deg, 0, 6, 3, s2.ctypes.data, s2.size, 0)
+    res["encode_host_2_points_us"] = round((time.perf_counter() - t0) / 500 * 1e6, 1)
     print(json.dumps(res))
 
 
