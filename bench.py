@@ -229,6 +229,26 @@ def main():
                                       stream[o_rot:e_rot].reshape(-1, rot_w)).any(dim=1).sum()),
         }
 
+    # BASELINE config 4, outside the timed region: the reference-shaped decode (decode to RUB, then a
+    # separate convertCoordinates pass, load-spz.cc:529) next to the fused decode used above.
+    two_pass = None
+    if world == 1 and to != 0:
+        e2 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+        reps = 5
+        D.decode(stream, hdr, 0, out=out)
+        D.convert_coordinates(out, n, deg, 4, to)
+        torch.cuda.synchronize()
+        e2[0].record()
+        for _ in range(reps):
+            D.decode(stream, hdr, 0, out=out)
+            D.convert_coordinates(out, n, deg, 4, to)
+        e2[1].record()
+        torch.cuda.synchronize()
+        two_pass = {"fused_decode_ms": dec_ms, "decode_then_flip_pass_ms": e2[0].elapsed_time(e2[1]) / reps,
+                    "algorithmic_bytes_two_pass": n * (algorithmic_bytes_per_point(deg, ver) + 2 * 4 * (3 + 4 + {0: 0, 1: 9, 2: 24, 3: 45}[deg]))}
+        run_decode()  # leave `out` as the fused decode produced it
+        torch.cuda.synchronize()
+
     if rank == 0:
         bpp = algorithmic_bytes_per_point(deg, ver)
         total_points = n * world
@@ -282,6 +302,7 @@ def main():
             "decode_gaussians_per_s_per_gpu": n / (dec_ms * 1e-3),
             "reencode_fixed_point": fixed_point,
             "gather_verified": gather_verified,
+            "config4_fused_vs_two_pass": two_pass,
         }
         if world == 1 and not args.no_cpu_baseline:
             def gpu_stream_fn(m):

@@ -1,7 +1,9 @@
 """spz_amd — MI355X-native SPZ (Gaussian-splat) pack/unpack hot path.
 
 Layout:
-  csrc/spz_kernels.hip  hand-written HIP kernels (gfx950) + the C ABI (include/spz_amd.h)
+  csrc/spz_kernels.hip  hand-written HIP pack/unpack/flip kernels (gfx950)
+  csrc/spz_ply_kernels.hip  .ply row <-> cloud shuffles
+  csrc/spz_abi.hip      the C ABI (include/spz_amd.h) over them
   csrc/spz_host.cpp     C++ drop-in layer: namespace spz saveSpz/loadSpz/... + host gzip
   csrc/spz_py.cpp       Python module `spz_amd.spz` with the reference nanobind shim's surface
   abi.py                ctypes binding of the C ABI

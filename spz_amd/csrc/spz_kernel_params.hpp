@@ -1,0 +1,127 @@
+// spz_kernel_params.hpp — what the host side (spz_abi.hip) and the kernels (spz_kernels.hip) share:
+// launch geometry, the section table passed by value to the fused kernels, table offsets, and the
+// kernel prototypes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "spz_amd.h"
+
+namespace spz_amd_detail {
+
+// ------------------------------------------------------------------------------------------
+// Geometry
+// ------------------------------------------------------------------------------------------
+// Launch geometry, per kernel.  A tile is BLOCK threads x UNROLL units.  The defaults are the
+// measured best on MI355X (profiles/README.md); the macros exist so that tools/tune.py can build
+// variants.  WC: a wave owns one contiguous span of its tile instead of UNROLL strided 1 KiB spans.
+// NTL / NTS: non-temporal loads / stores (every byte on this path is touched exactly once).
+#ifndef SPZ_DEC_BLOCK
+#define SPZ_DEC_BLOCK 256
+#endif
+#ifndef SPZ_DEC_UNROLL
+#define SPZ_DEC_UNROLL 4
+#endif
+#ifndef SPZ_DEC_WC
+#define SPZ_DEC_WC 0
+#endif
+#ifndef SPZ_DEC_NTL
+#define SPZ_DEC_NTL 0
+#endif
+#ifndef SPZ_DEC_NTS
+#define SPZ_DEC_NTS 0
+#endif
+#ifndef SPZ_ENC_BLOCK
+#define SPZ_ENC_BLOCK 256
+#endif
+#ifndef SPZ_ENC_UNROLL
+#define SPZ_ENC_UNROLL 4
+#endif
+#ifndef SPZ_ENC_WC
+#define SPZ_ENC_WC 1
+#endif
+#ifndef SPZ_ENC_NTL
+#define SPZ_ENC_NTL 1
+#endif
+#ifndef SPZ_ENC_NTS
+#define SPZ_ENC_NTS 0
+#endif
+// 0: one tile per block ("flat" grid, measured faster than a persistent grid-stride loop: a wave's
+// next loads would queue behind its own stores in the in-order vmcnt).  k > 0: at most k blocks per CU.
+// Optional second __launch_bounds__ argument (minimum waves per SIMD) for the encode kernel.
+#ifndef SPZ_ENC_MIN_WAVES
+#define SPZ_ENC_MIN_WAVES 1
+#endif
+#ifndef SPZ_BLOCKS_PER_CU
+#define SPZ_BLOCKS_PER_CU 0
+#endif
+
+template <int BLOCK_, int UNROLL_, bool WC_, bool NTL_, bool NTS_>
+struct Geom {
+  static constexpr int kBlock = BLOCK_;
+  static constexpr int kUnroll = UNROLL_;
+  static constexpr int kTileUnits = BLOCK_ * UNROLL_;  // one unit = 4 float elements
+  static constexpr bool kWaveContig = WC_;
+  static constexpr bool kNtLoad = NTL_;
+  static constexpr bool kNtStore = NTS_;
+  // Unit handled by thread `tid` in round `r` of a tile.
+  __device__ static __forceinline__ uint32_t local_unit(int r, uint32_t tid) {
+    if constexpr (WC_) return ((tid >> 6) * (uint32_t)UNROLL_ + (uint32_t)r) * 64u + (tid & 63u);
+    else return (uint32_t)(r * BLOCK_) + tid;
+  }
+};
+using DecGeom = Geom<SPZ_DEC_BLOCK, SPZ_DEC_UNROLL, SPZ_DEC_WC != 0, SPZ_DEC_NTL != 0, SPZ_DEC_NTS != 0>;
+using EncGeom = Geom<SPZ_ENC_BLOCK, SPZ_ENC_UNROLL, SPZ_ENC_WC != 0, SPZ_ENC_NTL != 0, SPZ_ENC_NTS != 0>;
+using FlipGeom = Geom<256, 4, false, false, false>;
+constexpr int kMaxBlocksPerCU = SPZ_BLOCKS_PER_CU;
+
+enum SecKind : uint32_t {
+  KIND_POS24 = 0,  // 24-bit fixed point, 12 bytes per unit
+  KIND_POS16,      // legacy float16 positions (decode only), 8 bytes per unit
+  KIND_ALPHA,      // 4 bytes per unit, table / threshold search
+  KIND_COLOR,      // 4 bytes per unit
+  KIND_SCALE,      // 4 bytes per unit
+  KIND_ROT_S3,     // smallest-three quaternion: 1 point = 4 floats <-> 4 bytes
+  KIND_ROT_F3,     // first-three quaternion:    1 point = 4 floats <-> 3 bytes
+  KIND_SH,         // 4 bytes per unit, flip + bucket depend on (element % D)
+  KIND_FLIP_POS,   // in-place convertCoordinates passes (floats only)
+  KIND_FLIP_ROT,
+  KIND_FLIP_SH,
+};
+
+struct SecDesc {
+  uint8_t *bytes;              // stream side (encode writes, decode reads); unused by flip kinds
+  float *floats;               // float side
+  unsigned long long n_elems;  // float elements in this section
+  unsigned long long n_units;  // ceil(n_elems / 4)
+  uint32_t tile_begin;         // first tile of this section in the fused grid
+  uint32_t kind;
+};
+
+struct KParams {
+  SecDesc sec[SPZ_AMD_NUM_SECTIONS];
+  uint32_t n_sec;
+  uint32_t total_tiles;
+  uint32_t flip_p;                // bit a set: axis a is negated
+  uint32_t flip_q;                // bit i set: quaternion component i (x,y,z) is negated
+  unsigned long long sh_mask_ext; // bit j: element j of a point's D sh floats is negated; bits D..D+2 repeat 0..2
+  uint32_t sh_d;                  // 0, 9, 24, 45
+  float pos_scale;                // decode: 1 / (1 << fractionalBits)
+  const float *tables;            // device tables, see kTable* below
+  uint8_t *header_dst;            // encode: where the 16 header bytes go (nullptr: none)
+  uint32_t header_words[4];
+};
+
+constexpr int kTableAlphaDec = 0;    // 256 floats
+constexpr int kTableColorDec = 256;  // 256 floats
+constexpr int kTableAlphaThr = 512;  // 255 floats + 1 NaN pad
+constexpr int kTableFloats = 768;
+
+// The three kernels (spz_kernels.hip).
+__global__ void spz_decode_kernel(const KParams p);
+__global__ void spz_encode_kernel(const KParams p);
+__global__ void spz_flip_kernel(const KParams p);
+
+}  // namespace spz_amd_detail
