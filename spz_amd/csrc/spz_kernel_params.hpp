@@ -54,6 +54,11 @@ namespace spz_amd_detail {
 #ifndef SPZ_ENC_MIN_WAVES
 #define SPZ_ENC_MIN_WAVES 1
 #endif
+// 1: a scheduling barrier after every unit of an encode tile, so the compiler does not interleave the
+// arithmetic of the four units (fewer live registers, more waves per SIMD).
+#ifndef SPZ_ENC_SCHED_BARRIER
+#define SPZ_ENC_SCHED_BARRIER 1
+#endif
 #ifndef SPZ_BLOCKS_PER_CU
 #define SPZ_BLOCKS_PER_CU 0
 #endif

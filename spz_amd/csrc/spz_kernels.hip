@@ -605,6 +605,9 @@ __device__ __forceinline__ void encode_tile(const SecDesc &s, uint32_t tile_loca
     for (int r = 0; r < G::kUnroll; ++r) {
       const uint32_t local = G::local_unit(r, tid);
       store_raw<KIND, G>(dst, base + local, encode_unit<KIND, D>(v[r], unit_phase<KIND, D>(pb, local), c));
+#if SPZ_ENC_SCHED_BARRIER
+      __builtin_amdgcn_sched_barrier(0);
+#endif
     }
   } else {
 #pragma unroll

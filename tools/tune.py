@@ -27,28 +27,20 @@ def D(block=256, unroll=4, wc=0, ntl=0, nts=0):
 # Encode and decode geometries are independent; library i carries encode config i and decode config i
 # (the two columns of a row are unrelated experiments).  All are "flat" (one tile per block).
 ENC = {
-    "b256u4_wc_ntl":        E(wc=1, ntl=1),
-    "b256u4_wc_ntl_w6":     dict(E(wc=1, ntl=1), SPZ_ENC_MIN_WAVES=6),
-    "b256u4_wc_ntl_w8":     dict(E(wc=1, ntl=1), SPZ_ENC_MIN_WAVES=8),
-    "b256u2_wc_ntl":        E(unroll=2, wc=1, ntl=1),
-    "b256u2_wc_ntl_w8":     dict(E(unroll=2, wc=1, ntl=1), SPZ_ENC_MIN_WAVES=8),
-    "b256u4_ntl":           E(ntl=1),
-    "b256u8_wc_ntl":        E(unroll=8, wc=1, ntl=1),
-    "b128u4_wc_ntl":        E(block=128, wc=1, ntl=1),
-    "b512u4_wc_ntl":        E(block=512, wc=1, ntl=1),
-    "b256u3_wc_ntl":        E(unroll=3, wc=1, ntl=1),
+    "b256u4_wc_ntl":         E(wc=1, ntl=1),
+    "sb":                    dict(E(wc=1, ntl=1), SPZ_ENC_SCHED_BARRIER=1),
+    "sb_w7":                 dict(E(wc=1, ntl=1), SPZ_ENC_SCHED_BARRIER=1, SPZ_ENC_MIN_WAVES=7),
+    "sb_w8":                 dict(E(wc=1, ntl=1), SPZ_ENC_SCHED_BARRIER=1, SPZ_ENC_MIN_WAVES=8),
+    "sb_u8":                 dict(E(unroll=8, wc=1, ntl=1), SPZ_ENC_SCHED_BARRIER=1),
+    "sb_b512":               dict(E(block=512, wc=1, ntl=1), SPZ_ENC_SCHED_BARRIER=1),
 }
 DEC = {
     "b256u4":          D(),
-    "b256u4_wc":       D(wc=1),
-    "b256u2":          D(unroll=2),
-    "b256u3":          D(unroll=3),
-    "b256u6":          D(unroll=6),
-    "b256u8":          D(unroll=8),
-    "b128u4":          D(block=128),
-    "b512u4":          D(block=512),
-    "b256u4_nts":      D(nts=1),
-    "b256u4_ntl":      D(ntl=1),
+    "b256u4_b":        D(),
+    "b256u4_c":        D(),
+    "b256u4_d":        D(),
+    "b256u4_e":        D(),
+    "b256u4_f":        D(),
 }
 VARIANTS = {}
 for _i, (_e, _d) in enumerate(zip(ENC.items(), DEC.items())):
