@@ -98,6 +98,11 @@ int spz_amd_device_count(void);
 /* hipError_t value of the last failing HIP call on this thread (0 if none). */
 int spz_amd_last_hip_error(void);
 
+/* Frees what the library keeps on the devices between calls (decode tables / thresholds, the cached
+ * workspace of the *_host entry points).  Optional: everything is re-created on demand.  Must not
+ * run concurrently with other calls into the library. */
+int spz_amd_release_device_memory(void);
+
 /* ---- stream geometry: replaces the size arithmetic spread over packGaussians
  *      (load-spz.cc:273-278), serializePackedGaussians (:540-545) and
  *      deserializePackedGaussians (:578-590).  Pure host function. ------------------------ */

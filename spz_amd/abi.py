@@ -31,6 +31,7 @@ REFERENCE_MAX_POINTS = 10_000_000
 # Every symbol include/spz_amd.h declares (tests check the library exports all of them).
 EXPORTS = (
     "spz_amd_abi_version", "spz_amd_status_string", "spz_amd_device_count", "spz_amd_last_hip_error",
+    "spz_amd_release_device_memory",
     "spz_amd_stream_layout", "spz_amd_write_header", "spz_amd_peek_header", "spz_amd_peek_header_ex",
     "spz_amd_encode_device", "spz_amd_decode_device", "spz_amd_encode_shard_device",
     "spz_amd_decode_shard_device", "spz_amd_convert_coordinates_device", "spz_amd_encode_host",
@@ -99,6 +100,7 @@ def bind(L):
     L.spz_amd_status_string.argtypes = [i32]
     L.spz_amd_device_count.restype = i32
     L.spz_amd_last_hip_error.restype = i32
+    L.spz_amd_release_device_memory.restype = i32
     L.spz_amd_stream_layout.restype = i32
     L.spz_amd_stream_layout.argtypes = [u64, i32, i32, C.POINTER(Layout)]
     L.spz_amd_write_header.restype = i32

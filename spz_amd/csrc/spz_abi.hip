@@ -55,6 +55,20 @@ void workspace_release(int device, void *base, bool temporary) {
   if (temporary && base) (void)hipFree(base);
   g_ws_mutex[device].unlock();
 }
+
+void workspace_free_all() {
+  int prev = 0;
+  if (hipGetDevice(&prev) != hipSuccess) return;
+  for (int d = 0; d < kMaxDevices; ++d) {
+    std::lock_guard<std::mutex> lock(g_ws_mutex[d]);
+    if (g_ws_ptr[d]) {
+      if (hipSetDevice(d) == hipSuccess) (void)hipFree(g_ws_ptr[d]);
+      g_ws_ptr[d] = nullptr;
+      g_ws_cap[d] = 0;
+    }
+  }
+  (void)hipSetDevice(prev);
+}
 }  // namespace spz_amd_detail
 
 namespace {
@@ -359,6 +373,25 @@ int spz_amd_device_count(void) {
 }
 
 int spz_amd_last_hip_error(void) { return g_last_hip_error; }
+
+int spz_amd_release_device_memory(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return SPZ_AMD_OK;  // nothing can have been allocated
+  workspace_free_all();
+  int prev = 0;
+  SPZ_HIP_TRY(hipGetDevice(&prev));
+  {
+    std::lock_guard<std::mutex> lock(g_tables_mutex);
+    for (int d = 0; d < kMaxDevices && d < n; ++d) {
+      if (g_tables.dev[d]) {
+        if (hipSetDevice(d) == hipSuccess) (void)hipFree(g_tables.dev[d]);
+        g_tables.dev[d] = nullptr;
+      }
+    }
+  }
+  SPZ_HIP_TRY(hipSetDevice(prev));
+  return SPZ_AMD_OK;
+}
 
 int spz_amd_stream_layout(uint64_t num_points, int sh_degree, int version, spz_amd_layout *out) {
   return layout_impl(num_points, sh_degree, version, out);

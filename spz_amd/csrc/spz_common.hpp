@@ -85,6 +85,7 @@ inline int current_device(int *device) {
 constexpr size_t kWorkspaceKeep = size_t(256) << 20;
 int workspace_acquire(int device, size_t bytes, void **base, bool *temporary);  // locks `device`
 void workspace_release(int device, void *base, bool temporary);                 // unlocks
+void workspace_free_all();                                                      // drops the cached allocations
 
 class Workspace {
  public:

@@ -571,3 +571,61 @@ def test_host_entry_points_from_several_threads(dev, oracle):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_config5_80m_stream_geometry_on_one_gpu(dev, oracle):
+    """BASELINE configs[4] at full scale on ONE card: eight 10 M-point SH3 shards written at their
+    global offsets of an 80 M-point stream (5.2 GB: offsets beyond 2^32 exercise the 64-bit address
+    arithmetic).  The reference cannot read an 80 M header (load-spz.cc:549,561), so parity is per
+    shard: every fragment of the global stream equals the stand-alone encode of that shard (whose
+    arithmetic the other tests pin to the reference), a window of the LAST shard equals the oracle,
+    and decoding the last shard from the global stream equals decoding it stand-alone."""
+    import torch
+    from spz_amd import abi, device as D, shard
+    from spz_amd.synth import make_cloud_torch, floats_per_point
+    world, n, deg = 8, 10_000_000, 3
+    plan = shard.plan_from_counts([n] * world, deg)
+    assert plan.num_points == 80_000_000 and plan.layout.total_bytes == 16 + 65 * 80_000_000 > 2 ** 32
+    g = torch.zeros(plan.layout.total_bytes, dtype=torch.uint8, device=dev)
+    local = torch.empty(plan.local_layout(0).total_bytes, dtype=torch.uint8, device=dev)
+    ghdr = D.make_header(plan.num_points, deg)
+    for r in range(world):
+        t = make_cloud_torch(n, deg, 50 + r, dev)   # SURVEY §8d: seeds 50..57
+        D.encode_shard(t, plan.first[r], n, plan.num_points, deg, g, from_coord=abi.RDF, write_header=(r == 0))
+        D.encode(t, n, deg, False, abi.RDF, out=local)
+        torch.cuda.synchronize()
+        for goff, loff, nb in plan.fragments(r):
+            assert torch.equal(g[goff:goff + nb], local[loff:loff + nb]), (r, goff)
+        if r == world - 1:
+            a, w = 9_000_001, 32_768
+            sub = {k: t[k][a * floats_per_point(k, deg):(a + w) * floats_per_point(k, deg)].cpu().numpy() for k in FIELDS}
+            want = oracle.pack(sub, w, deg, False, abi.RDF)
+            lay_w = abi.stream_layout(w, deg, 3)
+            for sec, (goff, _, _) in enumerate(plan.fragments(r)):
+                bpp = plan.layout.bytes_per_point[sec]
+                got = g[goff + a * bpp:goff + (a + w) * bpp].cpu().numpy()
+                assert_bytes_equal(got, want[lay_w.offset[sec]:lay_w.offset[sec] + w * bpp], f"last shard, section {sec}")
+            alone = D.decode(local, D.make_header(n, deg), abi.LUF)
+            from_global = D.decode_shard(g, ghdr, plan.first[r], n, abi.LUF)
+            torch.cuda.synchronize()
+            for k in FIELDS:
+                assert torch.equal(alone[k].view(torch.int32), from_global[k].view(torch.int32)), k
+            del alone, from_global
+        del t
+    rc, h = abi.peek_header(g[:16].cpu().numpy().tobytes() + b"", max_points=0)
+    assert rc == abi.ERR_SHORT_STREAM  # 16 bytes only: header fields parse, size check fails as designed
+    hdr_bytes = g[:16].cpu().numpy().tobytes()
+    assert hdr_bytes == abi.write_header(3, 80_000_000, 3, 12, False)
+
+
+def test_release_device_memory_and_reuse(dev, oracle):
+    from spz_amd import abi, device as D
+    from spz_amd.synth import make_cloud_numpy
+    L = abi.load_library()
+    n, deg = 1000, 2
+    c = make_cloud_numpy(n, deg, 5)
+    want = oracle.pack(c, n, deg, False, 6)
+    assert_bytes_equal(gpu_encode(c, n, deg, False, 6, dev), want)
+    assert L.spz_amd_release_device_memory() == 0
+    assert L.spz_amd_release_device_memory() == 0          # idempotent
+    assert_bytes_equal(gpu_encode(c, n, deg, False, 6, dev), want)   # tables are rebuilt on demand
