@@ -133,16 +133,21 @@ def main():
     frm, to = COORD[args.from_coord], COORD[args.to_coord]
     cloud = make_cloud_torch(n, deg, 3 + 47 * rank, dev)           # seeds 3, 50, 97, ... per rank
     lay = abi.stream_layout(n, deg, ver)
-    stream = torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev)
     out = D.alloc_cloud(n, deg, dev)
     hdr = D.make_header(n, deg, ver)
 
     use_coll = distributed and not args.no_collective
     plan = shard.plan_from_counts([n] * world, deg, ver) if distributed else None
-    global_stream = None
+    # With the collective, stream buffers are double-buffered so that the gatherv of step k (link-bound,
+    # on RCCL's own stream) overlaps the encode and decode kernels of steps k+1 and k+2.
+    nbuf = 2 if use_coll else 1
+    streams = [torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    stream = streams[0]
+    global_streams = [None] * nbuf
     if use_coll and rank == 0:
-        global_stream = torch.empty(plan.layout.total_bytes, dtype=torch.uint8, device=dev)
-        shard.write_global_header(global_stream, plan)
+        for b in range(nbuf):
+            global_streams[b] = torch.empty(plan.layout.total_bytes, dtype=torch.uint8, device=dev)
+            shard.write_global_header(global_streams[b], plan)
 
     K, W = args.steps, args.warmup
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
@@ -150,27 +155,40 @@ def main():
     if use_coll and rank == 0:
         # the root encodes straight into (and decodes straight from) its slot of the global stream
         ghdr = D.make_header(plan.num_points, deg, ver)
-        run_encode = lambda: D.encode_shard(cloud, plan.first[0], n, plan.num_points, deg, global_stream,
-                                            from_coord=frm, version=ver, write_header=True)
-        run_decode = lambda: D.decode_shard(global_stream, ghdr, plan.first[0], n, to, out=out)
+        run_encode = lambda b: D.encode_shard(cloud, plan.first[0], n, plan.num_points, deg, global_streams[b],
+                                              from_coord=frm, version=ver, write_header=True)
+        run_decode = lambda b: D.decode_shard(global_streams[b], ghdr, plan.first[0], n, to, out=out)
     else:
-        run_encode = lambda: D.encode(cloud, n, deg, False, frm, ver, out=stream)
-        run_decode = lambda: D.decode(stream, hdr, to, out=out)
+        run_encode = lambda b: D.encode(cloud, n, deg, False, frm, ver, out=streams[b])
+        run_decode = lambda b: D.decode(streams[b], hdr, to, out=out)
+
+    pending = [[] for _ in range(nbuf)]
+    counter = [0]
+
+    def drain(b):
+        for w in pending[b]:
+            w.wait()       # RCCL: the current stream waits for the gatherv that last used buffer b
+        pending[b] = []
 
     def step(k, timed):
+        b = counter[0] % nbuf
+        counter[0] += 1
+        drain(b)
         e = ev[k] if timed else None
         if e: e[0].record()
-        run_encode()
+        run_encode(b)
         if e: e[1].record()
-        works = shard.gather_stream(None if rank == 0 else stream, plan, rank, global_stream, async_op=True) \
-            if use_coll else []
+        if use_coll:
+            pending[b] = shard.gather_stream(None if rank == 0 else streams[b], plan, rank, global_streams[b],
+                                             async_op=True)
         if e: e[2].record()
-        run_decode()
+        run_decode(b)
         if e: e[3].record()
-        for w in works:
-            w.wait()
+        return b
 
     def fence():
+        for b in range(nbuf):
+            drain(b)
         torch.cuda.synchronize()
         if distributed:
             dist.barrier()
@@ -184,10 +202,10 @@ def main():
     # rank encoded (per-section byte sums, exchanged with one small all_gather outside the timed region).
     gather_verified = None
     if use_coll:
-        if W == 0:
-            step(0, False)
-            fence()
-        src_buf = global_stream if rank == 0 else stream
+        last = step(0, False)     # one more untimed step whose buffers are then checked
+        fence()
+        global_stream = global_streams[last]
+        src_buf = global_stream if rank == 0 else streams[last]
         mine = torch.stack([src_buf[(g if rank == 0 else l):(g if rank == 0 else l) + nb].sum(dtype=torch.int64)
                             for g, l, nb in plan.fragments(rank)])
         if args.backend != "nccl":
@@ -217,6 +235,7 @@ def main():
     if frm == to and not (use_coll and rank == 0):
         # quantisation is idempotent except for smallest-three near-ties (format property): every
         # section but the rotations must re-encode to identical bytes
+        stream = streams[(counter[0] - 1) % nbuf]
         s2 = D.encode(out, n, deg, False, to, ver)
         torch.cuda.synchronize()
         o_rot = lay.offset[abi.SEC_ROTATIONS]
@@ -235,6 +254,7 @@ def main():
     if world == 1 and to != 0:
         e2 = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
         reps = 5
+        stream = streams[(counter[0] - 1) % nbuf]
         D.decode(stream, hdr, 0, out=out)
         D.convert_coordinates(out, n, deg, 4, to)
         torch.cuda.synchronize()
@@ -246,7 +266,7 @@ def main():
         torch.cuda.synchronize()
         two_pass = {"fused_decode_ms": dec_ms, "decode_then_flip_pass_ms": e2[0].elapsed_time(e2[1]) / reps,
                     "algorithmic_bytes_two_pass": n * (algorithmic_bytes_per_point(deg, ver) + 2 * 4 * (3 + 4 + {0: 0, 1: 9, 2: 24, 3: 45}[deg]))}
-        run_decode()  # leave `out` as the fused decode produced it
+        run_decode((counter[0] - 1) % nbuf)  # leave `out` as the fused decode produced it
         torch.cuda.synchronize()
 
     if rank == 0:
@@ -281,7 +301,7 @@ def main():
                 "points_per_gpu": n, "sh_degree": deg, "version": ver,
                 "parallelism": ("single GPU" if world == 1 else
                                 f"point-range shards x{world}" + (", one grouped RCCL gatherv of the byte stream to "
-                                                                   "rank 0 per step, overlapped with decode"
+                                                                   "rank 0 per step, double-buffered: it overlaps the kernels of the next steps"
                                                                    if use_coll else ", no collective") +
                                 ("" if args.backend == "nccl" else " [REHEARSAL: gloo backend, host-staged, not a measurement]")),
             },
