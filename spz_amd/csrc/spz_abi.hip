@@ -106,6 +106,7 @@ struct Tables {
   float host[kTableFloats];
   float *dev[kMaxDevices];
   bool host_ready;
+  bool monotone;
 };
 Tables g_tables = {};
 std::mutex g_tables_mutex;
@@ -159,6 +160,18 @@ void build_host_tables() {
     t[kTableAlphaThr + v - 1] = key_float(hi);
   }
   t[kTableAlphaThr + 255] = NAN;
+  // The threshold form is exact only if toUint8(sigmoid(a) * 255) is monotone in a with this libm.
+  // Check the step at every threshold over +-8 ulp; a libm that breaks it makes the alpha encode
+  // fail loudly (SPZ_AMD_ERR_UNSUPPORTED) instead of silently differing from the reference.
+  g_tables.monotone = true;
+  for (int v = 1; v <= 255 && g_tables.monotone; ++v) {
+    const uint32_t k = float_key(t[kTableAlphaThr + v - 1]);
+    for (int d = -8; d <= 8; ++d) {
+      const int byte = ref_alpha_byte_host(key_float(k + (uint32_t)d));
+      if ((d < 0 && byte >= v) || (d >= 0 && byte < v)) g_tables.monotone = false;
+    }
+    if (v > 1 && !(t[kTableAlphaThr + v - 2] < t[kTableAlphaThr + v - 1])) g_tables.monotone = false;
+  }
   g_tables.host_ready = true;
 }
 
@@ -166,6 +179,7 @@ int ensure_tables(int device, const float **dev_tables) {
   if (device < 0 || device >= kMaxDevices) return SPZ_AMD_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lock(g_tables_mutex);
   if (!g_tables.host_ready) build_host_tables();
+  if (!g_tables.monotone) return SPZ_AMD_ERR_UNSUPPORTED;
   if (g_tables.dev[device] == nullptr) {
     float *d = nullptr;
     SPZ_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), sizeof(float) * kTableFloats));
