@@ -629,3 +629,76 @@ def test_release_device_memory_and_reuse(dev, oracle):
     assert L.spz_amd_release_device_memory() == 0
     assert L.spz_amd_release_device_memory() == 0          # idempotent
     assert_bytes_equal(gpu_encode(c, n, deg, False, 6, dev), want)   # tables are rebuilt on demand
+
+
+def _random_float_bits(rng, m, max_abs):
+    """m float32 values drawn uniformly over BIT PATTERNS (every exponent incl. denormals), finite and
+    |x| < max_abs."""
+    out = np.empty(0, np.float32)
+    while out.size < m:
+        b = rng.integers(0, 2 ** 32, 2 * m, dtype=np.uint64).astype(np.uint32).view(np.float32)
+        b = b[np.isfinite(b) & (np.abs(b) < max_abs)]
+        out = np.concatenate([out, b])
+    return out[:m].copy()
+
+
+def test_whole_float_domain_bit_patterns(dev, oracle):
+    """Inputs drawn over float bit patterns rather than a distribution: denormals, huge and tiny
+    exponents, both zeros — everything inside the reference's DEFINED domain (finite, and small
+    enough that no float->int conversion overflows: |pos * 4096| < 2^31, |sh * 128| < 2^31)."""
+    rng = np.random.default_rng(2024)
+    n, deg = 400_000, 3
+    q = _random_float_bits(rng, 4 * n, 1e18).reshape(-1, 4)
+    q[np.linalg.norm(q.astype(np.float64), axis=1) < 1e-18] = [0, 0, 0, 1]   # keep the norm's square a normal float
+    c = dict(positions=_random_float_bits(rng, 3 * n, 2.0 ** 18), scales=_random_float_bits(rng, 3 * n, 3e38),
+             rotations=q.reshape(-1), alphas=_random_float_bits(rng, n, 3e38),
+             colors=_random_float_bits(rng, 3 * n, 1e36), sh=_random_float_bits(rng, 45 * n, 2.0 ** 23))
+    for frm in (0, 6):
+        assert_bytes_equal(gpu_encode(c, n, deg, False, frm, dev), oracle.pack(c, n, deg, False, frm), f"from={frm}")
+
+
+def test_outside_the_defined_domain_matches_the_x86_build(dev, oracle):
+    """NOT pinned by the reference's semantics (float->int of NaN / out-of-range values and zero-norm
+    quaternions are undefined behaviour there).  The kernels reproduce what the
+    reference's x86-64 build does (cvttss2si 'integer indefinite'); the oracle, compiled by the same
+    compiler with the same casts, shows that behaviour, so equality is checked here as a
+    bug-compatibility property, separate from the parity claim."""
+    rng = np.random.default_rng(7)
+    n, deg = 50_000, 1
+    special = np.float32([np.nan, -np.nan, np.inf, -np.inf, 3e38, -3e38, 2.0 ** 31, -2.0 ** 31, 2.0 ** 31 - 128,
+                          2.0 ** 24, -2.0 ** 24, 1e10, -1e10, 524288.0, -524288.0, 16777216.0 / 128])
+
+    def salted(m, scale):
+        a = (rng.standard_normal(m) * scale).astype(np.float32)
+        idx = rng.integers(0, m, m // 4)
+        a[idx] = special[rng.integers(0, special.size, idx.size)]
+        return a
+
+    q = salted(4 * n, 1.0).reshape(-1, 4)
+    q[:64] = 0.0                      # zero-norm quaternions: 0/0
+    q[64:128] = np.float32(1e-30)     # squares underflow to zero
+    c = dict(positions=salted(3 * n, 5.0), scales=salted(3 * n, 3.0), rotations=q.reshape(-1), alphas=salted(n, 3.0),
+             colors=salted(3 * n, 1.0), sh=salted(9 * n, 0.3))
+    with np.errstate(all="ignore"):
+        want = oracle.pack(c, n, deg, False, 6)
+    got = gpu_encode(c, n, deg, False, 6, dev)
+    assert_bytes_equal(got, want, "x86 bug-compatibility")
+
+
+@pytest.mark.parametrize("version", [1, 2, 3])
+def test_decode_of_arbitrary_bytes(dev, oracle, version):
+    """A stream whose every payload byte is random (any v1/v2/v3 stream a peer could send): decode is
+    total — every bit pattern has a defined result in the reference — and must match bit for bit,
+    NaNs from impossible quaternions and float16 NaN/inf positions included."""
+    from spz_amd import abi
+    rng = np.random.default_rng(100 + version)
+    n, deg = 100_003, 3
+    lay = abi.stream_layout(n, deg, version)
+    s = rng.integers(0, 256, lay.total_bytes, dtype=np.uint16).astype(np.uint8)
+    s[:16] = np.frombuffer(abi.write_header(version, n, deg, 12, True), np.uint8)
+    for to in (0, 6, 7):
+        _, u = gpu_decode(s, to, dev)
+        rc, w = oracle.unpack(s, to)
+        assert rc == 0
+        for k in FIELDS:
+            assert_bits_equal(u[k], w[k], f"v{version} to={to} {k}")
