@@ -207,6 +207,9 @@ int grid_for(int device, uint32_t total_tiles, uint32_t *grid) {
     cap = (uint32_t)cus[device] * (uint32_t)kMaxBlocksPerCU;
   }
   uint32_t g = total_tiles < cap ? total_tiles : cap;
+#if SPZ_XCD_REMAP
+  g = ((total_tiles + 7u) / 8u) * 8u;  // every XCD gets ceil(tiles / 8) blocks; surplus blocks exit
+#endif
   *grid = g > 0 ? g : 1;
   return SPZ_AMD_OK;
 }

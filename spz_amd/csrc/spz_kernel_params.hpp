@@ -59,6 +59,10 @@ namespace spz_amd_detail {
 #ifndef SPZ_ENC_SCHED_BARRIER
 #define SPZ_ENC_SCHED_BARRIER 1
 #endif
+// 1: XCD-contiguous tile assignment (flat grids only), see first_tile() in spz_kernels.hip.
+#ifndef SPZ_XCD_REMAP
+#define SPZ_XCD_REMAP 0
+#endif
 #ifndef SPZ_BLOCKS_PER_CU
 #define SPZ_BLOCKS_PER_CU 0
 #endif

@@ -463,6 +463,20 @@ __device__ __forceinline__ void decode_tile_sh_dispatch(const SecDesc &s, uint32
   else decode_tile<KIND, 9, DecGeom>(s, tile_local, c);
 }
 
+// First tile of a block.  Default: block b takes tile b (the dispatcher deals consecutive blocks
+// round-robin over the 8 XCDs, so each XCD streams every 8th 16 KiB chunk).  SPZ_XCD_REMAP: each XCD
+// gets one contiguous eighth of the tiles instead (measured: no gain, there is no inter-block reuse
+// for an XCD-local L2 to capture; kept as a tuning switch).
+__device__ __forceinline__ uint32_t first_tile(const KParams &p) {
+#if SPZ_XCD_REMAP
+  const uint32_t chunk = (p.total_tiles + 7u) / 8u;
+  const uint32_t t = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
+  return ((blockIdx.x >> 3) < chunk && t < p.total_tiles) ? t : 0xffffffffu;
+#else
+  return blockIdx.x;
+#endif
+}
+
 __device__ __forceinline__ uint32_t find_section(const KParams &p, uint32_t tile) {
   uint32_t si = 0;
 #pragma unroll
@@ -489,7 +503,7 @@ __global__ __launch_bounds__(DecGeom::kBlock) void spz_decode_kernel(const KPara
   c.sh_mask_ext = p.sh_mask_ext;
   c.pos_scale = p.pos_scale;
   c.lut = lut;
-  for (uint32_t tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+  for (uint32_t tile = first_tile(p); tile < p.total_tiles; tile = SPZ_XCD_REMAP ? 0xffffffffu : tile + gridDim.x) {
     const uint32_t si = find_section(p, tile);
     const SecDesc &s = p.sec[si];
     const uint32_t tl = tile - s.tile_begin;
@@ -658,7 +672,7 @@ __global__ __launch_bounds__(EncGeom::kBlock, SPZ_ENC_MIN_WAVES) void spz_encode
     // PackedGaussiansHeader, load-spz.cc:131-139,534-539
     p.header_dst[threadIdx.x] = (uint8_t)(p.header_words[threadIdx.x >> 2] >> ((threadIdx.x & 3u) * 8u));
   }
-  for (uint32_t tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+  for (uint32_t tile = first_tile(p); tile < p.total_tiles; tile = SPZ_XCD_REMAP ? 0xffffffffu : tile + gridDim.x) {
     const uint32_t si = find_section(p, tile);
     const SecDesc &s = p.sec[si];
     const uint32_t tl = tile - s.tile_begin;
@@ -733,7 +747,7 @@ __device__ __forceinline__ void flip_tile(const SecDesc &s, uint32_t tile_local,
 }  // namespace
 
 __global__ __launch_bounds__(FlipGeom::kBlock) void spz_flip_kernel(const KParams p) {
-  for (uint32_t tile = blockIdx.x; tile < p.total_tiles; tile += gridDim.x) {
+  for (uint32_t tile = first_tile(p); tile < p.total_tiles; tile = SPZ_XCD_REMAP ? 0xffffffffu : tile + gridDim.x) {
     const uint32_t si = find_section(p, tile);
     const SecDesc &s = p.sec[si];
     const uint32_t tl = tile - s.tile_begin;

@@ -27,20 +27,14 @@ def D(block=256, unroll=4, wc=0, ntl=0, nts=0):
 # Encode and decode geometries are independent; library i carries encode config i and decode config i
 # (the two columns of a row are unrelated experiments).  All are "flat" (one tile per block).
 ENC = {
-    "b256u4_wc_ntl":         E(wc=1, ntl=1),
-    "sb":                    dict(E(wc=1, ntl=1), SPZ_ENC_SCHED_BARRIER=1),
-    "sb_w7":                 dict(E(wc=1, ntl=1), SPZ_ENC_SCHED_BARRIER=1, SPZ_ENC_MIN_WAVES=7),
-    "sb_w8":                 dict(E(wc=1, ntl=1), SPZ_ENC_SCHED_BARRIER=1, SPZ_ENC_MIN_WAVES=8),
-    "sb_u8":                 dict(E(unroll=8, wc=1, ntl=1), SPZ_ENC_SCHED_BARRIER=1),
-    "sb_b512":               dict(E(block=512, wc=1, ntl=1), SPZ_ENC_SCHED_BARRIER=1),
+    "shipped":        dict(E(wc=1, ntl=1), SPZ_ENC_SCHED_BARRIER=1),
+    "xcd_remap":      dict(E(wc=1, ntl=1), SPZ_ENC_SCHED_BARRIER=1, SPZ_XCD_REMAP=1),
+    "shipped_b":      dict(E(wc=1, ntl=1), SPZ_ENC_SCHED_BARRIER=1),
 }
 DEC = {
-    "b256u4":          D(),
-    "b256u4_b":        D(),
-    "b256u4_c":        D(),
-    "b256u4_d":        D(),
-    "b256u4_e":        D(),
-    "b256u4_f":        D(),
+    "shipped":        D(),
+    "xcd_remap":      D(),
+    "shipped_b":      D(),
 }
 VARIANTS = {}
 for _i, (_e, _d) in enumerate(zip(ENC.items(), DEC.items())):
