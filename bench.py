@@ -59,7 +59,7 @@ def algorithmic_bytes_per_point(sh_degree, version):
     return (14 + d) * 4 + packed
 
 
-def cpu_baseline(cloud_t, n, sh_degree, frm, to, sample_points, gpu_stream_fn):
+def cpu_baseline(cloud_t, n, sh_degree, frm, to, sample_points, gpu_stream_fn, gpu_decoded_bit_sums_fn=None):
     """Times the reference C++ (or the C port) on one host core over the same synthetic points and
     checks that what was timed produced the same bytes as the GPU path."""
     import numpy as np
@@ -69,9 +69,13 @@ def cpu_baseline(cloud_t, n, sh_degree, frm, to, sample_points, gpu_stream_fn):
     m = n if sample_points <= 0 else min(n, sample_points)
     host = {k: cloud_t[k][: m * floats_per_point(k, sh_degree)].cpu().numpy() for k in FIELDS}
     gpu_stream = gpu_stream_fn(m)
+    decoded_identical = None
     if os.path.exists(REF_SO):
         kind = "reference"
-        t_pack, t_unpack, stream = Reference().bench_pack_unpack(host, m, sh_degree, frm, to, want_stream=True)
+        R = Reference()
+        t_pack, t_unpack, stream = R.bench_pack_unpack(host, m, sh_degree, frm, to, want_stream=True)
+        if gpu_decoded_bit_sums_fn is not None:
+            decoded_identical = bool(R.last_decoded_bit_sums == gpu_decoded_bit_sums_fn(m))
     else:
         kind = "port"
         O = Oracle()
@@ -93,6 +97,7 @@ def cpu_baseline(cloud_t, n, sh_degree, frm, to, sample_points, gpu_stream_fn):
         "pack_gaussians_per_s": m / t_pack,
         "unpack_gaussians_per_s": m / t_unpack,
         "stream_bit_identical_to_gpu": parity,
+        "decoded_bit_sums_identical_to_gpu": decoded_identical,
     }
 
 
@@ -107,6 +112,7 @@ def main():
                os.path.abspath(__file__)] + sys.argv[1:]
         sys.exit(subprocess.call(cmd))
 
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this pool
     import torch
     import torch.distributed as dist
 
@@ -330,7 +336,22 @@ def main():
                 s = D.encode(sub, m, deg, False, frm, 3)
                 torch.cuda.synchronize()
                 return s.cpu().numpy()
-            res["cpu_baseline"] = cpu_baseline(cloud, n, deg, frm, to, args.cpu_sample_points, gpu_stream_fn)
+            def gpu_decoded_bit_sums_fn(m):
+                # per-array sum of the decoded floats' bit patterns (what the reference shim sums on its side)
+                sub = {k: cloud[k][: m * floats_per_point(k, deg)] for k in FIELDS}
+                s = D.encode(sub, m, deg, False, frm, 3)
+                d = D.decode(s, D.make_header(m, deg, 3), to)
+                torch.cuda.synchronize()
+                sums = []
+                for k in FIELDS:
+                    v = d[k].view(torch.int32)
+                    total = 0
+                    for part in v.split(1 << 26):   # bounded temporaries
+                        total += int((part.to(torch.int64) & 0xffffffff).sum().item())
+                    sums.append(total & 0xffffffffffffffff)
+                return sums
+            res["cpu_baseline"] = cpu_baseline(cloud, n, deg, frm, to, args.cpu_sample_points, gpu_stream_fn,
+                                               gpu_decoded_bit_sums_fn)
         print(json.dumps(res), flush=True)
     if distributed:
         dist.barrier()

@@ -178,7 +178,8 @@ class Reference:
         L.ref_half_to_float.argtypes = [C.c_uint16]
         L.ref_bench_pack_unpack.restype = C.c_int
         L.ref_bench_pack_unpack.argtypes = cloud6 + [C.c_int32, C.c_int, C.c_int, C.c_int,
-                                                     C.POINTER(C.c_double), C.POINTER(C.c_double), _u8p, C.c_size_t]
+                                                     C.POINTER(C.c_double), C.POINTER(C.c_double), _u8p, C.c_size_t,
+                                                     C.POINTER(C.c_uint64)]
 
     def pack(self, cloud, n, deg, antialiased=False, from_coord=0):
         arrs = [_f32(cloud[k]) for k in ("positions", "scales", "rotations", "alphas", "colors", "sh")]
@@ -276,9 +277,11 @@ class Reference:
         arrs = [_f32(cloud[k]) for k in ("positions", "scales", "rotations", "alphas", "colors", "sh")]
         tp, tu = C.c_double(), C.c_double()
         stream = np.zeros(stream_size(n, deg, 3), np.uint8) if want_stream else None
+        sums = (C.c_uint64 * 6)()
         rc = self.lib.ref_bench_pack_unpack(*[_fp(a) for a in arrs], n, deg, from_coord, to_coord,
                                             C.byref(tp), C.byref(tu), _bp(stream),
-                                            stream.size if want_stream else 0)
+                                            stream.size if want_stream else 0, sums)
         if rc:
             raise RuntimeError(f"ref_bench_pack_unpack rc={rc}")
+        self.last_decoded_bit_sums = [int(x) for x in sums]
         return tp.value, tu.value, stream

@@ -218,7 +218,7 @@ int ref_load_ply(const char *filename, int to, float *pos, float *scales, float 
 int ref_bench_pack_unpack(const float *pos, const float *scales, const float *rot,
                           const float *alphas, const float *colors, const float *sh, int32_t n,
                           int shDegree, int from, int to, double *t_pack_s, double *t_unpack_s,
-                          uint8_t *stream_out, size_t capacity) {
+                          uint8_t *stream_out, size_t capacity, uint64_t *decoded_bit_sums) {
   spz::GaussianCloud g = makeCloud(pos, scales, rot, alphas, colors, sh, n, shDegree, 0);
   spz::PackOptions po;
   po.from = static_cast<spz::CoordinateSystem>(from);
@@ -232,6 +232,20 @@ int ref_bench_pack_unpack(const float *pos, const float *scales, const float *ro
   *t_pack_s = t1 - t0;
   *t_unpack_s = t2 - t1;
   if (back.numPoints != n) return -1;
+  if (decoded_bit_sums) {
+    // order-independent checksum of what unpackGaussians produced: sum of the float bit patterns per array
+    const std::vector<float> *arrs[6] = {&back.positions, &back.scales, &back.rotations,
+                                         &back.alphas,    &back.colors, &back.sh};
+    for (int a = 0; a < 6; ++a) {
+      uint64_t acc = 0;
+      for (float f : *arrs[a]) {
+        uint32_t b;
+        std::memcpy(&b, &f, 4);
+        acc += b;
+      }
+      decoded_bit_sums[a] = acc;
+    }
+  }
   if (stream_out) {
     std::stringstream ss;
     spz::serializePackedGaussians(packed, &ss);

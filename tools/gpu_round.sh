@@ -20,6 +20,8 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_stats_$TAG -- python3 $R/bench.py --steps 20 --warmup 3 --no-cpu-baseline > $O/bench_prof_$TAG.log 2>&1 || { echo "rocprof stats failed"; tail -n 5 $O/bench_prof_$TAG.log; exit 4; }
 timeout -k 10 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/prof_fetch_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_fetch_$TAG.log 2>&1 || { echo "rocprof FETCH_SIZE failed"; tail -n 5 $O/bench_fetch_$TAG.log; exit 5; }
 timeout -k 10 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/prof_write_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_write_$TAG.log 2>&1 || { echo "rocprof WRITE_SIZE failed"; tail -n 5 $O/bench_write_$TAG.log; exit 6; }
+# best effort: wave / instruction mix of the two kernels (not needed for the roofline numbers)
+timeout -k 10 300 rocprofv3 --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_VMEM SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU --kernel-trace --output-format csv -d $O/prof_sq_$TAG -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_sq_$TAG.log 2>&1 || echo "SQ pass failed (ignored)"
 cd $R
 timeout -k 10 400 python bench.py > $O/bench_$TAG.log 2>&1 || { echo "bench failed"; tail -n 5 $O/bench_$TAG.log; exit 7; }
 tail -n 1 $O/bench_$TAG.log
