@@ -17,7 +17,10 @@ namespace spz_amd_detail {
 // Launch geometry, per kernel.  A tile is BLOCK threads x UNROLL units.  The defaults are the
 // measured best on MI355X (profiles/README.md); the macros exist so that tools/tune.py can build
 // variants.  WC: a wave owns one contiguous span of its tile instead of UNROLL strided 1 KiB spans.
-// NTL / NTS: non-temporal loads / stores (every byte on this path is touched exactly once).
+// NTL / NTS: non-temporal loads / stores (every byte on this path is touched exactly once).  What a
+// kernel leaves in the write-back caches is paid for by the NEXT kernel: with plain stores in decode
+// the following encode ran 0.537 ms, with non-temporal ones 0.484 ms (profiles/r01_tune_h_*.jsonl),
+// so pairs are tuned in their own steady state, not kernel by kernel.
 #ifndef SPZ_DEC_BLOCK
 #define SPZ_DEC_BLOCK 256
 #endif
@@ -28,10 +31,10 @@ namespace spz_amd_detail {
 #define SPZ_DEC_WC 0
 #endif
 #ifndef SPZ_DEC_NTL
-#define SPZ_DEC_NTL 0
+#define SPZ_DEC_NTL 1
 #endif
 #ifndef SPZ_DEC_NTS
-#define SPZ_DEC_NTS 0
+#define SPZ_DEC_NTS 1
 #endif
 #ifndef SPZ_ENC_BLOCK
 #define SPZ_ENC_BLOCK 256
