@@ -21,6 +21,14 @@ namespace {
 
 using namespace spz_amd_detail;
 
+// Non-temporal loads / stores (every byte is touched once; see spz_kernel_params.hpp on why pairs of
+// kernels are tuned together).
+#ifndef SPZ_PLY_NTL
+#define SPZ_PLY_NTL 1
+#endif
+#ifndef SPZ_PLY_NTS
+#define SPZ_PLY_NTS 1
+#endif
 #ifndef SPZ_PLY_LANE_IS_FIELD
 #define SPZ_PLY_LANE_IS_FIELD 1
 #endif
@@ -38,10 +46,40 @@ struct PlyParams {
   uint32_t flip_p, flip_q, flip_sh15;
 };
 
+typedef float ply_v4f __attribute__((ext_vector_type(4)));
+typedef ply_v4f ply_v4f_a4 __attribute__((aligned(4)));
+typedef float ply_f32_a4 __attribute__((aligned(4)));
+
+__device__ __forceinline__ F32x4 ply_load4(const float *p) {
+#if SPZ_PLY_NTL
+  ply_v4f t = __builtin_nontemporal_load(reinterpret_cast<const ply_v4f_a4 *>(p));
+  F32x4 v;
+  v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w;
+  return v;
+#else
+  return *reinterpret_cast<const F32x4 *>(p);
+#endif
+}
+__device__ __forceinline__ void ply_store4(float *p, F32x4 v) {
+#if SPZ_PLY_NTS
+  ply_v4f t = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(t, reinterpret_cast<ply_v4f_a4 *>(p));
+#else
+  *reinterpret_cast<F32x4 *>(p) = v;
+#endif
+}
+__device__ __forceinline__ void ply_store1(float *p, float v) {
+#if SPZ_PLY_NTS
+  __builtin_nontemporal_store(v, p);
+#else
+  *p = v;
+#endif
+}
+
 __device__ __forceinline__ void copy_to_lds(float *__restrict__ dst, const float *__restrict__ src, uint32_t count) {
   const uint32_t vec = count & ~3u;
   for (uint32_t i = threadIdx.x * 4u; i < vec; i += kPlyBlock * 4u) {
-    F32x4 v = *reinterpret_cast<const F32x4 *>(src + i);
+    F32x4 v = ply_load4(src + i);
     dst[i] = v.x; dst[i + 1] = v.y; dst[i + 2] = v.z; dst[i + 3] = v.w;
   }
   for (uint32_t i = vec + threadIdx.x; i < count; i += kPlyBlock) dst[i] = src[i];
@@ -67,19 +105,19 @@ __global__ __launch_bounds__(kPlyBlock) void spz_ply_rows_to_cloud_kernel(const 
   // positions: value * flipP[axis] (convertCoordinates multiplies every element, load-spz.cc:842)
   for (uint32_t i = tid; i < np * 3u; i += kPlyBlock) {
     const uint32_t pt = i / 3u, a = i - pt * 3u;
-    p.out[0][first * 3u + i] = mul_pm1(tile[pt * stride + (uint32_t)p.cols.position[a]], (p.flip_p >> a) & 1u);
+    ply_store1(&p.out[0][first * 3u + i], mul_pm1(tile[pt * stride + (uint32_t)p.cols.position[a]], (p.flip_p >> a) & 1u));
   }
   for (uint32_t i = tid; i < np * 3u; i += kPlyBlock) {
     const uint32_t pt = i / 3u, a = i - pt * 3u;
-    p.out[1][first * 3u + i] = tile[pt * stride + (uint32_t)p.cols.scale[a]];
-    p.out[4][first * 3u + i] = tile[pt * stride + (uint32_t)p.cols.color[a]];
+    ply_store1(&p.out[1][first * 3u + i], tile[pt * stride + (uint32_t)p.cols.scale[a]]);
+    ply_store1(&p.out[4][first * 3u + i], tile[pt * stride + (uint32_t)p.cols.color[a]]);
   }
   for (uint32_t i = tid; i < np * 4u; i += kPlyBlock) {
     const uint32_t pt = i >> 2, c = i & 3u;
     const float v = tile[pt * stride + (uint32_t)p.cols.rotation[c]];
-    p.out[2][first * 4u + i] = (c < 3u) ? mul_pm1(v, (p.flip_q >> c) & 1u) : v;  // w is never multiplied
+    ply_store1(&p.out[2][first * 4u + i], (c < 3u) ? mul_pm1(v, (p.flip_q >> c) & 1u) : v);  // w is never multiplied
   }
-  for (uint32_t i = tid; i < np; i += kPlyBlock) p.out[3][first + i] = tile[i * stride + (uint32_t)p.cols.alpha];
+  for (uint32_t i = tid; i < np; i += kPlyBlock) ply_store1(&p.out[3][first + i], tile[i * stride + (uint32_t)p.cols.alpha]);
   // sh: file [channel][coeff] -> cloud [coeff][channel], times flipSh[coeff]; 76 % of the output bytes
   if (d) {
     auto element = [&](uint32_t i) -> float {
@@ -92,7 +130,7 @@ __global__ __launch_bounds__(kPlyBlock) void spz_ply_rows_to_cloud_kernel(const 
     for (uint32_t i = tid * 4u; i < vec; i += kPlyBlock * 4u) {
       F32x4 v;
       v.x = element(i); v.y = element(i + 1); v.z = element(i + 2); v.w = element(i + 3);
-      *reinterpret_cast<F32x4 *>(dst + i) = v;
+      ply_store4(dst + i, v);
     }
     for (uint32_t i = vec + tid; i < total; i += kPlyBlock) dst[i] = element(i);
   }
@@ -156,7 +194,7 @@ __global__ __launch_bounds__(kPlyBlock) void spz_cloud_to_ply_rows_kernel(const 
       for (uint32_t pt = wave * ppw + sub; pt < np; pt += (kPlyBlock / 64) * ppw) {
         const uint32_t b = __float_as_uint(tile[off + pt * step]);
         const uint32_t mul = is_nan_bits(b) ? (b | 0x00400000u) : (b ^ ((mode & 2u) << 30));
-        dst[pt * D + f] = __uint_as_float(mode == 0u ? b : (mode == 3u ? 0u : mul));
+        ply_store1(&dst[pt * D + f], __uint_as_float(mode == 0u ? b : (mode == 3u ? 0u : mul)));
       }
     }
     return;
@@ -174,7 +212,7 @@ __global__ __launch_bounds__(kPlyBlock) void spz_cloud_to_ply_rows_kernel(const 
   for (uint32_t i = threadIdx.x * 4u; i < vec; i += kPlyBlock * 4u) {
     F32x4 v;
     v.x = element(i); v.y = element(i + 1); v.z = element(i + 2); v.w = element(i + 3);
-    *reinterpret_cast<F32x4 *>(dst + i) = v;
+    ply_store4(dst + i, v);
   }
   for (uint32_t i = vec + threadIdx.x; i < total; i += kPlyBlock) dst[i] = element(i);
 }
