@@ -115,6 +115,10 @@ int spz_amd_stream_layout(uint64_t num_points, int sh_degree, int version, spz_a
 int spz_amd_write_header(const spz_amd_header *hdr, uint8_t out16[16]);
 int spz_amd_peek_header(const uint8_t *stream, size_t size, spz_amd_header *out);
 int spz_amd_peek_header_ex(const uint8_t *stream, size_t size, uint64_t max_points, spz_amd_header *out);
+/* Same checks for a stream that lives in DEVICE memory (e.g. fragments reassembled over RCCL): copies
+ * the 16 header bytes to the host on `hip_stream` and waits for that copy. */
+int spz_amd_peek_header_device(const uint8_t *d_stream, size_t size, uint64_t max_points, spz_amd_header *out,
+                               void *hip_stream);
 
 /* ---- encode: packGaussians (load-spz.cc:257-331) + serializePackedGaussians (:533-546)
  *      fused: float SoA -> header + six sections written in place.

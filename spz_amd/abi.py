@@ -33,6 +33,7 @@ EXPORTS = (
     "spz_amd_abi_version", "spz_amd_status_string", "spz_amd_device_count", "spz_amd_last_hip_error",
     "spz_amd_release_device_memory",
     "spz_amd_stream_layout", "spz_amd_write_header", "spz_amd_peek_header", "spz_amd_peek_header_ex",
+    "spz_amd_peek_header_device",
     "spz_amd_encode_device", "spz_amd_decode_device", "spz_amd_encode_shard_device",
     "spz_amd_decode_shard_device", "spz_amd_convert_coordinates_device", "spz_amd_encode_host",
     "spz_amd_decode_host", "spz_amd_convert_coordinates_host", "spz_amd_get_tables",
@@ -109,6 +110,8 @@ def bind(L):
     L.spz_amd_peek_header.argtypes = [vp, sz, C.POINTER(Header)]
     L.spz_amd_peek_header_ex.restype = i32
     L.spz_amd_peek_header_ex.argtypes = [vp, sz, u64, C.POINTER(Header)]
+    L.spz_amd_peek_header_device.restype = i32
+    L.spz_amd_peek_header_device.argtypes = [vp, sz, u64, C.POINTER(Header), vp]
     L.spz_amd_encode_device.restype = i32
     L.spz_amd_encode_device.argtypes = [C.POINTER(CloudPtrs), u64, i32, i32, i32, i32, vp, sz, vp]
     L.spz_amd_decode_device.restype = i32

@@ -451,6 +451,41 @@ int spz_amd_peek_header_ex(const uint8_t *stream, size_t size, uint64_t max_poin
   return SPZ_AMD_OK;
 }
 
+int spz_amd_peek_header_device(const uint8_t *d_stream, size_t size, uint64_t max_points, spz_amd_header *out,
+                               void *hip_stream) {
+  if (out == nullptr || d_stream == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  if (size < 16) return SPZ_AMD_ERR_HEADER_NOT_FOUND;
+  int device = 0;
+  int rc = current_device(&device);
+  if (rc != SPZ_AMD_OK) return rc;
+  uint8_t raw[16];
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  SPZ_HIP_TRY(hipMemcpyAsync(raw, d_stream, 16, hipMemcpyDeviceToHost, st));
+  SPZ_HIP_TRY(hipStreamSynchronize(st));
+  // validate the fields on the 16 bytes, then the size against the full device stream
+  spz_amd_header h;
+  rc = spz_amd_peek_header_ex(raw, 16, max_points, &h);
+  if (rc != SPZ_AMD_OK && rc != SPZ_AMD_ERR_SHORT_STREAM) return rc;
+  if (rc == SPZ_AMD_ERR_SHORT_STREAM) {
+    // the 16-byte probe is always "short" unless the stream is empty: redo the size check with `size`
+    auto u32 = [&](int o) {
+      return (uint32_t)raw[o] | ((uint32_t)raw[o + 1] << 8) | ((uint32_t)raw[o + 2] << 16) | ((uint32_t)raw[o + 3] << 24);
+    };
+    h.version = u32(4);
+    h.num_points = u32(8);
+    h.sh_degree = raw[12];
+    h.fractional_bits = raw[13];
+    h.flags = raw[14];
+    h.reserved = raw[15];
+    spz_amd_layout lay;
+    rc = layout_impl(h.num_points, h.sh_degree, (int)h.version, &lay);
+    if (rc != SPZ_AMD_OK) return rc;
+    if (size < lay.total_bytes) return SPZ_AMD_ERR_SHORT_STREAM;
+  }
+  *out = h;
+  return SPZ_AMD_OK;
+}
+
 int spz_amd_peek_header(const uint8_t *stream, size_t size, spz_amd_header *out) {
   return spz_amd_peek_header_ex(stream, size, SPZ_AMD_REFERENCE_MAX_POINTS, out);
 }

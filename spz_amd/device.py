@@ -43,6 +43,17 @@ def make_header(num_points, sh_degree, version=3, fractional_bits=12, antialiase
                       1 if antialiased else 0, 0)
 
 
+def peek_header(stream_t, max_points=abi.REFERENCE_MAX_POINTS, stream=None):
+    """Header checks of deserializePackedGaussians (load-spz.cc:551-568,591-594) on a device-resident
+    stream.  Returns (status, Header or None)."""
+    L = abi.load_library()
+    h = abi.Header()
+    with torch.cuda.device(stream_t.device):
+        rc = L.spz_amd_peek_header_device(stream_t.data_ptr(), stream_t.numel(), int(max_points), C.byref(h),
+                                          _stream_handle(stream))
+    return rc, (h if rc == abi.OK else None)
+
+
 def encode(cloud, num_points, sh_degree, antialiased=False, from_coord=0, version=3, out=None, stream=None):
     """packGaussians + serializePackedGaussians on the GPU -> uint8 CUDA tensor holding the raw
     (pre-gzip) stream.  Asynchronous on `stream` (default: torch's current stream)."""

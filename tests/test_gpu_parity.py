@@ -702,3 +702,25 @@ def test_decode_of_arbitrary_bytes(dev, oracle, version):
         assert rc == 0
         for k in FIELDS:
             assert_bits_equal(u[k], w[k], f"v{version} to={to} {k}")
+
+
+def test_peek_header_on_device_streams(dev):
+    import torch
+    from spz_amd import abi, device as D
+    from spz_amd.synth import make_cloud_numpy
+    g = load_golden("legacy.npz")
+    n, deg = 1234, 2
+    s = D.encode(D.to_device(make_cloud_numpy(n, deg, 1), dev), n, deg, True, 6)
+    rc, h = D.peek_header(s)
+    assert rc == 0 and (h.version, h.num_points, h.sh_degree, h.fractional_bits, h.antialiased) == (3, n, deg, 12, True)
+    assert D.peek_header(s[:-1])[0] == abi.ERR_SHORT_STREAM
+    assert D.peek_header(s[:10])[0] == abi.ERR_HEADER_NOT_FOUND
+    want = {"magic": abi.ERR_HEADER_NOT_FOUND, "version4": abi.ERR_VERSION, "version0": abi.ERR_VERSION,
+            "toomany": abi.ERR_TOO_MANY_POINTS, "shdeg4": abi.ERR_SH_DEGREE, "short": abi.ERR_SHORT_STREAM}
+    for name, code in want.items():
+        t = torch.from_numpy(g[f"bad_{name}_stream"].copy()).to(dev)
+        assert D.peek_header(t)[0] == code, name
+    # the same decode works from what peek returned
+    out = D.decode(s, h, 7)
+    torch.cuda.synchronize()
+    assert out["positions"].numel() == 3 * n
