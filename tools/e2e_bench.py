@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""End-to-end saveSpz / loadSpz through the Python module (host arrays in, .spz bytes out): where the
+wall-clock goes once the quantise step is on the GPU, and what the opt-in parallel gzip buys."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import spz_amd.spz as spz  # noqa: E402
+from spz_amd.synth import FIELDS, make_cloud_numpy  # noqa: E402
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+    deg = 3
+    c = make_cloud_numpy(n, deg, 3)
+    g = spz.GaussianCloud()
+    g.sh_degree = deg
+    for k in FIELDS:
+        setattr(g, k, c[k])
+    o = spz.PackOptions()
+    o.from_coord = spz.RDF
+    res = {"points": n, "sh_degree": deg, "host_cores": os.cpu_count()}
+    t0 = time.perf_counter(); raw = spz._pack_to_stream(g, o); res["pack_to_stream_s"] = round(time.perf_counter() - t0, 4)
+    t0 = time.perf_counter(); raw = spz._pack_to_stream(g, o); res["pack_to_stream_warm_s"] = round(time.perf_counter() - t0, 4)
+    res["stream_bytes"] = len(raw)
+    for threads in (1, 8, 32, 128):
+        if threads > (os.cpu_count() or 1):
+            continue
+        t0 = time.perf_counter()
+        z = spz._compress_gzipped_parallel(raw, threads)
+        res[f"gzip_{threads}_threads_s"] = round(time.perf_counter() - t0, 3)
+        res[f"gzip_{threads}_threads_bytes"] = len(z)
+    t0 = time.perf_counter(); back = spz._decompress_gzipped(z); res["gunzip_s"] = round(time.perf_counter() - t0, 3)
+    assert back == raw
+    u = spz.UnpackOptions()
+    u.to_coord = spz.RDF
+    t0 = time.perf_counter(); d = spz._load_spz_bytes(z, u); res["load_spz_total_s"] = round(time.perf_counter() - t0, 3)
+    assert d.num_points == n
+    os.environ["SPZ_AMD_GZIP_THREADS"] = "64"
+    t0 = time.perf_counter(); b = spz._save_spz_bytes(g, o); res["save_spz_total_64_threads_s"] = round(time.perf_counter() - t0, 3)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
