@@ -88,6 +88,49 @@ __global__ __launch_bounds__(256) void dec_shape(const uint32_t *__restrict__ in
   }
 }
 
+// decode shape with 16-byte loads: a wave reads 1 KiB of packed bytes with one dwordx4 per lane,
+// transposes through LDS (lane i of round r needs dword r*64+i), and writes four float4 rounds.
+template <bool NT>
+__global__ __launch_bounds__(256) void dec_shape16(const uint32_t *__restrict__ in, v4f *__restrict__ out, size_t n) {
+  __shared__ uint32_t lds[256 * 4];
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  size_t base = (size_t)blockIdx.x * 1024 + (size_t)wave * 256;   // dwords
+  typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+  if (base + 256 <= n) {
+    u4 w = NT ? __builtin_nontemporal_load(reinterpret_cast<const u4 *>(in + base) + lane)
+              : reinterpret_cast<const u4 *>(in + base)[lane];
+    uint32_t *my = lds + wave * 256;
+    reinterpret_cast<u4 *>(my)[lane] = w;
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      uint32_t d = my[r * 64 + lane];
+      v4f v = {(float)(d & 0xff), (float)((d >> 8) & 0xff), (float)((d >> 16) & 0xff), (float)(d >> 24)};
+      if (NT) __builtin_nontemporal_store(v, out + base + r * 64 + lane);
+      else out[base + r * 64 + lane] = v;
+    }
+  }
+}
+
+template <int U>
+__global__ __launch_bounds__(256) void dec_shape_nt(const uint32_t *__restrict__ in, v4f *__restrict__ out, size_t n) {
+  size_t base = (size_t)blockIdx.x * (256 * U) + threadIdx.x;
+  uint32_t w[U];
+#pragma unroll
+  for (int r = 0; r < U; ++r) {
+    size_t i = base + (size_t)r * 256;
+    if (i < n) w[r] = __builtin_nontemporal_load(in + i);
+  }
+#pragma unroll
+  for (int r = 0; r < U; ++r) {
+    size_t i = base + (size_t)r * 256;
+    if (i < n) {
+      v4f v = {(float)(w[r] & 0xff), (float)((w[r] >> 8) & 0xff), (float)((w[r] >> 16) & 0xff), (float)(w[r] >> 24)};
+      __builtin_nontemporal_store(v, out + i);
+    }
+  }
+}
+
 template <int U, bool NT>
 __global__ __launch_bounds__(256) void enc_shape(const v4f *__restrict__ in, uint32_t *__restrict__ out, size_t n) {
   size_t base = (size_t)blockIdx.x * (256 * U) + threadIdx.x;
@@ -151,6 +194,10 @@ int main() {
   time_it("read16_u8", 1.0 * n16 * 16, it, [&] { hipLaunchKernelGGL((read16<8>), grid(8), dim3(256), 0, 0, a, sink, n16); });
   time_it("dec_shape_u4", 20.0 * n16, it, [&] { hipLaunchKernelGGL((dec_shape<4>), grid(4), dim3(256), 0, 0, w, b, n16); });
   time_it("dec_shape_u8", 20.0 * n16, it, [&] { hipLaunchKernelGGL((dec_shape<8>), grid(8), dim3(256), 0, 0, w, b, n16); });
+  time_it("dec_shape_u4_nt", 20.0 * n16, it, [&] { hipLaunchKernelGGL((dec_shape_nt<4>), grid(4), dim3(256), 0, 0, w, b, n16); });
+  time_it("dec_shape16", 20.0 * n16, it, [&] { hipLaunchKernelGGL((dec_shape16<false>), grid(4), dim3(256), 0, 0, w, b, n16); });
+  time_it("dec_shape16_nt", 20.0 * n16, it, [&] { hipLaunchKernelGGL((dec_shape16<true>), grid(4), dim3(256), 0, 0, w, b, n16); });
+  time_it("dec_shape_u4_nt_again", 20.0 * n16, it, [&] { hipLaunchKernelGGL((dec_shape_nt<4>), grid(4), dim3(256), 0, 0, w, b, n16); });
   time_it("enc_shape_u4", 20.0 * n16, it, [&] { hipLaunchKernelGGL((enc_shape<4, false>), grid(4), dim3(256), 0, 0, a, w, n16); });
   time_it("enc_shape_u4_ntl", 20.0 * n16, it, [&] { hipLaunchKernelGGL((enc_shape<4, true>), grid(4), dim3(256), 0, 0, a, w, n16); });
   time_it("enc_shape_u8_ntl", 20.0 * n16, it, [&] { hipLaunchKernelGGL((enc_shape<8, true>), grid(8), dim3(256), 0, 0, a, w, n16); });
