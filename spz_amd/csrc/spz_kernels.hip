@@ -473,6 +473,7 @@ __device__ __forceinline__ uint32_t first_tile(const KParams &p) {
   const uint32_t t = (blockIdx.x & 7u) * chunk + (blockIdx.x >> 3);
   return ((blockIdx.x >> 3) < chunk && t < p.total_tiles) ? t : 0xffffffffu;
 #else
+  (void)p;
   return blockIdx.x;
 #endif
 }
