@@ -149,6 +149,14 @@ int spz_amd_decode_shard_device(const uint8_t *d_stream, size_t size, const spz_
                                 uint64_t first, uint64_t count, int to_coord,
                                 const spz_amd_cloud_out *d_cloud, void *hip_stream);
 
+/* ---- random access: decode only the points d_indices[0..count) out of a stream that
+ *      stays packed in device memory — the bulk form of PackedGaussians::unpack(i, converter)
+ *      (load-spz.cc:383-463), output in the GaussianCloud array layout (d_cloud holds `count` points).
+ *      Indices >= hdr->num_points are clamped to the last point.  Same arithmetic as decode. ------- */
+int spz_amd_decode_gather_device(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr,
+                                 const uint32_t *d_indices, uint64_t count, int to_coord,
+                                 const spz_amd_cloud_out *d_cloud, void *hip_stream);
+
 /* ---- GaussianCloud::convertCoordinates (splat-types.h:134-164) as a standalone in-place
  *      device pass (the reference-shaped, un-fused second pass; kept for API parity and
  *      for the fused-vs-unfused measurement).  Any of the three pointers may be NULL. ------- */

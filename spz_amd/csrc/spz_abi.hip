@@ -516,6 +516,58 @@ int spz_amd_decode_shard_device(const uint8_t *d_stream, size_t size, const spz_
   return decode_impl(d_stream, size, hdr, first, count, to_coord, d_cloud, hip_stream);
 }
 
+int spz_amd_decode_gather_device(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr,
+                                 const uint32_t *d_indices, uint64_t count, int to_coord,
+                                 const spz_amd_cloud_out *cl, void *hip_stream) {
+  if (d_stream == nullptr || cl == nullptr || !valid_coord(to_coord)) return SPZ_AMD_ERR_INVALID_ARG;
+  int rc = check_header_fields(hdr);
+  if (rc != SPZ_AMD_OK) return rc;
+  spz_amd_layout lay;
+  rc = layout_impl(hdr->num_points, hdr->sh_degree, (int)hdr->version, &lay);
+  if (rc != SPZ_AMD_OK) return rc;
+  if (size < lay.total_bytes) return SPZ_AMD_ERR_SHORT_STREAM;
+  if (count == 0) return SPZ_AMD_OK;
+  const int sd = sh_dim_for_degree(hdr->sh_degree);
+  if (hdr->num_points == 0 || d_indices == nullptr || !cl->positions || !cl->scales || !cl->rotations ||
+      !cl->alphas || !cl->colors || (sd > 0 && !cl->sh)) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  int device = 0;
+  rc = current_device(&device);
+  if (rc != SPZ_AMD_OK) return rc;
+  GatherParams p = {};
+  rc = ensure_tables(device, &p.tables);
+  if (rc != SPZ_AMD_OK) return rc;
+  p.positions = d_stream + lay.offset[SPZ_AMD_SEC_POSITIONS];
+  p.alphas = d_stream + lay.offset[SPZ_AMD_SEC_ALPHAS];
+  p.colors = d_stream + lay.offset[SPZ_AMD_SEC_COLORS];
+  p.scales = d_stream + lay.offset[SPZ_AMD_SEC_SCALES];
+  p.rotations = d_stream + lay.offset[SPZ_AMD_SEC_ROTATIONS];
+  p.sh = d_stream + lay.offset[SPZ_AMD_SEC_SH];
+  p.out_positions = cl->positions;
+  p.out_scales = cl->scales;
+  p.out_rotations = cl->rotations;
+  p.out_alphas = cl->alphas;
+  p.out_colors = cl->colors;
+  p.out_sh = cl->sh;
+  p.indices = d_indices;
+  p.count = count;
+  p.num_points = hdr->num_points;
+  p.version = hdr->version;
+  p.sh_dim = (uint32_t)sd;
+  const FlipMasks fm = flip_masks(SPZ_AMD_RUB, to_coord);
+  p.flip_p = fm.p;
+  p.flip_q = fm.q;
+  p.flip_sh15 = fm.sh15;
+  p.pos_scale = (float)(1.0 / (double)(int32_t)(1u << (hdr->fractional_bits & 31)));
+  const unsigned long long items = count * (unsigned long long)(sd > 0 ? sd * 3 : 3);
+  unsigned long long blocks = (items + 255) / 256;
+  if (blocks > 65536ull * 16) blocks = 65536ull * 16;  // grid-stride beyond that
+  hipLaunchKernelGGL(spz_decode_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), p);
+  SPZ_HIP_TRY(hipGetLastError());
+  return SPZ_AMD_OK;
+}
+
 int spz_amd_convert_coordinates_device(float *d_positions, float *d_rotations, float *d_sh, uint64_t num_points,
                                        int sh_degree, int from_coord, int to_coord, void *hip_stream) {
   const int sd = sh_dim_for_degree(sh_degree);

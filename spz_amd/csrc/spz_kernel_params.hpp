@@ -131,7 +131,23 @@ constexpr int kTableColorDec = 256;  // 256 floats
 constexpr int kTableAlphaThr = 512;  // 255 floats + 1 NaN pad
 constexpr int kTableFloats = 768;
 
-// The three kernels (spz_kernels.hip).
+// Random-access decode: the points named by an index list, out of a stream that
+// stays packed in HBM.  Sections / outputs in the order of the spz_amd_cloud_out fields.
+struct GatherParams {
+  const uint8_t *positions, *alphas, *colors, *scales, *rotations, *sh;  // section bases in the stream
+  float *out_positions, *out_scales, *out_rotations, *out_alphas, *out_colors, *out_sh;
+  const uint32_t *indices;
+  unsigned long long count;       // number of indices
+  uint32_t num_points;            // points in the stream (indices are clamped to num_points - 1)
+  uint32_t version;               // 1, 2, 3
+  uint32_t sh_dim;                // 0, 3, 8, 15
+  uint32_t flip_p, flip_q, flip_sh15;
+  float pos_scale;
+  const float *tables;
+};
+
+// The kernels (spz_kernels.hip).
+__global__ void spz_decode_gather_kernel(const GatherParams p);
 __global__ void spz_decode_kernel(const KParams p);
 __global__ void spz_encode_kernel(const KParams p);
 __global__ void spz_flip_kernel(const KParams p);

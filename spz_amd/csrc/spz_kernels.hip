@@ -767,5 +767,69 @@ __global__ __launch_bounds__(FlipGeom::kBlock) void spz_flip_kernel(const KParam
 
 namespace {
 
+// One gathered value of an element-wise section: element e of the output is float (e % FPP) of the
+// point indices[e / FPP].  Same arithmetic as the bulk decode (decode_unit), one element at a time.
+template <int KIND, int FPP>
+__device__ __forceinline__ float gather_element(const GatherParams &p, unsigned long long e) {
+  const unsigned long long g = e / (unsigned)FPP;
+  const uint32_t o = (uint32_t)(e - g * (unsigned)FPP);
+  uint32_t i = p.indices[g];
+  i = i < p.num_points ? i : p.num_points - 1u;
+  if constexpr (KIND == KIND_POS24) {
+    const uint8_t *b = p.positions + ((unsigned long long)i * 3u + o) * 3u;
+    const uint32_t v = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
+    return xor_sign((float)((int32_t)(v << 8) >> 8) * p.pos_scale, (p.flip_p >> o) & 1u);
+  } else if constexpr (KIND == KIND_POS16) {
+    const uint8_t *b = p.positions + ((unsigned long long)i * 3u + o) * 2u;
+    return mul_pm1(half_to_float((uint32_t)b[0] | ((uint32_t)b[1] << 8)), (p.flip_p >> o) & 1u);
+  } else if constexpr (KIND == KIND_ALPHA) {
+    return p.tables[kTableAlphaDec + p.alphas[i]];
+  } else if constexpr (KIND == KIND_COLOR) {
+    return p.tables[kTableColorDec + p.colors[(unsigned long long)i * 3u + o]];
+  } else {  // KIND_SCALE
+    return (float)p.scales[(unsigned long long)i * 3u + o] / 16.0f - 10.0f;
+  }
+}
+
+}  // namespace
+
+__global__ __launch_bounds__(256) void spz_decode_gather_kernel(const GatherParams p) {
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  const unsigned long long t0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long c = p.count;
+  const uint32_t d = p.sh_dim * 3u;
+  // sh: element e -> point e / d, coefficient (e % d) / 3
+  for (unsigned long long e = t0; e < c * d; e += stride) {
+    const unsigned long long g = e / d;
+    const uint32_t o = (uint32_t)(e - g * d);
+    uint32_t i = p.indices[g];
+    i = i < p.num_points ? i : p.num_points - 1u;
+    const float v = ((float)p.sh[(unsigned long long)i * d + o] - 128.0f) / 128.0f;
+    p.out_sh[e] = xor_sign(v, (p.flip_sh15 >> (o / 3u)) & 1u);
+  }
+  for (unsigned long long e = t0; e < c * 3u; e += stride) {
+    p.out_positions[e] = (p.version == 1u) ? gather_element<KIND_POS16, 3>(p, e) : gather_element<KIND_POS24, 3>(p, e);
+    p.out_scales[e] = gather_element<KIND_SCALE, 3>(p, e);
+    p.out_colors[e] = gather_element<KIND_COLOR, 3>(p, e);
+  }
+  for (unsigned long long g = t0; g < c; g += stride) {
+    p.out_alphas[g] = gather_element<KIND_ALPHA, 1>(p, g);
+    uint32_t i = p.indices[g];
+    i = i < p.num_points ? i : p.num_points - 1u;
+    F32x4 q;
+    if (p.version >= 3u) {
+      const uint8_t *b = p.rotations + (unsigned long long)i * 4u;
+      q = unpack_quat_smallest_three((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24),
+                                     p.flip_q);
+    } else {
+      const uint8_t *b = p.rotations + (unsigned long long)i * 3u;
+      q = unpack_quat_first_three((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16), p.flip_q);
+    }
+    store_f4<false>(p.out_rotations, g, q);
+  }
+}
+
+namespace {
+
 }  // namespace
 }  // namespace spz_amd_detail

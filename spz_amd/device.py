@@ -111,6 +111,22 @@ def decode_shard(stream_t, header, first, count, to_coord=0, out=None, stream=No
     return out
 
 
+def decode_gather(stream_t, header, indices, to_coord=0, out=None, stream=None):
+    """Decode only the points `indices` (uint32/int32 CUDA tensor) of a packed device stream."""
+    L = abi.load_library()
+    count, deg = indices.numel(), header.sh_degree
+    if indices.dtype not in (torch.int32, torch.uint32) or not indices.is_cuda or not indices.is_contiguous():
+        raise ValueError("indices must be a contiguous int32/uint32 CUDA tensor")
+    if out is None:
+        out = alloc_cloud(count, deg, stream_t.device)
+    p = _ptrs(out, deg, count, stream_t.device)
+    with torch.cuda.device(stream_t.device):
+        rc = L.spz_amd_decode_gather_device(stream_t.data_ptr(), stream_t.numel(), C.byref(header), indices.data_ptr(),
+                                            count, to_coord, C.byref(p), _stream_handle(stream))
+    abi.check(rc, "spz_amd_decode_gather_device")
+    return out
+
+
 def convert_coordinates(cloud, num_points, sh_degree, from_coord, to_coord, stream=None):
     """In-place GaussianCloud::convertCoordinates on device tensors (positions, rotations, sh)."""
     L = abi.load_library()
@@ -135,5 +151,6 @@ def to_numpy(cloud_t):
     return {k: cloud_t[k].cpu().numpy() for k in FIELDS}
 
 
-__all__ = ["encode", "decode", "encode_shard", "decode_shard", "convert_coordinates", "alloc_cloud",
+__all__ = ["encode", "decode", "encode_shard", "decode_shard", "decode_gather", "peek_header", "convert_coordinates",
+           "alloc_cloud",
            "make_header", "to_device", "to_numpy", "SH_DIM"]

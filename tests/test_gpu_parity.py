@@ -724,3 +724,34 @@ def test_peek_header_on_device_streams(dev):
     out = D.decode(s, h, 7)
     torch.cuda.synchronize()
     assert out["positions"].numel() == 3 * n
+
+
+@pytest.mark.parametrize("version", [1, 2, 3])
+def test_random_access_gather_decode(dev, version):
+    """decoding an index list out of a packed device stream gives, bit for bit, the
+    rows of the bulk decode at those indices (repeats, reversed order, first/last point, and an
+    out-of-range index that is clamped to the last point)."""
+    import torch
+    from spz_amd import abi, device as D
+    rng = np.random.default_rng(300 + version)
+    n, deg = 50_003, 3
+    lay = abi.stream_layout(n, deg, version)
+    s = rng.integers(0, 256, lay.total_bytes, dtype=np.uint16).astype(np.uint8)
+    s[:16] = np.frombuffer(abi.write_header(version, n, deg, 12, False), np.uint8)
+    st = torch.from_numpy(s).to(dev)
+    rc, h = D.peek_header(st)
+    assert rc == 0
+    idx = np.concatenate([[0, n - 1, n - 1, 0, 7, n + 5], rng.integers(0, n, 9_991), np.arange(99, -1, -1)]).astype(np.int64)
+    it = torch.from_numpy(idx.astype(np.uint32).view(np.int32)).to(dev)
+    clamp = torch.from_numpy(np.minimum(idx, n - 1)).to(dev)
+    from spz_amd.synth import floats_per_point
+    for to in (0, 6, 7):
+        bulk = D.decode(st, h, to)
+        got = D.decode_gather(st, h, it, to)
+        torch.cuda.synchronize()
+        for k in FIELDS:
+            f = floats_per_point(k, deg)
+            want = bulk[k].view(torch.int32).reshape(n, f)[clamp].reshape(-1)
+            assert torch.equal(got[k].view(torch.int32), want), (version, to, k)
+    empty = D.decode_gather(st, h, it[:0], 0)
+    assert all(empty[k].numel() == 0 for k in FIELDS)
