@@ -755,3 +755,41 @@ def test_random_access_gather_decode(dev, version):
             assert torch.equal(got[k].view(torch.int32), want), (version, to, k)
     empty = D.decode_gather(st, h, it[:0], 0)
     assert all(empty[k].numel() == 0 for k in FIELDS)
+
+
+def test_device_entry_points_are_graph_capturable(dev, oracle):
+    """The *_device entry points do no allocation, copy or synchronisation after their first call on a
+    device, so a caller can capture encode+decode into a hipGraph (here via torch.cuda.graph) and
+    replay it; replays on new input produce the oracle's bytes."""
+    import torch
+    from spz_amd import abi, device as D
+    from spz_amd.synth import make_cloud_numpy
+    n, deg = 60_000, 3                      # BASELINE config 1 size: launch-bound, where a graph pays
+    c0, c1 = make_cloud_numpy(n, deg, 81), make_cloud_numpy(n, deg, 82)
+    t = D.to_device(c0, dev)
+    lay = abi.stream_layout(n, deg, 3)
+    stream_buf = torch.zeros(lay.total_bytes, dtype=torch.uint8, device=dev)
+    out = D.alloc_cloud(n, deg, dev)
+    hdr = D.make_header(n, deg)
+    D.encode(t, n, deg, False, 6, out=stream_buf)   # first call: builds / uploads the tables
+    D.decode(stream_buf, hdr, 7, out=out)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            D.encode(t, n, deg, False, 6, out=stream_buf)
+            D.decode(stream_buf, hdr, 7, out=out)
+    torch.cuda.current_stream().wait_stream(side)
+    for c in (c1, c0):
+        for k in FIELDS:
+            t[k].copy_(torch.from_numpy(c[k]))
+        stream_buf.zero_()
+        g.replay()
+        torch.cuda.synchronize()
+        want = oracle.pack(c, n, deg, False, 6)
+        assert_bytes_equal(stream_buf.cpu().numpy(), want, "graph replay encode")
+        rc, w = oracle.unpack(want, 7)
+        for k in FIELDS:
+            assert_bits_equal(out[k].cpu().numpy(), w[k], f"graph replay decode {k}")
