@@ -159,3 +159,55 @@ def test_python_module_raises_without_a_gpu():
     c.colors = np.zeros(3, np.float32)
     with pytest.raises(RuntimeError, match="no usable HIP device"):
         spz.save_spz(c, spz.PackOptions(), os.path.join("/tmp", "spz_amd_never_written.spz"))
+
+
+def test_argument_validation_happens_before_any_device_work(lib):
+    """Every argument error is reported as such even on a machine without a GPU (validation comes
+    first, ERR_NO_DEVICE last), with the reference's checkSizes-style conditions (load-spz.cc:106-127)."""
+    from spz_amd import abi
+    n = 8
+    arrs = [np.zeros(m, np.float32) for m in (3 * n, 3 * n, 4 * n, n, 3 * n, 9 * n)]
+    good = abi.CloudPtrs(*[a.ctypes.data for a in arrs])
+    no_sh = abi.CloudPtrs(*[a.ctypes.data for a in arrs[:5]], None)
+    out = np.zeros(abi.stream_layout(n, 1, 3).total_bytes, np.uint8)
+    enc = lambda cloud, deg=1, frm=0, ver=3, cap=out.size, dst=out.ctypes.data: lib.spz_amd_encode_device(
+        C.byref(cloud) if cloud is not None else None, n, deg, 0, frm, ver, dst, cap, None)
+    assert enc(None) == abi.ERR_INVALID_ARG
+    assert enc(good, dst=None) == abi.ERR_INVALID_ARG
+    assert enc(good, frm=9) == abi.ERR_INVALID_ARG
+    assert enc(good, frm=-1) == abi.ERR_INVALID_ARG
+    assert enc(good, deg=4) == abi.ERR_INVALID_ARG
+    assert enc(good, ver=4) == abi.ERR_INVALID_ARG
+    assert enc(good, ver=1) == abi.ERR_UNSUPPORTED
+    assert enc(good, cap=out.size - 1) == abi.ERR_CAPACITY
+    assert enc(no_sh) == abi.ERR_INVALID_ARG          # sh missing although sh_degree = 1
+    hdr = abi.Header(3, n, 1, 12, 0, 0)
+    dec = lambda h, size=out.size, to=0, cloud=good, src=out.ctypes.data: lib.spz_amd_decode_device(
+        src, size, C.byref(h) if h is not None else None, to, C.byref(cloud) if cloud is not None else None, None)
+    assert dec(None) == abi.ERR_INVALID_ARG
+    assert dec(hdr, src=None) == abi.ERR_INVALID_ARG
+    assert dec(hdr, cloud=None) == abi.ERR_INVALID_ARG
+    assert dec(hdr, to=9) == abi.ERR_INVALID_ARG
+    assert dec(abi.Header(0, n, 1, 12, 0, 0)) == abi.ERR_VERSION
+    assert dec(abi.Header(3, n, 4, 12, 0, 0)) == abi.ERR_SH_DEGREE
+    assert dec(hdr, size=out.size - 1) == abi.ERR_SHORT_STREAM
+    assert dec(hdr, cloud=no_sh) == abi.ERR_INVALID_ARG
+    # shards must lie inside the stream
+    assert lib.spz_amd_encode_shard_device(C.byref(good), 4, 8, 8, 1, 0, 0, 3, 0, out.ctypes.data, out.size, None) \
+        == abi.ERR_INVALID_ARG
+    assert lib.spz_amd_decode_shard_device(out.ctypes.data, out.size, C.byref(hdr), 9, 1, 0, C.byref(good), None) \
+        == abi.ERR_INVALID_ARG
+    # zero points: nothing to do, no device needed
+    assert lib.spz_amd_convert_coordinates_device(None, None, None, 0, 0, 4, 6, None) == abi.OK
+    assert lib.spz_amd_decode_shard_device(out.ctypes.data, out.size, C.byref(hdr), 3, 0, 0, C.byref(good), None) == abi.OK
+    # .ply column maps
+    cols = abi.PlyColumns()
+    assert lib.spz_amd_ply_default_columns(3, C.byref(cols)) == abi.OK and cols.stride == 26
+    bad = abi.PlyColumns.from_buffer_copy(bytes(cols))
+    bad.alpha = 26
+    assert lib.spz_amd_ply_rows_to_cloud_device(out.ctypes.data, n, C.byref(bad), 0, C.byref(good), None) == abi.ERR_INVALID_ARG
+    bad = abi.PlyColumns.from_buffer_copy(bytes(cols))
+    bad.stride = 300
+    assert lib.spz_amd_ply_rows_to_cloud_device(out.ctypes.data, n, C.byref(bad), 0, C.byref(good), None) == abi.ERR_INVALID_ARG
+    assert lib.spz_amd_cloud_to_ply_rows_device(C.byref(good), n, 16, 0, out.ctypes.data, None) == abi.ERR_INVALID_ARG
+    assert lib.spz_amd_release_device_memory() == abi.OK   # harmless without a device

@@ -793,3 +793,26 @@ def test_device_entry_points_are_graph_capturable(dev, oracle):
         rc, w = oracle.unpack(want, 7)
         for k in FIELDS:
             assert_bits_equal(out[k].cpu().numpy(), w[k], f"graph replay decode {k}")
+
+
+def test_fuzz_sizes_degrees_and_coordinate_systems(dev, oracle):
+    """150 random (N, degree, from, to, antialiased) combinations around tile and unit boundaries
+    (a tile is 1024 units of 4 floats; sections end in partial units when 3N or D*N is not a
+    multiple of 4), encode and decode against the oracle."""
+    from spz_amd.synth import make_cloud_numpy
+    rng = np.random.default_rng(4242)
+    interesting = [1, 2, 3, 4, 5, 1023, 1024, 1025, 1365, 1366, 4095, 4096, 4097, 5461, 5462, 8191, 8193, 12289]
+    for it in range(150):
+        n = int(rng.choice(interesting)) if it % 3 == 0 else int(rng.integers(1, 20000))
+        deg = int(rng.integers(0, 4))
+        frm, to = int(rng.integers(0, 9)), int(rng.integers(0, 9))
+        aa = bool(rng.integers(0, 2))
+        c = make_cloud_numpy(n, deg, 9000 + it)
+        want = oracle.pack(c, n, deg, aa, frm)
+        got = gpu_encode(c, n, deg, aa, frm, dev)
+        assert_bytes_equal(got, want, f"it={it} n={n} deg={deg} from={frm}")
+        h, u = gpu_decode(got, to, dev)
+        rc, w = oracle.unpack(want, to)
+        assert rc == 0 and h.antialiased == aa
+        for k in FIELDS:
+            assert_bits_equal(u[k], w[k], f"it={it} n={n} deg={deg} to={to} {k}")
