@@ -233,6 +233,28 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # N>1: the same K steps once more WITHOUT the exchange (every rank encodes and decodes its own shard,
+    # nothing crosses xGMI), so the line shows what the kernels sustain next to the link-bound headline.
+    shards_only = None
+    if use_coll:
+        t1 = time.perf_counter()
+        for k in range(K):
+            D.encode(cloud, n, deg, False, frm, ver, out=streams[0])
+            D.decode(streams[0], hdr, to, out=out)
+        fence()
+        el2 = time.perf_counter() - t1
+        t = torch.tensor([el2], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el2 = float(t.item())
+        into_root = sum(nb for r in range(1, world) for _, _, nb in plan.fragments(r))
+        shards_only = {
+            "value": n * world * K / el2, "unit": "Gaussians/s", "ms_per_step": el2 / K * 1e3,
+            "note": "same shards and kernels, no gatherv: the data-parallel rate of the path itself",
+            "gatherv_bytes_into_root_per_step": into_root,
+            "gatherv_GBps_into_root": into_root * K / elapsed / 1e9,
+            "gatherv_GBps_per_peer_link": into_root * K / elapsed / 1e9 / (world - 1),
+        }
+
     enc_ms = sum(e[0].elapsed_time(e[1]) for e in ev) / K
     dec_ms = sum(e[2].elapsed_time(e[3]) for e in ev) / K
 
@@ -328,6 +350,7 @@ def main():
             "decode_gaussians_per_s_per_gpu": n / (dec_ms * 1e-3),
             "reencode_fixed_point": fixed_point,
             "gather_verified": gather_verified,
+            "shards_only": shards_only,
             "config4_fused_vs_two_pass": two_pass,
         }
         if world == 1 and not args.no_cpu_baseline:
