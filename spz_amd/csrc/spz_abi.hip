@@ -596,7 +596,7 @@ int spz_amd_convert_coordinates_device(float *d_positions, float *d_rotations, f
 
 int spz_amd_encode_host(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int antialiased, int from_coord,
                         int version, uint8_t *h_stream, size_t capacity, int device) {
-  if (h == nullptr || h_stream == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  if (h == nullptr || h_stream == nullptr || !valid_coord(from_coord)) return SPZ_AMD_ERR_INVALID_ARG;
   spz_amd_layout lay;
   int rc = layout_impl(n, sh_degree, version, &lay);
   if (rc != SPZ_AMD_OK) return rc;
@@ -605,6 +605,10 @@ int spz_amd_encode_host(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, in
   const int sd = sh_dim_for_degree(sh_degree);
   if (n > 0 && (!h->positions || !h->scales || !h->rotations || !h->alphas || !h->colors || (sd > 0 && !h->sh))) {
     return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  if (n == 0) {  // a zero-point stream is its header (:534-539): nothing for a device to do
+    const spz_amd_header hdr = {(uint32_t)version, 0u, (uint8_t)sh_degree, 12, (uint8_t)(antialiased ? 1 : 0), 0};
+    return spz_amd_write_header(&hdr, h_stream);
   }
   DeviceGuard guard;
   rc = guard.enter(device);
