@@ -37,7 +37,7 @@ $(LIBDIR)/libspz_amd.so: $(DEVICE_SRCS) $(CSRC)/spz_common.hpp $(CSRC)/spz_kerne
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(DEVICE_SRCS)
 
 $(LIBDIR)/libspz_host.so: $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp $(INC)/spz_amd_host.hpp $(INC)/spz_amd.h $(LIBDIR)/libspz_amd.so
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp -L$(LIBDIR) -lspz_amd -lz -lpthread \
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp -L$(LIBDIR) -lspz_amd -lz -ldl -lpthread \
 	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 $(ROOT)spz_amd/spz$(PYEXT): $(CSRC)/spz_py.cpp $(INC)/spz_amd_host.hpp $(LIBDIR)/libspz_host.so

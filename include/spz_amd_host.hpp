@@ -114,11 +114,15 @@ GaussianCloud unpackGaussians(const PackedGaussians &packed, const UnpackOptions
 PackedGaussians deserializePackedGaussians(std::istream &in);
 
 // Extras of this implementation -------------------------------------------------------------
-// Inverse of compressGzipped (the reference keeps it file-local, load-spz.cc:141-182).
+// Inverse of compressGzipped (the reference keeps it file-local, load-spz.cc:141-182).  Members written
+// by compressGzippedParallel are inflated piece-parallel (SPZ_AMD_GUNZIP_THREADS, default min(cores, 32));
+// other members go through libdeflate when the system has libdeflate.so.0 (SPZ_AMD_NO_LIBDEFLATE=1 turns
+// that off); zlib's streaming inflate, what the reference uses, is the fallback and decides every case
+// the fast readers decline, so acceptance and output are zlib's.
 bool decompressGzipped(const uint8_t *compressed, size_t size, std::vector<uint8_t> *out);
-// Opt-in multi-threaded gzip (pigz construction: independent deflate blocks in one gzip member).
-// Readable by every gzip reader including the reference's loadSpz, NOT byte-identical to
-// compressGzipped.  saveSpz uses it when the environment sets SPZ_AMD_GZIP_THREADS > 1.
+// Opt-in multi-threaded gzip (pigz's independent-blocks construction: 1 MiB raw-deflate pieces in one
+// gzip member, their sizes listed in an FEXTRA subfield "SZ" that other readers skip).  Readable by
+// every gzip reader including the reference's loadSpz, NOT byte-identical to compressGzipped.  saveSpz uses it when the environment sets SPZ_AMD_GZIP_THREADS > 1.
 bool compressGzippedParallel(const uint8_t *data, size_t size, std::vector<uint8_t> *out, int threads);
 // Raw (pre-gzip) stream <-> cloud, i.e. saveSpz / loadSpz without the zlib step.
 bool packToStream(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream);

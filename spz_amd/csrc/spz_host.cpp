@@ -6,6 +6,7 @@
 // stream is written/read in place (no stringstream double copy).
 #include "spz_amd_host.hpp"
 
+#include <dlfcn.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -258,16 +259,177 @@ bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out
 }
 
 // ---- opt-in parallel gzip ---------------------------------------------------------
-// zlib is ~87 % of an end-to-end saveSpz.  This is the pigz construction: the input is
-// cut into blocks, every block is deflated independently (raw deflate, primed with the last 32 KiB of
-// the previous block as dictionary, ended on a byte boundary with Z_SYNC_FLUSH; the last one with
-// Z_FINISH), and the pieces are concatenated inside ONE gzip member whose CRC-32 is folded together
-// with crc32_combine.  Any gzip reader, the reference's loadSpz included, reads the result; the bytes
-// differ from single-stream deflate, so it is used only when asked for (threads > 1).
+// zlib is ~87 % of an end-to-end saveSpz.  This is pigz's "independent blocks"
+// construction: the input is cut into blocks, every block is deflated on its own (raw deflate, ended
+// on a byte boundary with Z_SYNC_FLUSH; the last one with Z_FINISH), and the pieces are concatenated
+// inside ONE gzip member whose CRC-32 is folded together with crc32_combine.  Any gzip reader, the
+// reference's loadSpz included, reads the result; the bytes differ from single-stream deflate, so it
+// is used only when asked for (threads > 1).  The member's header carries an FEXTRA subfield "SZ"
+// (RFC 1952 §2.3.1.1; readers that do not know it skip it) listing the compressed size of every piece,
+// which is what lets decompressGzipped below inflate the pieces concurrently.
+namespace {
+
+constexpr uint8_t kIndexId1 = 'S', kIndexId2 = 'Z';
+constexpr uint32_t kIndexVersion = 1;
+
+struct GzipIndex {
+  uint32_t blockBytes = 0;            // uncompressed bytes per piece (the last may be shorter)
+  uint64_t totalBytes = 0;            // uncompressed size of the member
+  std::vector<uint32_t> pieceBytes;   // compressed size of every piece
+};
+
+void putLe(std::vector<uint8_t> *v, uint64_t x, int bytes) {
+  for (int k = 0; k < bytes; ++k) v->push_back(static_cast<uint8_t>(x >> (8 * k)));
+}
+uint64_t getLe(const uint8_t *p, int bytes) {
+  uint64_t x = 0;
+  for (int k = 0; k < bytes; ++k) x |= static_cast<uint64_t>(p[k]) << (8 * k);
+  return x;
+}
+
+// Walks a gzip member header (RFC 1952 §2.3).  Returns its length, 0 if it is not one; fills *idx when
+// an "SZ" subfield of the known version is present.
+size_t parseGzipHeader(const uint8_t *p, size_t n, GzipIndex *idx) {
+  if (n < 18 || p[0] != 0x1f || p[1] != 0x8b || p[2] != 8 || (p[3] & 0xe0)) return 0;
+  const uint8_t flg = p[3];
+  size_t pos = 10;
+  if (flg & 4) {  // FEXTRA
+    if (pos + 2 > n) return 0;
+    const size_t xlen = getLe(p + pos, 2);
+    pos += 2;
+    if (pos + xlen > n) return 0;
+    size_t q = pos;
+    while (q + 4 <= pos + xlen) {
+      const size_t len = getLe(p + q + 2, 2);
+      if (q + 4 + len > pos + xlen) break;
+      const uint8_t *d = p + q + 4;
+      if (p[q] == kIndexId1 && p[q + 1] == kIndexId2 && len >= 20 && getLe(d, 4) == kIndexVersion) {
+        const uint64_t nb = getLe(d + 16, 4);
+        if (20 + 4 * nb == len) {
+          idx->blockBytes = static_cast<uint32_t>(getLe(d + 4, 4));
+          idx->totalBytes = getLe(d + 8, 8);
+          idx->pieceBytes.resize(nb);
+          for (uint64_t i = 0; i < nb; ++i) idx->pieceBytes[i] = static_cast<uint32_t>(getLe(d + 20 + 4 * i, 4));
+        }
+      }
+      q += 4 + len;
+    }
+    pos += xlen;
+  }
+  for (int f = 8; f <= 16; f <<= 1) {  // FNAME, FCOMMENT: zero-terminated
+    if (flg & f) {
+      while (pos < n && p[pos] != 0) ++pos;
+      if (pos >= n) return 0;
+      ++pos;
+    }
+  }
+  if (flg & 2) pos += 2;  // FHCRC
+  return pos + 8 <= n ? pos : 0;
+}
+
+int gunzipThreads(size_t pieces) {
+  const char *e = std::getenv("SPZ_AMD_GUNZIP_THREADS");
+  size_t t = e ? static_cast<size_t>(std::max(1, std::atoi(e))) : std::min<size_t>(std::thread::hardware_concurrency(), 32);
+  return static_cast<int>(std::max<size_t>(1, std::min(t, pieces)));
+}
+
+// Inflates the pieces of an indexed member concurrently, straight into their final positions.  Every
+// size, the CRC-32 and ISIZE are checked; on ANY inconsistency the caller falls back to the serial
+// reader, which is the authority on what is and is not a valid gzip file.
+bool inflateIndexed(const uint8_t *p, size_t n, size_t headerLen, const GzipIndex &idx, std::vector<uint8_t> *out) {
+  const size_t nb = idx.pieceBytes.size();
+  if (nb == 0 || idx.blockBytes == 0) return false;
+  if ((idx.totalBytes + idx.blockBytes - 1) / idx.blockBytes != nb) return false;
+  std::vector<size_t> off(nb + 1, headerLen);
+  for (size_t i = 0; i < nb; ++i) off[i + 1] = off[i] + idx.pieceBytes[i];
+  if (off[nb] + 8 != n) return false;  // exactly one member, nothing after it
+  if (idx.totalBytes > (n - headerLen) * 1032 + 1024) return false;  // beyond deflate's maximum expansion
+  out->resize(idx.totalBytes);
+  std::vector<uLong> crcs(nb);
+  std::atomic<size_t> next{0};
+  std::atomic<bool> failed{false};
+  auto worker = [&]() {
+    for (;;) {
+      const size_t b = next.fetch_add(1);
+      if (b >= nb || failed.load()) return;
+      const size_t uoff = b * static_cast<size_t>(idx.blockBytes);
+      const size_t ulen = std::min<size_t>(idx.blockBytes, idx.totalBytes - uoff);
+      z_stream zs = {};
+      if (inflateInit2(&zs, -MAX_WBITS) != Z_OK) {
+        failed = true;
+        return;
+      }
+      zs.next_in = const_cast<Bytef *>(p + off[b]);
+      zs.avail_in = idx.pieceBytes[b];
+      zs.next_out = out->data() + uoff;
+      zs.avail_out = static_cast<uInt>(ulen);
+      int rc = inflate(&zs, Z_SYNC_FLUSH);
+      if (rc == Z_OK && zs.avail_in > 0) rc = inflate(&zs, Z_SYNC_FLUSH);  // the empty stored block after a full buffer
+      const bool last = (b + 1 == nb);
+      const bool ok = zs.total_out == ulen && zs.avail_in == 0 && (last ? rc == Z_STREAM_END : (rc == Z_OK || rc == Z_BUF_ERROR));
+      inflateEnd(&zs);
+      if (!ok) {
+        failed = true;
+        return;
+      }
+      crcs[b] = crc32(crc32(0L, Z_NULL, 0), out->data() + uoff, static_cast<uInt>(ulen));
+    }
+  };
+  std::vector<std::thread> pool;
+  const int nt = gunzipThreads(nb);
+  for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto &t : pool) t.join();
+  if (failed) return false;
+  uLong crc = crc32(0L, Z_NULL, 0);
+  for (size_t b = 0; b < nb; ++b) {
+    const size_t ulen = std::min<size_t>(idx.blockBytes, idx.totalBytes - b * static_cast<size_t>(idx.blockBytes));
+    crc = crc32_combine(crc, crcs[b], static_cast<z_off_t>(ulen));
+  }
+  return getLe(p + n - 8, 4) == static_cast<uint32_t>(crc) && getLe(p + n - 4, 4) == (idx.totalBytes & 0xffffffffu);
+}
+
+// libdeflate (a whole-buffer inflater, about twice zlib's speed) is used when the system has it; it is
+// looked up at run time so that nothing depends on it being there.  SPZ_AMD_NO_LIBDEFLATE=1 disables it.
+struct LibDeflate {
+  void *(*alloc)() = nullptr;
+  int (*gunzip)(void *, const void *, size_t, void *, size_t, size_t *) = nullptr;
+  void (*release)(void *) = nullptr;
+  LibDeflate() {
+    const char *e = std::getenv("SPZ_AMD_NO_LIBDEFLATE");
+    if (e && std::atoi(e) != 0) return;
+    void *h = dlopen("libdeflate.so.0", RTLD_NOW | RTLD_LOCAL);
+    if (!h) return;
+    alloc = reinterpret_cast<void *(*)()>(dlsym(h, "libdeflate_alloc_decompressor"));
+    gunzip = reinterpret_cast<int (*)(void *, const void *, size_t, void *, size_t, size_t *)>(
+        dlsym(h, "libdeflate_gzip_decompress"));
+    release = reinterpret_cast<void (*)(void *)>(dlsym(h, "libdeflate_free_decompressor"));
+    if (!alloc || !gunzip || !release) alloc = nullptr;
+  }
+  bool usable() const { return alloc != nullptr; }
+};
+
+bool inflateWholeBuffer(const uint8_t *p, size_t n, std::vector<uint8_t> *out) {
+  static const LibDeflate lib;
+  if (!lib.usable()) return false;
+  const uint64_t isize = getLe(p + n - 4, 4);  // mod 2^32; a mismatch sends the caller to the serial reader
+  if (isize == 0 || isize > n * 1032 + 1024) return false;
+  void *d = lib.alloc();
+  if (!d) return false;
+  out->resize(isize);
+  size_t got = 0;
+  const int rc = lib.gunzip(d, p, n, out->data(), out->size(), &got);
+  lib.release(d);
+  return rc == 0 && got == isize;
+}
+
+}  // namespace
+
 bool compressGzippedParallel(const uint8_t *data, size_t size, std::vector<uint8_t> *out, int threads) {
   if (threads <= 1 || size < (1u << 20)) return compressGzipped(data, size, out);
-  constexpr size_t kBlock = size_t(1) << 20;  // 1 MiB of input per deflate job
-  constexpr size_t kDict = 32768;
+  size_t blockBytes = size_t(1) << 20;  // 1 MiB of input per deflate job
+  while ((size + blockBytes - 1) / blockBytes > 16000) blockBytes <<= 1;  // the index must fit FEXTRA's 64 KiB
+  const size_t kBlock = blockBytes;
   const size_t nblocks = (size + kBlock - 1) / kBlock;
   std::vector<std::vector<uint8_t>> pieces(nblocks);
   std::vector<uLong> crcs(nblocks);
@@ -284,7 +446,6 @@ bool compressGzippedParallel(const uint8_t *data, size_t size, std::vector<uint8
         failed = true;
         return;
       }
-      if (b > 0) deflateSetDictionary(&zs, data + off - kDict, static_cast<uInt>(kDict));  // kBlock > kDict
       buf.resize(deflateBound(&zs, static_cast<uLong>(len)) + 16);
       zs.next_in = const_cast<Bytef *>(data + off);
       zs.avail_in = static_cast<uInt>(len);
@@ -304,26 +465,46 @@ bool compressGzippedParallel(const uint8_t *data, size_t size, std::vector<uint8
   for (int t = 0; t < nt; ++t) pool.emplace_back(worker);
   for (auto &t : pool) t.join();
   if (failed) return false;
-  size_t total = 10 + 8;
+  const size_t indexBytes = 20 + 4 * nblocks;
+  size_t total = 10 + 2 + 4 + indexBytes + 8;
   for (const auto &p : pieces) total += p.size();
   out->clear();
   out->reserve(total);
-  // the 10-byte gzip header zlib itself writes: magic, deflate, no flags, mtime 0, xfl 0, OS 3 (Unix)
-  const uint8_t header[10] = {0x1f, 0x8b, 0x08, 0x00, 0, 0, 0, 0, 0x00, 0x03};
+  // zlib's own 10-byte header (magic, deflate, mtime 0, xfl 0, OS 3 = Unix) with FLG.FEXTRA set
+  const uint8_t header[10] = {0x1f, 0x8b, 0x08, 0x04, 0, 0, 0, 0, 0x00, 0x03};
   out->insert(out->end(), header, header + 10);
+  putLe(out, 4 + indexBytes, 2);  // XLEN
+  out->push_back(kIndexId1);
+  out->push_back(kIndexId2);
+  putLe(out, indexBytes, 2);
+  putLe(out, kIndexVersion, 4);
+  putLe(out, kBlock, 4);
+  putLe(out, size, 8);
+  putLe(out, nblocks, 4);
+  for (const auto &p : pieces) putLe(out, p.size(), 4);
   uLong crc = crc32(0L, Z_NULL, 0);
   for (size_t b = 0; b < nblocks; ++b) {
     out->insert(out->end(), pieces[b].begin(), pieces[b].end());
     crc = crc32_combine(crc, crcs[b], static_cast<z_off_t>(std::min(kBlock, size - b * kBlock)));
   }
-  const uint32_t tail[2] = {static_cast<uint32_t>(crc), static_cast<uint32_t>(size & 0xffffffffu)};
-  for (uint32_t w : tail) {
-    for (int k = 0; k < 4; ++k) out->push_back(static_cast<uint8_t>(w >> (8 * k)));
-  }
+  putLe(out, static_cast<uint32_t>(crc), 4);
+  putLe(out, size & 0xffffffffu, 4);
   return true;
 }
 
+// gunzip (load-spz.cc:141-182).  Three readers with one result: members written by
+// compressGzippedParallel are inflated piece-parallel through their index; anything else goes through
+// libdeflate when the system has it; and the zlib loop the reference uses is the fallback for every
+// case the fast readers decline or fail on, so acceptance and rejection are exactly zlib's.
 bool decompressGzipped(const uint8_t *compressed, size_t size, std::vector<uint8_t> *out) {
+  if (compressed != nullptr) {
+    GzipIndex idx;
+    const size_t headerLen = parseGzipHeader(compressed, size, &idx);
+    if (headerLen != 0) {
+      if (!idx.pieceBytes.empty() && inflateIndexed(compressed, size, headerLen, idx, out)) return true;
+      if (inflateWholeBuffer(compressed, size, out)) return true;
+    }
+  }
   z_stream stream = {};
   // 16 | MAX_WBITS: gzip wrapper only (load-spz.cc:172).
   if (inflateInit2(&stream, 16 | MAX_WBITS) != Z_OK) return false;

@@ -1,6 +1,8 @@
 """Pins the CPU restatement against the REFERENCE's own compiled C++ (oracle/_ref/libspz_ref.so)
 on fresh random inputs.  Runs wherever that library exists (the build container, and the GPU box
 since the built .so travels); skipped otherwise — the committed golden vectors then carry the pin."""
+import os
+
 import numpy as np
 import pytest
 
@@ -86,7 +88,9 @@ def test_parallel_gzip_is_read_by_the_reference(reference):
     stream = reference.pack(c, n, deg, True, 6).tobytes()
     par = spz._compress_gzipped_parallel(stream, 4)
     one = spz._compress_gzipped(stream)
-    assert par != one and par[:10] == one[:10]
+    # same gzip member header as zlib's except FLG.FEXTRA: the piece index rides in subfield "SZ"
+    assert par != one and par[:3] == one[:3] and par[3] == 4 and par[4:10] == one[4:10]
+    assert par[12:14] == b"SZ" and int.from_bytes(par[10:12], "little") == 4 + int.from_bytes(par[14:16], "little")
     assert gzip.decompress(par) == stream and spz._decompress_gzipped(par) == stream
     a = reference.load_spz(np.frombuffer(par, np.uint8), n, deg, 7)
     b = reference.load_spz(np.frombuffer(one, np.uint8), n, deg, 7)
@@ -96,3 +100,75 @@ def test_parallel_gzip_is_read_by_the_reference(reference):
     # threads <= 1 and small inputs fall back to the reference-identical single stream
     assert spz._compress_gzipped_parallel(stream, 1) == one
     assert spz._compress_gzipped_parallel(stream[:1000], 8) == spz._compress_gzipped(stream[:1000])
+
+
+def test_gunzip_readers_agree_with_zlib(reference):
+    """decompressGzipped has three readers (piece-parallel through the "SZ" index, libdeflate, the
+    reference's zlib loop) and must return what zlib returns for every input: valid members from any
+    writer, members with other header fields, damaged indexes (the index is advisory), corrupt,
+    truncated and trailing bytes."""
+    import gzip
+    import subprocess
+    import sys
+    import zlib
+    import spz_amd.spz as spz
+    rng = np.random.default_rng(8)
+    raw = (rng.integers(0, 256, 5_300_017, dtype=np.uint16) >> 3).astype(np.uint8).tobytes()
+
+    def zlib_verdict(b):
+        # the reference's loop (load-spz.cc:141-182): success only when inflate reached Z_STREAM_END
+        d = zlib.decompressobj(31)
+        try:
+            out = d.decompress(b)
+        except zlib.error:
+            return None
+        return out if d.eof else None
+
+    par = spz._compress_gzipped_parallel(raw, 8)
+    one = spz._compress_gzipped(raw)
+    named = gzip.compress(raw, 6)                                  # python's writer: mtime set, XFL/OS differ
+    co = zlib.compressobj(9, zlib.DEFLATED, 31)
+    other = co.compress(raw) + co.flush()
+    cases = {"indexed": par, "single": one, "python": named, "level9": other}
+    # FNAME + FCOMMENT + FHCRC in front of the same deflate data
+    body = one[10:]
+    hdr = bytearray(one[:10]); hdr[3] = 0x08 | 0x10 | 0x02
+    hdr += b"scene.bin\0" + b"a comment\0"
+    hdr += (zlib.crc32(bytes(hdr)) & 0xffff).to_bytes(2, "little")
+    cases["fname_fcomment_fhcrc"] = bytes(hdr) + body
+    # damaged index: a piece size off by one, an impossible block size, a wrong total
+    for name, at, val in (("index_piece", 16 + 20, 1), ("index_block", 16 + 4, 0x40), ("index_total", 16 + 8, 3)):
+        b = bytearray(par); b[at] ^= val
+        cases[name] = bytes(b)
+    for name, b in list(cases.items()):
+        assert zlib_verdict(b) == raw, name
+    mid = bytearray(par); mid[len(mid) // 2] ^= 0x10
+    cases["corrupt_indexed"] = bytes(mid)
+    mid = bytearray(one); mid[len(mid) // 2] ^= 0x10
+    cases["corrupt_single"] = bytes(mid)
+    crc = bytearray(one); crc[-6] ^= 1
+    cases["bad_crc"] = bytes(crc)
+    isz = bytearray(par); isz[-1] ^= 1
+    cases["bad_isize_indexed"] = bytes(isz)
+    cases["truncated_indexed"] = par[:-9]
+    cases["truncated_single"] = one[: len(one) // 2]
+    cases["trailing_indexed"] = par + b"\0" * 7
+    cases["trailing_single"] = one + b"junk"
+    cases["two_members"] = one + one          # zlib's inflate stops after the first member (load-spz.cc:141-182)
+    cases["empty"] = b""
+    cases["header_only"] = one[:10]
+    cases["not_gzip"] = b"This is not a valid SPZ file"
+    for name, b in cases.items():
+        want = zlib_verdict(b)
+        got = spz._decompress_gzipped(b)
+        assert got == want, f"{name}: reader disagrees with zlib ({'accepts' if got is not None else 'rejects'})"
+    # the same through the zlib-only configuration (no libdeflate, one thread), in a fresh process
+    code = ("import sys, zlib, spz_amd.spz as spz\n"
+            "b = open(sys.argv[1], 'rb').read()\n"
+            "assert spz._decompress_gzipped(b) == zlib.decompressobj(31).decompress(b)\n")
+    import tempfile
+    with tempfile.NamedTemporaryFile(suffix=".gz") as f:
+        f.write(par); f.flush()
+        env = dict(os.environ, SPZ_AMD_NO_LIBDEFLATE="1", SPZ_AMD_GUNZIP_THREADS="1",
+                   PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        subprocess.run([sys.executable, "-c", code, f.name], check=True, env=env, timeout=120)
