@@ -16,7 +16,8 @@ pytestmark = pytest.mark.gpu
 def dev(cuda):
     from spz_amd import abi
     abi.load_library()
-    assert abi.load_library().spz_amd_device_count() >= 1
+    L = abi.load_library()
+    assert L.spz_amd_device_count() >= 1, f"hipGetDeviceCount failed: hipError {L.spz_amd_last_hip_error()}"
     return cuda
 
 
