@@ -14,3 +14,33 @@ Layout:
 Nothing here falls back to the CPU: without libspz_amd.so or a HIP device, calls raise.
 """
 __version__ = "0.1.0"
+
+
+def _share_hip_runtime_with_torch():
+    """One HIP runtime per process.  PyTorch-ROCm wheels carry their own libamdhip64.so (SONAME
+    libamdhip64.so.7) and look it up by FILE name, libspz_amd.so asks for the SONAME: loaded after
+    torch it binds to torch's copy, loaded BEFORE torch the process would end up with two runtimes,
+    and the second one to initialise finds no device (hipErrorNoDevice).  So, when a torch with a
+    bundled runtime is installed, that copy is mapped first — without importing torch; either import
+    order then works.  Without torch the system runtime in libspz_amd.so's RUNPATH is used."""
+    import ctypes
+    import importlib.util
+    import os
+    import sys
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if spec is None or not spec.origin:
+        return
+    path = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(path):
+        try:
+            ctypes.CDLL(path, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
+_share_hip_runtime_with_torch()

@@ -310,3 +310,31 @@ def test_timing_bounds_of_the_reference_suite(spz, tmp_path):
     t0 = time.time()
     d = spz.load_spz(f, spz.UnpackOptions())
     assert time.time() - t0 < 5.0 and d.num_points == n
+
+
+@pytest.mark.parametrize("order", ["module_first", "torch_first"])
+def test_one_hip_runtime_whatever_the_import_order(spz, order):
+    """PyTorch-ROCm bundles its own libamdhip64; a process that mapped the system copy first (through
+    libspz_amd.so) and torch's second had two runtimes and the later one saw no device.  Both orders
+    must work, in a fresh process each."""
+    import subprocess
+    import sys
+    first, second = ("import spz_amd.spz as spz", "import torch") if order == "module_first" else \
+                    ("import torch", "import spz_amd.spz as spz")
+    code = "\n".join([
+        first, second,
+        "import numpy as np, os",
+        "from spz_amd import abi",
+        "assert torch.cuda.is_available()",
+        "L = abi.load_library()",
+        "assert L.spz_amd_device_count() >= 1, L.spz_amd_last_hip_error()",
+        "x = torch.arange(8, device='cuda').sum().item(); assert x == 28",
+        "c = spz.GaussianCloud(); c.positions = np.zeros(3); c.scales = np.zeros(3)",
+        "c.rotations = np.array([0, 0, 0, 1.0]); c.alphas = np.zeros(1); c.colors = np.zeros(3)",
+        "b = spz._save_spz_bytes(c, spz.PackOptions()); assert spz._load_spz_bytes(b, spz.UnpackOptions()).num_points == 1",
+        "maps = {l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}",
+        "assert len(maps) == 1, maps",
+    ])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
