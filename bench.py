@@ -59,6 +59,66 @@ def algorithmic_bytes_per_point(sh_degree, version):
     return (14 + d) * 4 + packed
 
 
+def cpu_shard_child(argv):
+    """Child of cpu_all_cores: one host process, one shard, the reference's pack+unpack; never touches the GPU."""
+    per, deg, frm, to, seed, tmp, idx = int(argv[0]), int(argv[1]), int(argv[2]), int(argv[3]), int(argv[4]), argv[5], argv[6]
+    from oracle.pyoracle import Reference
+    from spz_amd.synth import make_cloud_numpy
+    R = Reference()
+    c = make_cloud_numpy(per, deg, seed)
+    R.bench_pack_unpack(c, min(per, 1000), deg, frm, to)          # page the library in
+    open(os.path.join(tmp, f"ready.{idx}"), "w").close()
+    go = os.path.join(tmp, "go")
+    deadline = time.monotonic() + 300
+    while not os.path.exists(go):
+        if time.monotonic() > deadline:
+            return 3
+        time.sleep(0.002)
+    t0 = time.perf_counter()
+    tp, tu, _ = R.bench_pack_unpack(c, per, deg, frm, to)
+    print(json.dumps({"wall": time.perf_counter() - t0, "pack": tp, "unpack": tu}), flush=True)
+    return 0
+
+
+def cpu_all_cores(m, sh_degree, frm, to):
+    import shutil
+    import tempfile
+    procs = max(1, min(16, os.cpu_count() or 1))
+    per = m // procs
+    if procs < 2 or per < 1000:
+        return None
+    tmp = tempfile.mkdtemp(prefix="spz_cpu_shards_")
+    kids = []
+    try:
+        for t in range(procs):
+            kids.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-shard-child", str(per),
+                                          str(sh_degree), str(frm), str(to), str(1000 + t), tmp, str(t)],
+                                         stdout=subprocess.PIPE, text=True, cwd=ROOT,
+                                         env=dict(os.environ, SPZ_AMD_NO_HIP_PRELOAD="1")))
+        deadline = time.monotonic() + 300
+        while sum(os.path.exists(os.path.join(tmp, f"ready.{t}")) for t in range(procs)) < procs:
+            if time.monotonic() > deadline or any(k.poll() is not None for k in kids):
+                raise RuntimeError("a shard process did not get ready")
+            time.sleep(0.01)
+        open(os.path.join(tmp, "go"), "w").close()
+        walls = []
+        for k in kids:
+            out, _ = k.communicate(timeout=600)
+            if k.returncode != 0:
+                raise RuntimeError("a shard process failed")
+            walls.append(json.loads(out.strip().splitlines()[-1])["wall"])
+        return {"value": per * procs / max(walls), "unit": "Gaussians/s", "cores": procs,
+                "sample": f"{procs} processes x {per} Gaussians each (same distributions, seeds 1000..), pack+unpack, "
+                          f"slowest {max(walls):.2f} s, fastest {min(walls):.2f} s"}
+    except (OSError, RuntimeError, ValueError, subprocess.SubprocessError) as e:
+        return {"value": None, "error": str(e)}
+    finally:
+        for k in kids:
+            if k.poll() is None:
+                k.kill()
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def cpu_baseline(cloud_t, n, sh_degree, frm, to, sample_points, gpu_stream_fn, gpu_decoded_bit_sums_fn=None):
     """Times the reference C++ (or the C port) on one host core over the same synthetic points and
     checks that what was timed produced the same bytes as the GPU path."""
@@ -86,6 +146,9 @@ def cpu_baseline(cloud_t, n, sh_degree, frm, to, sample_points, gpu_stream_fn, g
         t2 = time.perf_counter()
         t_pack, t_unpack = t1 - t0, t2 - t1
     parity = bool(stream.size == gpu_stream.size and np.array_equal(stream, gpu_stream))
+    # the "all cores" figure — the same reference code over P independent point-range shards
+    # in P processes at once (no code change to it), P = this box's CPU share for one GPU.
+    all_cores = cpu_all_cores(m, sh_degree, frm, to) if kind == "reference" else None
     return {
         "value": m / (t_pack + t_unpack),
         "unit": "Gaussians/s",
@@ -98,10 +161,13 @@ def cpu_baseline(cloud_t, n, sh_degree, frm, to, sample_points, gpu_stream_fn, g
         "unpack_gaussians_per_s": m / t_unpack,
         "stream_bit_identical_to_gpu": parity,
         "decoded_bit_sums_identical_to_gpu": decoded_identical,
+        "all_cores": all_cores,
     }
 
 
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-shard-child":
+        sys.exit(cpu_shard_child(sys.argv[2:]))
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 and world == 1:

@@ -27,7 +27,7 @@ def _share_hip_runtime_with_torch():
     import importlib.util
     import os
     import sys
-    if "torch" in sys.modules:
+    if "torch" in sys.modules or os.environ.get("SPZ_AMD_NO_HIP_PRELOAD"):   # host-only helper processes
         return
     try:
         spec = importlib.util.find_spec("torch")
