@@ -173,6 +173,12 @@ int spz_amd_decode_host(const uint8_t *h_stream, size_t size, int to_coord,
 int spz_amd_convert_coordinates_host(float *h_positions, float *h_rotations, float *h_sh,
                                      uint64_t num_points, int sh_degree, int from_coord,
                                      int to_coord, int device);
+/* Host form of spz_amd_decode_gather_device: the packed stream and the index list are in host memory,
+ * the `count` decoded points land in host arrays.  The header is read from the stream with the checks
+ * of spz_amd_peek_header_ex(max_points). */
+int spz_amd_decode_gather_host(const uint8_t *h_stream, size_t size, uint64_t max_points,
+                               const uint32_t *h_indices, uint64_t count, int to_coord,
+                               const spz_amd_cloud_out *h_cloud, int device);
 
 /* ---- .ply vertex rows <-> GaussianCloud arrays (the step on the far side of
  *      the hot path).  A binary-LE 3DGS .ply stores one row of `property float` columns per

@@ -22,6 +22,8 @@
 #include <string>
 #include <vector>
 
+#include "spz_amd_c_types.h"
+
 namespace spz {
 
 // splat-types.h:24-34
@@ -65,9 +67,43 @@ struct GaussianCloud {
   void rotate180DegAboutX() { convertCoordinates(CoordinateSystem::RUB, CoordinateSystem::RDF); }
   // splat-types.h:170-185 (host utility, not on the hot path).
   float medianVolume() const;
+  // splat-types.h:117-130: copies of the six arrays in new float[] buffers the CALLER frees.
+  GaussianCloudData data() const;
 };
 
-// load-spz.h:42-59.  at()/unpack(i) random access is out of scope.
+// load-spz.h:11-22: one inflated Gaussian (236 bytes).
+struct UnpackedGaussian {
+  std::array<float, 3> position;  // x, y, z
+  std::array<float, 4> rotation;  // x, y, z, w
+  std::array<float, 3> scale;     // log scale
+  std::array<float, 3> color;     // rgb sh0 encoding
+  float alpha;                    // inverse logistic
+  std::array<float, 15> shR;
+  std::array<float, 15> shG;
+  std::array<float, 15> shB;
+};
+
+// load-spz.h:24-38: one packed Gaussian, always 65 bytes (missing sh coefficients are 128 = 0.0).
+struct PackedGaussian {
+  std::array<uint8_t, 9> position{};
+  std::array<uint8_t, 4> rotation{};
+  std::array<uint8_t, 3> scale{};
+  std::array<uint8_t, 3> color{};
+  uint8_t alpha = 0;
+  std::array<uint8_t, 15> shR{};
+  std::array<uint8_t, 15> shG{};
+  std::array<uint8_t, 15> shB{};
+
+  // load-spz.cc:383-431.  Runs the decode kernel on this one point (a 1-point stream through
+  // spz_amd_decode_host): bit-identical to the reference, but a device round trip per call — use
+  // unpackIndices / spz_amd_decode_gather_* for more than a handful of points.  `c` must be a table
+  // that coordinateConverter() can produce (every from/to pair is; hand-edited tables are rejected
+  // with a log line and a zeroed result).
+  UnpackedGaussian unpack(bool usesFloat16, bool usesQuaternionSmallestThree, int32_t fractionalBits,
+                          const CoordinateConverter &c) const;
+};
+
+// load-spz.h:42-59.
 struct PackedGaussians {
   int32_t numPoints = 0;
   int32_t shDegree = 0;
@@ -82,6 +118,8 @@ struct PackedGaussians {
   std::vector<uint8_t> sh;
 
   bool usesFloat16() const;  // load-spz.cc:465
+  PackedGaussian at(int32_t i) const;                                         // load-spz.cc:433-459 (bytes only)
+  UnpackedGaussian unpack(int32_t i, const CoordinateConverter &c) const;     // load-spz.cc:461-463
 };
 
 // load-spz.h:61-67
@@ -124,6 +162,11 @@ bool decompressGzipped(const uint8_t *compressed, size_t size, std::vector<uint8
 // gzip member, their sizes listed in an FEXTRA subfield "SZ" that other readers skip).  Readable by
 // every gzip reader including the reference's loadSpz, NOT byte-identical to compressGzipped.  saveSpz uses it when the environment sets SPZ_AMD_GZIP_THREADS > 1.
 bool compressGzippedParallel(const uint8_t *data, size_t size, std::vector<uint8_t> *out, int threads);
+// Bulk random access: the points `indices` of a packed cloud, decoded by one gather
+// launch into a GaussianCloud of indices.size() points (same arithmetic as unpackGaussians; indices
+// past the end are clamped to the last point).  Empty cloud on failure.
+GaussianCloud unpackIndices(const PackedGaussians &packed, const std::vector<uint32_t> &indices,
+                            const UnpackOptions &o);
 // Raw (pre-gzip) stream <-> cloud, i.e. saveSpz / loadSpz without the zlib step.
 bool packToStream(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream);
 GaussianCloud unpackFromStream(const uint8_t *stream, size_t size, const UnpackOptions &o);

@@ -273,6 +273,21 @@ class Reference:
         out.update(num_points=info[0], sh_degree=info[1], sh_size=info[2])
         return out
 
+    def packed_unpack(self, stream, indices, from_coord, to_coord):
+        """PackedGaussians::at(i) bytes [count,65] and ::unpack(i, converter) floats [count,59] of a raw stream."""
+        stream = np.ascontiguousarray(stream, np.uint8)
+        idx = np.ascontiguousarray(indices, np.int32)
+        b = np.zeros((idx.size, 65), np.uint8)
+        f = np.zeros((idx.size, 59), np.float32)
+        self.lib.ref_packed_unpack.restype = C.c_int
+        self.lib.ref_packed_unpack.argtypes = [C.c_void_p, C.c_size_t, C.c_void_p, C.c_int32, C.c_int, C.c_int,
+                                               C.c_void_p, C.c_void_p]
+        rc = self.lib.ref_packed_unpack(stream.ctypes.data, stream.size, idx.ctypes.data, idx.size, from_coord,
+                                        to_coord, b.ctypes.data, f.ctypes.data)
+        if rc:
+            raise RuntimeError(f"ref_packed_unpack rc={rc}")
+        return b, f
+
     def bench_pack_unpack(self, cloud, n, deg, from_coord=0, to_coord=0, want_stream=False):
         arrs = [_f32(cloud[k]) for k in ("positions", "scales", "rotations", "alphas", "colors", "sh")]
         tp, tu = C.c_double(), C.c_double()

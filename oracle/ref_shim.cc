@@ -189,6 +189,43 @@ void ref_unpack_quat_first_three(const uint8_t *r, int32_t n, int to, float *out
 
 float ref_half_to_float(uint16_t h) { return spz::halfToFloat(h); }
 
+// deserializePackedGaussians on a raw stream, then PackedGaussians::at(i) and ::unpack(i, converter) for every
+// index: bytes65 gets 65 bytes per index (PackedGaussian field order), floats59 gets 59 floats per index
+// (UnpackedGaussian field order: position, rotation, scale, color, alpha, shR, shG, shB).
+int ref_packed_unpack(const uint8_t *stream, size_t size, const int32_t *indices, int32_t count, int from, int to,
+                      uint8_t *bytes65, float *floats59) {
+  std::stringstream ss(std::string(reinterpret_cast<const char *>(stream), size));
+  spz::PackedGaussians packed = spz::deserializePackedGaussians(ss);
+  if (packed.numPoints == 0) return -1;
+  const spz::CoordinateConverter c = spz::coordinateConverter(static_cast<spz::CoordinateSystem>(from),
+                                                              static_cast<spz::CoordinateSystem>(to));
+  for (int32_t k = 0; k < count; ++k) {
+    const int32_t i = indices[k];
+    if (i < 0 || i >= packed.numPoints) return -2;
+    const spz::PackedGaussian one = packed.at(i);
+    uint8_t *b = bytes65 + static_cast<size_t>(k) * 65;
+    std::memcpy(b, one.position.data(), 9);
+    std::memcpy(b + 9, one.rotation.data(), 4);
+    std::memcpy(b + 13, one.scale.data(), 3);
+    std::memcpy(b + 16, one.color.data(), 3);
+    b[19] = one.alpha;
+    std::memcpy(b + 20, one.shR.data(), 15);
+    std::memcpy(b + 35, one.shG.data(), 15);
+    std::memcpy(b + 50, one.shB.data(), 15);
+    const spz::UnpackedGaussian u = packed.unpack(i, c);
+    float *f = floats59 + static_cast<size_t>(k) * 59;
+    std::memcpy(f, u.position.data(), 12);
+    std::memcpy(f + 3, u.rotation.data(), 16);
+    std::memcpy(f + 7, u.scale.data(), 12);
+    std::memcpy(f + 10, u.color.data(), 12);
+    f[13] = u.alpha;
+    std::memcpy(f + 14, u.shR.data(), 60);
+    std::memcpy(f + 29, u.shG.data(), 60);
+    std::memcpy(f + 44, u.shB.data(), 60);
+  }
+  return 0;
+}
+
 // saveSplatToPly / loadSplatFromPly through real files (the reference has no in-memory form).
 int ref_save_ply(const float *pos, const float *scales, const float *rot, const float *alphas,
                  const float *colors, const float *sh, int32_t n, int shDegree, int from, const char *filename) {

@@ -35,7 +35,8 @@ EXPORTS = (
     "spz_amd_stream_layout", "spz_amd_write_header", "spz_amd_peek_header", "spz_amd_peek_header_ex",
     "spz_amd_peek_header_device",
     "spz_amd_encode_device", "spz_amd_decode_device", "spz_amd_encode_shard_device",
-    "spz_amd_decode_shard_device", "spz_amd_decode_gather_device", "spz_amd_convert_coordinates_device",
+    "spz_amd_decode_shard_device", "spz_amd_decode_gather_device", "spz_amd_decode_gather_host",
+    "spz_amd_convert_coordinates_device",
     "spz_amd_encode_host",
     "spz_amd_decode_host", "spz_amd_convert_coordinates_host", "spz_amd_get_tables",
     "spz_amd_ply_default_columns", "spz_amd_ply_rows_to_cloud_device", "spz_amd_cloud_to_ply_rows_device",
@@ -151,6 +152,8 @@ def bind(L):
     L.spz_amd_decode_shard_device.argtypes = [vp, sz, C.POINTER(Header), u64, u64, i32, C.POINTER(CloudPtrs), vp]
     L.spz_amd_decode_gather_device.restype = i32
     L.spz_amd_decode_gather_device.argtypes = [vp, sz, C.POINTER(Header), vp, u64, i32, C.POINTER(CloudPtrs), vp]
+    L.spz_amd_decode_gather_host.restype = i32
+    L.spz_amd_decode_gather_host.argtypes = [vp, sz, u64, vp, u64, i32, C.POINTER(CloudPtrs), i32]
     L.spz_amd_convert_coordinates_device.restype = i32
     L.spz_amd_convert_coordinates_device.argtypes = [vp, vp, vp, u64, i32, i32, i32, vp]
     L.spz_amd_encode_host.restype = i32

@@ -674,6 +674,49 @@ int spz_amd_decode_host(const uint8_t *h_stream, size_t size, int to_coord, cons
   return SPZ_AMD_OK;
 }
 
+int spz_amd_decode_gather_host(const uint8_t *h_stream, size_t size, uint64_t max_points, const uint32_t *h_indices,
+                               uint64_t count, int to_coord, const spz_amd_cloud_out *h, int device) {
+  if (h_stream == nullptr || h == nullptr || !valid_coord(to_coord)) return SPZ_AMD_ERR_INVALID_ARG;
+  spz_amd_header hdr;
+  int rc = spz_amd_peek_header_ex(h_stream, size, max_points, &hdr);
+  if (rc != SPZ_AMD_OK) return rc;
+  spz_amd_layout lay;
+  rc = layout_impl(hdr.num_points, hdr.sh_degree, (int)hdr.version, &lay);
+  if (rc != SPZ_AMD_OK) return rc;
+  if (size < lay.total_bytes) return SPZ_AMD_ERR_SHORT_STREAM;
+  if (count == 0) return SPZ_AMD_OK;
+  const int sd = sh_dim_for_degree(hdr.sh_degree);
+  if (hdr.num_points == 0 || h_indices == nullptr || !h->positions || !h->scales || !h->rotations || !h->alphas ||
+      !h->colors || (sd > 0 && !h->sh)) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  DeviceGuard guard;
+  rc = guard.enter(device);
+  if (rc != SPZ_AMD_OK) return rc;
+  const size_t cnt[6] = {count * 3, count * 3, count * 4, count, count * 3, count * (size_t)sd * 3};
+  float *dst[6] = {h->positions, h->scales, h->rotations, h->alphas, h->colors, h->sh};
+  size_t total = Workspace::aligned(lay.total_bytes) + Workspace::aligned(count * sizeof(uint32_t));
+  for (int i = 0; i < 6; ++i) total += Workspace::aligned(cnt[i] * sizeof(float));
+  Workspace ws;
+  rc = ws.open(device, total);
+  if (rc != SPZ_AMD_OK) return rc;
+  void *sb = ws.take(lay.total_bytes);
+  SPZ_HIP_TRY(hipMemcpyAsync(sb, h_stream, lay.total_bytes, hipMemcpyHostToDevice, nullptr));
+  void *ib = ws.take(count * sizeof(uint32_t));
+  SPZ_HIP_TRY(hipMemcpyAsync(ib, h_indices, count * sizeof(uint32_t), hipMemcpyHostToDevice, nullptr));
+  void *fb[6];
+  for (int i = 0; i < 6; ++i) fb[i] = ws.take(cnt[i] * sizeof(float));
+  spz_amd_cloud_out d = {(float *)fb[0], (float *)fb[1], (float *)fb[2], (float *)fb[3], (float *)fb[4], (float *)fb[5]};
+  rc = spz_amd_decode_gather_device((const uint8_t *)sb, lay.total_bytes, &hdr, (const uint32_t *)ib, count, to_coord, &d,
+                                    nullptr);
+  if (rc != SPZ_AMD_OK) return rc;
+  for (int i = 0; i < 6; ++i) {
+    if (cnt[i]) SPZ_HIP_TRY(hipMemcpyAsync(dst[i], fb[i], cnt[i] * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+  }
+  SPZ_HIP_TRY(hipStreamSynchronize(nullptr));
+  return SPZ_AMD_OK;
+}
+
 int spz_amd_convert_coordinates_host(float *h_positions, float *h_rotations, float *h_sh, uint64_t n,
                                      int sh_degree, int from_coord, int to_coord, int device) {
   const int sd = sh_dim_for_degree(sh_degree);

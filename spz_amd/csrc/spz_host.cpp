@@ -216,6 +216,140 @@ float GaussianCloud::medianVolume() const {  // splat-types.h:170-185
   return static_cast<float>((M_PI * 4 / 3) * std::exp(median));
 }
 
+GaussianCloudData GaussianCloud::data() const {  // splat-types.h:14-22,117-130
+  auto copy = [](const std::vector<float> &v) {
+    SpzFloatBuffer b = {0, nullptr};
+    if (!v.empty()) {
+      b.count = v.size();
+      b.data = new float[b.count];
+      std::memcpy(b.data, v.data(), b.count * sizeof(float));
+    }
+    return b;
+  };
+  GaussianCloudData d;
+  d.numPoints = numPoints;
+  d.shDegree = shDegree;
+  d.antialiased = antialiased;
+  d.positions = copy(positions);
+  d.scales = copy(scales);
+  d.rotations = copy(rotations);
+  d.alphas = copy(alphas);
+  d.colors = copy(colors);
+  d.sh = copy(sh);
+  return d;
+}
+
+// ---- per-splat access, load-spz.cc:383-463 --------------------------------------------------------
+PackedGaussian PackedGaussians::at(int32_t i) const {  // byte moves only
+  PackedGaussian r;
+  const size_t k = static_cast<size_t>(i);
+  const size_t positionBytes = usesFloat16() ? 6 : 9;
+  std::copy_n(positions.data() + k * positionBytes, positionBytes, r.position.data());
+  std::copy_n(scales.data() + k * 3, 3, r.scale.data());
+  const size_t rotationBytes = usesQuaternionSmallestThree ? 4 : 3;
+  std::copy_n(rotations.data() + k * rotationBytes, rotationBytes, r.rotation.data());
+  std::copy_n(colors.data() + k * 3, 3, r.color.data());
+  r.alpha = alphas[k];
+  const size_t shDim = static_cast<size_t>(dimForDegree(shDegree));
+  const uint8_t *p = sh.data() + k * shDim * 3;
+  for (size_t j = 0; j < 15; ++j) {
+    const bool have = j < shDim;
+    r.shR[j] = have ? p[3 * j + 0] : 128;
+    r.shG[j] = have ? p[3 * j + 1] : 128;
+    r.shB[j] = have ? p[3 * j + 2] : 128;
+  }
+  return r;
+}
+
+UnpackedGaussian PackedGaussians::unpack(int32_t i, const CoordinateConverter &c) const {
+  return at(i).unpack(usesFloat16(), usesQuaternionSmallestThree, fractionalBits, c);
+}
+
+namespace {
+
+// The coordinate system X for which coordinateConverter(RUB, X) equals `c`, or -1 when `c` is not a
+// table coordinateConverter can produce.  (enum - 1: bit 0 = R, bit 1 = U, bit 2 = F; RUB = 0b011.)
+int targetSystemOf(const CoordinateConverter &c) {
+  for (float v : c.flipP) {
+    if (v != 1.0f && v != -1.0f) return -1;
+  }
+  const int bits = (c.flipP[0] > 0 ? 1 : 0) | (c.flipP[1] > 0 ? 2 : 0) | (c.flipP[2] > 0 ? 0 : 4);
+  const CoordinateSystem to = static_cast<CoordinateSystem>(bits + 1);
+  const CoordinateConverter want = coordinateConverter(CoordinateSystem::RUB, to);
+  if (want.flipP != c.flipP || want.flipQ != c.flipQ || want.flipSh != c.flipSh) return -1;
+  return static_cast<int>(to);
+}
+
+// One point as a complete SH3 stream: header + the six sections (load-spz.cc:540-545).
+size_t onePointStream(const PackedGaussian &g, uint32_t version, int32_t fractionalBits, uint8_t *out) {
+  spz_amd_header h = {};
+  h.version = version;
+  h.num_points = 1;
+  h.sh_degree = 3;
+  h.fractional_bits = static_cast<uint8_t>(fractionalBits);
+  spz_amd_write_header(&h, out);
+  uint8_t *p = out + 16;
+  const size_t positionBytes = version == 1 ? 6 : 9, rotationBytes = version >= 3 ? 4 : 3;
+  p = std::copy_n(g.position.data(), positionBytes, p);
+  *p++ = g.alpha;
+  p = std::copy_n(g.color.data(), 3, p);
+  p = std::copy_n(g.scale.data(), 3, p);
+  p = std::copy_n(g.rotation.data(), rotationBytes, p);
+  for (size_t j = 0; j < 15; ++j) {
+    *p++ = g.shR[j];
+    *p++ = g.shG[j];
+    *p++ = g.shB[j];
+  }
+  return static_cast<size_t>(p - out);
+}
+
+struct OnePoint {
+  float position[3], scale[3], rotation[4], alpha[1], color[3], sh[45];
+};
+
+bool decodeOnePoint(const PackedGaussian &g, uint32_t version, int32_t fractionalBits, int to, OnePoint *r) {
+  uint8_t stream[16 + 9 + 1 + 3 + 3 + 4 + 45];
+  const size_t size = onePointStream(g, version, fractionalBits, stream);
+  spz_amd_cloud_out out = {r->position, r->scale, r->rotation, r->alpha, r->color, r->sh};
+  return !deviceFailed(spz_amd_decode_host(stream, size, to, &out, deviceIndex()), "PackedGaussian::unpack");
+}
+
+}  // namespace
+
+UnpackedGaussian PackedGaussian::unpack(bool usesFloat16, bool usesQuaternionSmallestThree, int32_t fractionalBits,
+                                        const CoordinateConverter &c) const {
+  g_last_status = SPZ_AMD_OK;
+  UnpackedGaussian result = {};
+  const int to = targetSystemOf(c);
+  if (to < 0) {
+    logLine("[SPZ ERROR] spz_amd: PackedGaussian::unpack: the CoordinateConverter is not one coordinateConverter() makes");
+    g_last_status = SPZ_AMD_ERR_INVALID_ARG;
+    return result;
+  }
+  // stream versions: 1 = float16 positions + first-three rotations, 2 = 24-bit + first-three,
+  // 3 = 24-bit + smallest-three.  The fourth combination the signature allows (float16 with
+  // smallest-three, which no stream version encodes) takes positions from a v1 and the rest from a v3 decode.
+  OnePoint a;
+  const uint32_t version = usesQuaternionSmallestThree ? 3u : (usesFloat16 ? 1u : 2u);
+  if (!decodeOnePoint(*this, version, fractionalBits, to, &a)) return result;
+  if (usesFloat16 && usesQuaternionSmallestThree) {
+    OnePoint b;
+    if (!decodeOnePoint(*this, 1u, fractionalBits, to, &b)) return result;
+    std::copy_n(b.position, 3, a.position);
+  }
+  std::copy_n(a.position, 3, result.position.data());
+  std::copy_n(a.rotation, 4, result.rotation.data());
+  std::copy_n(a.scale, 3, result.scale.data());
+  std::copy_n(a.color, 3, result.color.data());
+  result.alpha = a.alpha[0];
+  for (size_t j = 0; j < 15; ++j) {
+    result.shR[j] = a.sh[3 * j + 0];
+    result.shG[j] = a.sh[3 * j + 1];
+    result.shB[j] = a.sh[3 * j + 2];
+  }
+  return result;
+}
+
 bool PackedGaussians::usesFloat16() const {  // load-spz.cc:465
   return positions.size() == static_cast<size_t>(numPoints) * 3 * 2;
 }
@@ -681,6 +815,48 @@ GaussianCloud unpackGaussians(const PackedGaussians &packed, const UnpackOptions
                            r.alphas.data(),    r.colors.data(), r.sh.empty() ? nullptr : r.sh.data()};
   const int rc = spz_amd_decode_host(stream.data(), stream.size(), static_cast<int>(o.to), &out, deviceIndex());
   if (deviceFailed(rc, "decode")) return {};
+  return r;
+}
+
+GaussianCloud unpackIndices(const PackedGaussians &packed, const std::vector<uint32_t> &indices,
+                            const UnpackOptions &o) {
+  g_last_status = SPZ_AMD_OK;
+  const int32_t shDim = dimForDegree(packed.shDegree);
+  const bool f16 = packed.usesFloat16();
+  if (!checkSizes(packed, packed.numPoints, shDim, f16)) return {};
+  GaussianCloud r;
+  r.shDegree = packed.shDegree;
+  r.antialiased = packed.antialiased;
+  if (indices.empty()) return r;
+  if (packed.numPoints == 0) {
+    logLine("[SPZ ERROR] spz_amd: unpackIndices: the packed cloud is empty");
+    return {};
+  }
+  spz_amd_header h = {};
+  h.version = f16 ? 1u : (packed.usesQuaternionSmallestThree ? 3u : 2u);
+  h.num_points = static_cast<uint32_t>(packed.numPoints);
+  h.sh_degree = static_cast<uint8_t>(packed.shDegree);
+  h.fractional_bits = static_cast<uint8_t>(packed.fractionalBits);
+  h.flags = packed.antialiased ? 1 : 0;
+  std::vector<uint8_t> stream(16);
+  spz_amd_write_header(&h, stream.data());
+  for (const auto *v : {&packed.positions, &packed.alphas, &packed.colors, &packed.scales, &packed.rotations,
+                        &packed.sh}) {
+    stream.insert(stream.end(), v->begin(), v->end());
+  }
+  const size_t n = indices.size();
+  r.numPoints = static_cast<int32_t>(n);
+  r.positions.resize(n * 3);
+  r.scales.resize(n * 3);
+  r.rotations.resize(n * 4);
+  r.alphas.resize(n);
+  r.colors.resize(n * 3);
+  r.sh.resize(n * shDim * 3);
+  spz_amd_cloud_out out = {r.positions.data(), r.scales.data(), r.rotations.data(),
+                           r.alphas.data(),    r.colors.data(), r.sh.empty() ? nullptr : r.sh.data()};
+  const int rc = spz_amd_decode_gather_host(stream.data(), stream.size(), 0, indices.data(), n, static_cast<int>(o.to),
+                                            &out, deviceIndex());
+  if (deviceFailed(rc, "unpackIndices")) return {};
   return r;
 }
 

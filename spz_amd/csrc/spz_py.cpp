@@ -9,8 +9,10 @@
 // arguments") is written out by hand in `toFloatVector`.
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
+#include <pybind11/stl.h>
 
 #include <cstring>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -245,6 +247,50 @@ PYBIND11_MODULE(spz, m) {
     if (g.numPoints == 0) raiseIfDeviceUnusable();
     return g;
   }, py::arg("data"), py::arg("options") = spz::UnpackOptions(), "loadSpz(ptr, size, options) from .spz bytes.");
+  m.def("_packed_unpack", [](const py::bytes &data, int32_t index, spz::CoordinateSystem from, spz::CoordinateSystem to,
+                              bool gzipped) -> py::object {
+    // loadSpzPacked (or deserializePackedGaussians for a raw stream) + PackedGaussians::at / unpack:
+    // returns (65 packed bytes, 59 floats) in the field order of PackedGaussian / UnpackedGaussian.
+    const std::string in = data;
+    spz::PackedGaussians packed;
+    if (gzipped) {
+      packed = spz::loadSpzPacked(reinterpret_cast<const uint8_t *>(in.data()), static_cast<int32_t>(in.size()));
+    } else {
+      std::istringstream ss(in);
+      packed = spz::deserializePackedGaussians(ss);
+    }
+    if (index < 0 || index >= packed.numPoints) return py::none();
+    spz::setLastDeviceStatus(SPZ_AMD_OK);
+    const spz::PackedGaussian one = packed.at(index);
+    const spz::UnpackedGaussian u = packed.unpack(index, spz::coordinateConverter(from, to));
+    raiseIfDeviceUnusable();
+    std::string b;
+    auto putb = [&](const uint8_t *p, size_t n) { b.append(reinterpret_cast<const char *>(p), n); };
+    putb(one.position.data(), 9); putb(one.rotation.data(), 4); putb(one.scale.data(), 3); putb(one.color.data(), 3);
+    putb(&one.alpha, 1); putb(one.shR.data(), 15); putb(one.shG.data(), 15); putb(one.shB.data(), 15);
+    std::vector<float> f;
+    auto putf = [&](const float *p, size_t n) { f.insert(f.end(), p, p + n); };
+    putf(u.position.data(), 3); putf(u.rotation.data(), 4); putf(u.scale.data(), 3); putf(u.color.data(), 3);
+    putf(&u.alpha, 1); putf(u.shR.data(), 15); putf(u.shG.data(), 15); putf(u.shB.data(), 15);
+    return py::make_tuple(py::bytes(b), toArray(f));
+  }, py::arg("data"), py::arg("index"), py::arg("from_coord"), py::arg("to_coord"), py::arg("gzipped") = true,
+     "PackedGaussians::at(i) bytes and PackedGaussians::unpack(i, coordinateConverter(from, to)) floats.");
+  m.def("_unpack_indices", [](const py::bytes &data, const std::vector<uint32_t> &indices, const spz::UnpackOptions &o,
+                               bool gzipped) {
+    const std::string in = data;
+    spz::PackedGaussians packed;
+    if (gzipped) {
+      packed = spz::loadSpzPacked(reinterpret_cast<const uint8_t *>(in.data()), static_cast<int32_t>(in.size()));
+    } else {
+      std::istringstream ss(in);
+      packed = spz::deserializePackedGaussians(ss);
+    }
+    spz::setLastDeviceStatus(SPZ_AMD_OK);
+    spz::GaussianCloud g = spz::unpackIndices(packed, indices, o);
+    if (g.numPoints == 0) raiseIfDeviceUnusable();
+    return g;
+  }, py::arg("data"), py::arg("indices"), py::arg("options") = spz::UnpackOptions(), py::arg("gzipped") = true,
+     "unpackIndices(loadSpzPacked(data), indices, options): one gather launch.");
   m.def("_pack_to_stream", [](const spz::GaussianCloud &g, const spz::PackOptions &o) -> py::object {
     std::vector<uint8_t> out;
     if (!spz::packToStream(g, o, &out)) {

@@ -1,5 +1,6 @@
 // A user program written against the REFERENCE's public C++ API only (load-spz.h / splat-types.h:
-// GaussianCloud, PackOptions, UnpackOptions, CoordinateSystem, saveSpz, loadSpz, convertCoordinates).
+// GaussianCloud incl. data(), PackOptions, UnpackOptions, CoordinateSystem, coordinateConverter, saveSpz,
+// loadSpz, loadSpzPacked, PackedGaussians::at / unpack, convertCoordinates).
 // It is compiled twice from this one source:
 //   * against /root/reference/src/cc (the reference itself)         -> expected output (golden)
 //   * against include/compat + libspz_host.so (this implementation) -> must print the same lines
@@ -58,6 +59,35 @@ int main() {
     spz::GaussianCloud back = spz::loadSpz(bytes, uo);
     std::printf("degree %d load points %d sh %d aa %d hash %016llx\n", degree, back.numPoints, back.shDegree,
                 back.antialiased ? 1 : 0, (unsigned long long)cloudHash(back));
+
+    // the C bridge view (caller frees) and per-splat access on the packed form
+    GaussianCloudData cd = back.data();
+    uint64_t dh = fnv(&cd.numPoints, sizeof(cd.numPoints));
+    for (const SpzFloatBuffer *b : {&cd.positions, &cd.scales, &cd.rotations, &cd.alphas, &cd.colors, &cd.sh}) {
+      dh = fnv(b->data, b->count * sizeof(float), dh);
+      delete[] b->data;
+    }
+    std::printf("degree %d data() counts %zu %zu %zu hash %016llx\n", degree, cd.positions.count, cd.rotations.count,
+                cd.sh.count, (unsigned long long)dh);
+    spz::PackedGaussians packed = spz::loadSpzPacked(bytes);
+    const spz::CoordinateConverter conv = spz::coordinateConverter(spz::CoordinateSystem::RUB, spz::CoordinateSystem::LDF);
+    uint64_t ph = 0, uh = 0;
+    for (int i : {0, 1, 777, n / 2, n - 1}) {
+      const spz::PackedGaussian one = packed.at(i);
+      ph = fnv(one.position.data(), 9, ph ? ph : 1469598103934665603ull);
+      ph = fnv(one.rotation.data(), 4, ph);
+      ph = fnv(&one.alpha, 1, ph);
+      ph = fnv(one.shR.data(), 15, fnv(one.shG.data(), 15, fnv(one.shB.data(), 15, ph)));
+      const spz::UnpackedGaussian u = packed.unpack(i, conv);
+      uh = fnv(u.position.data(), 12, uh ? uh : 1469598103934665603ull);
+      uh = fnv(u.rotation.data(), 16, uh);
+      uh = fnv(u.scale.data(), 12, uh);
+      uh = fnv(u.color.data(), 12, uh);
+      uh = fnv(&u.alpha, 4, uh);
+      uh = fnv(u.shR.data(), 60, fnv(u.shG.data(), 60, fnv(u.shB.data(), 60, uh)));
+    }
+    std::printf("degree %d packed points %d f16 %d at hash %016llx unpack hash %016llx\n", degree, packed.numPoints,
+                packed.usesFloat16() ? 1 : 0, (unsigned long long)ph, (unsigned long long)uh);
 
     back.convertCoordinates(spz::CoordinateSystem::LUF, spz::CoordinateSystem::RUB);
     back.rotate180DegAboutX();

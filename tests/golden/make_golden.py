@@ -19,6 +19,8 @@ Files (all numpy .npz, loaded with allow_pickle=False):
                     (including streams whose smallest-three sum exceeds 1 -> NaN).
   legacy.npz        v2 and v1 streams (header patched / float16 positions) and the
                     reference's decode of them.
+  persplat.npz      PackedGaussians::at(i) bytes and ::unpack(i, converter) floats for index sets of the
+                    clouds.npz / legacy.npz streams (v3 SH0..3, v2, v1, other fractionalBits), six converters.
   ply.npz           .ply files written by the reference's saveSplatToPly (from 0/4/7) and what its
                     loadSplatFromPly returned for them (to 0/4/7); a hand-made .ply with comments,
                     shuffled and extra properties.
@@ -383,12 +385,39 @@ def ply():
     np.savez_compressed(os.path.join(HERE, "ply.npz"), **out)
 
 
+def persplat():
+    """PackedGaussians::at(i) / ::unpack(i, converter) (load-spz.cc:383-463) on the streams of clouds.npz
+    (v3, SH0..3, edge values injected) and legacy.npz (v2 first-three, v1 float16): 65 packed bytes and
+    59 floats per index, for several from->to converters."""
+    out = {}
+    cl = np.load(os.path.join(HERE, "clouds.npz"))
+    lg = np.load(os.path.join(HERE, "legacy.npz"))
+    pairs = [(0, 0), (4, 6), (4, 1), (6, 7), (8, 3), (2, 5)]
+    out["pairs"] = np.array(pairs, np.int32)
+    streams = {f"d{deg}": cl[f"d{deg}_stream_from0"] for deg in range(4)}
+    streams["v2"] = lg["v2_stream"]
+    streams["v1"] = lg["v1_stream"]
+    for fb in (0, 8, 23):
+        streams[f"fb{fb}"] = lg[f"fb{fb}_stream"]
+    rng = np.random.default_rng(77)
+    for name, s in streams.items():
+        n = int(s[8]) | int(s[9]) << 8 | int(s[10]) << 16 | int(s[11]) << 24
+        idx = np.unique(np.concatenate([[0, 1, n - 1], rng.integers(0, n, 61)])).astype(np.int32)
+        out[f"{name}_indices"] = idx
+        for frm, to in pairs:
+            b, f = R.packed_unpack(s, idx, frm, to)
+            out[f"{name}_bytes"] = b
+            out[f"{name}_floats_{frm}_{to}"] = f
+    np.savez_compressed(os.path.join(HERE, "persplat.npz"), **out)
+
+
 if __name__ == "__main__":
     ply()
     kat_small()
     clouds()
     quats()
     legacy()
+    persplat()
     tables()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

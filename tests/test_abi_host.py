@@ -210,4 +210,18 @@ def test_argument_validation_happens_before_any_device_work(lib):
     bad.stride = 300
     assert lib.spz_amd_ply_rows_to_cloud_device(out.ctypes.data, n, C.byref(bad), 0, C.byref(good), None) == abi.ERR_INVALID_ARG
     assert lib.spz_amd_cloud_to_ply_rows_device(C.byref(good), n, 16, 0, out.ctypes.data, None) == abi.ERR_INVALID_ARG
+    # host gather: header checks of the stream, then arguments, then the device
+    hs = np.zeros(out.size, np.uint8)
+    assert lib.spz_amd_write_header(C.byref(hdr), hs.ctypes.data) == abi.OK
+    idx = np.array([0, 3], np.uint32)
+    gat = lambda stream=hs.ctypes.data, size=hs.size, ind=idx.ctypes.data, cnt=2, to=0, cloud=good: \
+        lib.spz_amd_decode_gather_host(stream, size, 0, ind, cnt, to, C.byref(cloud) if cloud is not None else None, 0)
+    assert gat(stream=None) == abi.ERR_INVALID_ARG
+    assert gat(cloud=None) == abi.ERR_INVALID_ARG
+    assert gat(to=12) == abi.ERR_INVALID_ARG
+    assert gat(size=10) == abi.ERR_HEADER_NOT_FOUND
+    assert gat(size=hs.size - 1) == abi.ERR_SHORT_STREAM
+    assert gat(cnt=0) == abi.OK
+    assert gat(ind=None) == abi.ERR_INVALID_ARG
+    assert gat(cloud=no_sh) == abi.ERR_INVALID_ARG
     assert lib.spz_amd_release_device_memory() == abi.OK   # harmless without a device

@@ -338,3 +338,64 @@ def test_one_hip_runtime_whatever_the_import_order(spz, order):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def _persplat_cases():
+    g = load_golden("persplat.npz")
+    cl, lg = load_golden("clouds.npz"), load_golden("legacy.npz")
+    streams = {f"d{d}": cl[f"d{d}_stream_from0"] for d in range(4)}
+    streams.update(v2=lg["v2_stream"], v1=lg["v1_stream"], fb0=lg["fb0_stream"], fb8=lg["fb8_stream"],
+                   fb23=lg["fb23_stream"])
+    return g, streams
+
+
+def test_per_splat_at_and_unpack_match_the_reference(spz):
+    """PackedGaussians::at(i) and ::unpack(i, converter) (load-spz.cc:383-463) of the C++ drop-in layer:
+    the 65 packed bytes and the 59 floats equal what the reference returned (tests/golden/persplat.npz:
+    v3 SH0..3 with edge values, v2 first-three, v1 float16, fractionalBits 0/8/23; six from->to
+    converters), bit for bit.  Each unpack is a one-point decode on the GPU."""
+    g, streams = _persplat_cases()
+    for name, s in streams.items():
+        idx = g[f"{name}_indices"]
+        raw = s.tobytes()
+        for frm, to in g["pairs"]:
+            want_f = g[f"{name}_floats_{frm}_{to}"]
+            step = 1 if (frm, to) == (4, 6) else 7        # every index for one converter, a sample for the others
+            for k in range(0, idx.size, step):
+                b, f = spz._packed_unpack(raw, int(idx[k]), spz.CoordinateSystem(int(frm)), spz.CoordinateSystem(int(to)),
+                                          False)
+                assert bytes(b) == g[f"{name}_bytes"][k].tobytes(), (name, int(idx[k]))
+                assert_bits_equal(f, want_f[k], f"{name} i={int(idx[k])} {frm}->{to}")
+    assert spz._packed_unpack(streams["d3"].tobytes(), 10**6, spz.RUB, spz.RUB, False) is None
+
+
+def test_unpack_indices_matches_per_splat_goldens(spz):
+    """unpackIndices (one gather launch over the packed cloud) returns, in cloud-array layout, the same
+    floats the reference's per-splat unpack gave for those indices (converter RUB -> to)."""
+    g, streams = _persplat_cases()
+    for name, s in streams.items():
+        idx = g[f"{name}_indices"]
+        for to in (6, 1):
+            o = spz.UnpackOptions()
+            o.to_coord = spz.CoordinateSystem(to)
+            c = spz._unpack_indices(s.tobytes(), [int(i) for i in idx], o, False)
+            f = g[f"{name}_floats_4_{to}"]
+            assert c.num_points == idx.size
+            d = c.sh_degree
+            shd = {0: 0, 1: 3, 2: 8, 3: 15}[d]
+            assert_bits_equal(c.positions, f[:, 0:3].reshape(-1), f"{name} positions")
+            assert_bits_equal(c.rotations, f[:, 3:7].reshape(-1), f"{name} rotations")
+            assert_bits_equal(c.scales, f[:, 7:10].reshape(-1), f"{name} scales")
+            assert_bits_equal(c.colors, f[:, 10:13].reshape(-1), f"{name} colors")
+            assert_bits_equal(c.alphas, f[:, 13], f"{name} alphas")
+            sh = np.stack([f[:, 14:14 + shd], f[:, 29:29 + shd], f[:, 44:44 + shd]], axis=2)   # [n][coeff][rgb]
+            assert_bits_equal(c.sh, sh.reshape(-1), f"{name} sh")
+    # repeated and out-of-order indices, gzip container, empty list
+    o = spz.UnpackOptions()
+    big = streams["d2"].tobytes()
+    gz = spz._compress_gzipped(big)
+    a = spz._unpack_indices(gz, [5, 5, 0, 511, 5], o)
+    assert a.num_points == 5
+    np.testing.assert_array_equal(a.positions[0:3], a.positions[3:6])
+    np.testing.assert_array_equal(a.positions[0:3], a.positions[12:15])
+    assert spz._unpack_indices(gz, [], o).num_points == 0
