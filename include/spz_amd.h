@@ -180,6 +180,17 @@ int spz_amd_decode_gather_host(const uint8_t *h_stream, size_t size, uint64_t ma
                                const uint32_t *h_indices, uint64_t count, int to_coord,
                                const spz_amd_cloud_out *h_cloud, int device);
 
+/* ---- GaussianCloud::medianVolume's selection step (splat-types.h:170-185): the
+ *      element of rank num_points/2 among the per-point sums (s0 + s1) + s2 of the log scales, found by
+ *      radix selection instead of a sort (4 streaming passes over d_scales, 48 B read per point).
+ *      d_workspace: SPZ_AMD_MEDIAN_WORKSPACE_BYTES of device memory owned by the caller for the
+ *      duration of the call's work on hip_stream; d_median: one float in device memory.  The volume
+ *      itself, 4/3*pi*exp(median), is one scalar the caller computes.  num_points must be >= 1. ---- */
+#define SPZ_AMD_MEDIAN_WORKSPACE_BYTES 8192
+int spz_amd_median_scale_sum_device(const float *d_scales, uint64_t num_points, void *d_workspace,
+                                    float *d_median, void *hip_stream);
+int spz_amd_median_scale_sum_host(const float *h_scales, uint64_t num_points, float *h_median, int device);
+
 /* ---- .ply vertex rows <-> GaussianCloud arrays (the step on the far side of
  *      the hot path).  A binary-LE 3DGS .ply stores one row of `property float` columns per
  *      Gaussian (load-spz.cc:728-740); the column map below is what the header parse yields

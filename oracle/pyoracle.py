@@ -136,6 +136,12 @@ class Oracle:
         self.lib.spzo_cloud_to_ply_rows(*[_fp(a) for a in arrs], n, sh_dim, from_coord, _fp(rows))
         return rows
 
+    def median_volume(self, scales, n):
+        a = _f32(scales)
+        self.lib.spzo_median_volume.restype = C.c_float
+        self.lib.spzo_median_volume.argtypes = [_f32p, C.c_int32]
+        return np.float32(self.lib.spzo_median_volume(_fp(a), n))
+
     def alpha_decode_table(self):
         return np.array([self.lib.spzo_alpha_value(b) for b in range(256)], np.float32)
 
@@ -272,6 +278,12 @@ class Reference:
         self.lib.ref_load_ply(filename.encode(), to_coord, *_cloud_ptrs(out), info)
         out.update(num_points=info[0], sh_degree=info[1], sh_size=info[2])
         return out
+
+    def median_volume(self, scales, n):
+        a = _f32(scales)
+        self.lib.ref_median_volume.restype = C.c_float
+        self.lib.ref_median_volume.argtypes = [_f32p, C.c_int32]
+        return np.float32(self.lib.ref_median_volume(_fp(a), n))
 
     def packed_unpack(self, stream, indices, from_coord, to_coord):
         """PackedGaussians::at(i) bytes [count,65] and ::unpack(i, converter) floats [count,59] of a raw stream."""

@@ -189,6 +189,14 @@ void ref_unpack_quat_first_three(const uint8_t *r, int32_t n, int to, float *out
 
 float ref_half_to_float(uint16_t h) { return spz::halfToFloat(h); }
 
+// GaussianCloud::medianVolume (splat-types.h:170-185) of a cloud that has these scales.
+float ref_median_volume(const float *scales, int32_t n) {
+  spz::GaussianCloud g;
+  g.numPoints = n;
+  g.scales.assign(scales, scales + static_cast<size_t>(n) * 3);
+  return g.medianVolume();
+}
+
 // deserializePackedGaussians on a raw stream, then PackedGaussians::at(i) and ::unpack(i, converter) for every
 // index: bytes65 gets 65 bytes per index (PackedGaussian field order), floats59 gets 59 floats per index
 // (UnpackedGaussian field order: position, rotation, scale, color, alpha, shR, shG, shB).

@@ -16,6 +16,7 @@
 #include "spz_oracle.h"
 
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 /* load-spz.cc:45-46 */
@@ -471,4 +472,26 @@ void spzo_cloud_to_ply_rows(const float *positions, const float *scales, const f
     i4 += 4;
   }
   (void)D;
+}
+
+/* ---- GaussianCloud::medianVolume, splat-types.h:170-185 ------------------------------------------
+ * sums[i] = (s[3i] + s[3i+1]) + s[3i+2] in f32; sorted ascending; the element of rank n/2 (the upper
+ * median for even n); volume = (double)(pi*4/3) * (double)expf(median), narrowed to f32 on return. */
+static int cmp_float(const void *a, const void *b) {
+  const float x = *(const float *)a, y = *(const float *)b;
+  return (x > y) - (x < y);
+}
+
+float spzo_median_volume(const float *scales, int32_t n) {
+  if (n <= 0) return 0.01f;
+  float *sums = (float *)malloc((size_t)n * sizeof(float));
+  if (!sums) return 0.01f;
+  for (int32_t i = 0; i < n; ++i) {
+    const float a = scales[3 * (size_t)i], b = scales[3 * (size_t)i + 1], c = scales[3 * (size_t)i + 2];
+    sums[i] = (a + b) + c;
+  }
+  qsort(sums, (size_t)n, sizeof(float), cmp_float);
+  const float median = sums[n / 2];
+  free(sums);
+  return (float)((M_PI * 4 / 3) * (double)expf(median));
 }

@@ -79,6 +79,8 @@ uint8_t spzo_alpha_byte(float a);               /* load-spz.cc:301 */
 float spzo_alpha_value(uint8_t b);              /* load-spz.cc:518 */
 float spzo_color_value(uint8_t b);              /* load-spz.cc:522 */
 float spzo_half_to_float(uint16_t h);           /* splat-types.cc:8-27 */
+/* GaussianCloud::medianVolume, splat-types.h:170-185: 0.01 for n == 0, else 4/3*pi*expf(middle scale sum). */
+float spzo_median_volume(const float *scales, int32_t n);
 void spzo_pack_quat_smallest_three(uint8_t r[4], const float q[4],
                                    const spzo_converter_t *c); /* load-spz.cc:216-255 */
 void spzo_unpack_quat_smallest_three(float q[4], const uint8_t r[4],

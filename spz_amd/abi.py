@@ -41,6 +41,7 @@ EXPORTS = (
     "spz_amd_decode_host", "spz_amd_convert_coordinates_host", "spz_amd_get_tables",
     "spz_amd_ply_default_columns", "spz_amd_ply_rows_to_cloud_device", "spz_amd_cloud_to_ply_rows_device",
     "spz_amd_ply_rows_to_cloud_host", "spz_amd_cloud_to_ply_rows_host",
+    "spz_amd_median_scale_sum_device", "spz_amd_median_scale_sum_host",
 )
 
 
@@ -74,6 +75,8 @@ class SpzAmdError(RuntimeError):
         self.status = status
         super().__init__(f"{where}: {status_string(status)} (status {status})")
 
+
+MEDIAN_WORKSPACE_BYTES = 8192   # SPZ_AMD_MEDIAN_WORKSPACE_BYTES
 
 _lib = None
 
@@ -152,6 +155,10 @@ def bind(L):
     L.spz_amd_decode_shard_device.argtypes = [vp, sz, C.POINTER(Header), u64, u64, i32, C.POINTER(CloudPtrs), vp]
     L.spz_amd_decode_gather_device.restype = i32
     L.spz_amd_decode_gather_device.argtypes = [vp, sz, C.POINTER(Header), vp, u64, i32, C.POINTER(CloudPtrs), vp]
+    L.spz_amd_median_scale_sum_device.restype = i32
+    L.spz_amd_median_scale_sum_device.argtypes = [vp, u64, vp, vp, vp]
+    L.spz_amd_median_scale_sum_host.restype = i32
+    L.spz_amd_median_scale_sum_host.argtypes = [vp, u64, vp, i32]
     L.spz_amd_decode_gather_host.restype = i32
     L.spz_amd_decode_gather_host.argtypes = [vp, sz, u64, vp, u64, i32, C.POINTER(CloudPtrs), i32]
     L.spz_amd_convert_coordinates_device.restype = i32

@@ -206,13 +206,14 @@ void GaussianCloud::convertCoordinates(CoordinateSystem from, CoordinateSystem t
 }
 
 float GaussianCloud::medianVolume() const {  // splat-types.h:170-185
-  if (numPoints == 0) return 0.01f;
-  std::vector<float> sums;
-  sums.reserve(scales.size() / 3);
-  for (size_t i = 0; i + 2 < scales.size(); i += 3) sums.push_back(scales[i] + scales[i + 1] + scales[i + 2]);
-  if (sums.empty()) return 0.01f;
-  std::sort(sums.begin(), sums.end());
-  const float median = sums[sums.size() / 2];
+  g_last_status = SPZ_AMD_OK;
+  if (numPoints == 0 || scales.size() < 3) return 0.01f;
+  // Selection of the middle scale sum on the device (no sort); the volume is one scalar on top of it.
+  float median = 0.0f;
+  if (deviceFailed(spz_amd_median_scale_sum_host(scales.data(), scales.size() / 3, &median, deviceIndex()),
+                   "medianVolume")) {
+    return 0.01f;
+  }
   return static_cast<float>((M_PI * 4 / 3) * std::exp(median));
 }
 

@@ -190,7 +190,12 @@ PYBIND11_MODULE(spz, m) {
              if (c.numPoints) raiseIfDeviceUnusable();
            },
            "RUB <-> RDF conversion (180 degrees about X).")
-      .def("median_volume", &Cloud::medianVolume, "Return the median Gaussian volume.");
+      .def("median_volume", [](const Cloud &c) {
+             spz::setLastDeviceStatus(SPZ_AMD_OK);
+             const float v = c.medianVolume();   // selection runs on the device
+             raiseIfDeviceUnusable();
+             return v;
+           }, "Return the median Gaussian volume.");
 
   m.def("load_spz",
         [](const std::string &filename, const spz::UnpackOptions &o) {

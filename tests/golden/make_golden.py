@@ -21,6 +21,7 @@ Files (all numpy .npz, loaded with allow_pickle=False):
                     reference's decode of them.
   persplat.npz      PackedGaussians::at(i) bytes and ::unpack(i, converter) floats for index sets of the
                     clouds.npz / legacy.npz streams (v3 SH0..3, v2, v1, other fractionalBits), six converters.
+  median.npz        scale arrays and the reference's GaussianCloud::medianVolume for them.
   ply.npz           .ply files written by the reference's saveSplatToPly (from 0/4/7) and what its
                     loadSplatFromPly returned for them (to 0/4/7); a hand-made .ply with comments,
                     shuffled and extra properties.
@@ -411,6 +412,34 @@ def persplat():
     np.savez_compressed(os.path.join(HERE, "persplat.npz"), **out)
 
 
+def median():
+    """GaussianCloud::medianVolume (splat-types.h:170-185) for scale arrays with odd/even counts, ties,
+    mixed signs, signed zeros and infinities."""
+    out = {}
+    rng = np.random.default_rng(515)
+    cases = {}
+    for n in (1, 2, 3, 4, 5, 100, 101, 4096, 20001):
+        cases[f"uniform_n{n}"] = rng.uniform(-8, 0, 3 * n).astype(np.float32)
+    cases["ties_n1000"] = (np.round(rng.uniform(-6, 2, 3000) * 2) / 2).astype(np.float32)
+    cases["all_equal_n64"] = np.full(192, -1.25, np.float32)
+    mixed = rng.normal(0, 3, 3 * 999).astype(np.float32)
+    cases["mixed_sign_n999"] = mixed
+    z = np.zeros(3 * 10, np.float32)
+    z[0:15] = -0.0
+    cases["signed_zeros_n10"] = z
+    inf = rng.uniform(-3, 3, 3 * 9).astype(np.float32)
+    inf[0] = np.inf
+    inf[3] = -np.inf
+    inf[6] = 3.0e38
+    inf[7] = 3.0e38
+    cases["infinities_n9"] = inf
+    cases["wide_range_n4097"] = (rng.normal(0, 1, 3 * 4097) * 10.0 ** rng.integers(-30, 30, 3 * 4097)).astype(np.float32)
+    for name, sc in cases.items():
+        out[f"{name}_scales"] = sc
+        out[f"{name}_volume"] = np.float32(R.median_volume(sc, sc.size // 3))
+    np.savez_compressed(os.path.join(HERE, "median.npz"), **out)
+
+
 if __name__ == "__main__":
     ply()
     kat_small()
@@ -418,6 +447,7 @@ if __name__ == "__main__":
     quats()
     legacy()
     persplat()
+    median()
     tables()
     for f in sorted(os.listdir(HERE)):
         if f.endswith(".npz"):

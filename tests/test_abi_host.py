@@ -224,4 +224,13 @@ def test_argument_validation_happens_before_any_device_work(lib):
     assert gat(cnt=0) == abi.OK
     assert gat(ind=None) == abi.ERR_INVALID_ARG
     assert gat(cloud=no_sh) == abi.ERR_INVALID_ARG
+    # median selection: arguments first
+    one = np.zeros(3, np.float32)
+    res = np.zeros(1, np.float32)
+    assert lib.spz_amd_median_scale_sum_host(None, 1, res.ctypes.data, 0) == abi.ERR_INVALID_ARG
+    assert lib.spz_amd_median_scale_sum_host(one.ctypes.data, 0, res.ctypes.data, 0) == abi.ERR_INVALID_ARG
+    assert lib.spz_amd_median_scale_sum_host(one.ctypes.data, 1, None, 0) == abi.ERR_INVALID_ARG
+    assert lib.spz_amd_median_scale_sum_device(one.ctypes.data, 1, None, res.ctypes.data, None) == abi.ERR_INVALID_ARG
+    assert lib.spz_amd_median_scale_sum_device(one.ctypes.data, 1 << 32, res.ctypes.data, res.ctypes.data, None) \
+        == abi.ERR_INVALID_ARG
     assert lib.spz_amd_release_device_memory() == abi.OK   # harmless without a device

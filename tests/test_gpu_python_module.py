@@ -3,6 +3,7 @@ on a GPU.  The cases restate what the reference's own suite pins for this path
 (/root/reference/tests/python/load_spz_test.py; line numbers cited per test) with the same inputs
 and tolerances, and add byte-level checks the reference's suite does not have: the .spz file
 bytes must equal the bytes the reference's saveSpz produced (golden vectors)."""
+import ctypes as C
 import os
 
 import numpy as np
@@ -399,3 +400,57 @@ def test_unpack_indices_matches_per_splat_goldens(spz):
     np.testing.assert_array_equal(a.positions[0:3], a.positions[3:6])
     np.testing.assert_array_equal(a.positions[0:3], a.positions[12:15])
     assert spz._unpack_indices(gz, [], o).num_points == 0
+
+
+def test_median_volume_matches_the_reference(spz):
+    """GaussianCloud.median_volume(): the device radix selection of the middle scale sum gives the
+    reference's value to the bit (tests/golden/median.npz), plus the literals of load_spz_test.py:403-441."""
+    import math
+    g = load_golden("median.npz")
+    for name in sorted(k[:-7] for k in g.files if k.endswith("_scales")):
+        sc = g[f"{name}_scales"]
+        c = spz.GaussianCloud()
+        c.positions = np.zeros(sc.size, np.float32)
+        c.scales = sc
+        got = np.float32(c.median_volume())
+        assert got.tobytes() == np.float32(g[f"{name}_volume"]).tobytes(), (name, got, g[f"{name}_volume"])
+    c = spz.GaussianCloud()
+    c.positions = np.zeros(9, np.float32)
+    c.scales = np.array([-1, -1, -1, 0, 0, 0, 1, 1, 1], np.float32)
+    assert abs(c.median_volume() - 4.0 / 3.0 * math.pi) < 1e-5
+    c.positions = np.zeros(15, np.float32)
+    c.scales = np.repeat(np.array([1, -2, 0, 2, -1], np.float32), 3)      # unsorted on purpose
+    assert abs(c.median_volume() - 4.0 / 3.0 * math.pi) < 1e-5
+    c.positions = np.zeros(12, np.float32)
+    c.scales = np.repeat(np.array([0.5, -1, 0.25, -3], np.float32), 3)    # sums -9 -3 0.75 1.5 -> rank 2
+    want = 4.0 / 3.0 * math.pi * math.exp(np.float32(0.75))
+    assert abs(c.median_volume() - want) < 1e-4 * want
+
+
+def test_median_scale_sum_device_entry_point_10m(cuda, oracle):
+    """spz_amd_median_scale_sum_device on device-resident scales: 10 M points equal numpy's order statistic
+    of the f32 sums (the oracle restates the rest), and the call is asynchronous on the given stream."""
+    import torch
+    from spz_amd import abi
+    L = abi.load_library()
+    n = 10_000_001
+    gen = torch.Generator(device=cuda).manual_seed(5)
+    sc = torch.empty(3 * n, dtype=torch.float32, device=cuda).uniform_(-8.0, 0.0, generator=gen)
+    ws = torch.empty(abi.MEDIAN_WORKSPACE_BYTES, dtype=torch.uint8, device=cuda)
+    out = torch.full((1,), float("nan"), dtype=torch.float32, device=cuda)
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        rc = L.spz_amd_median_scale_sum_device(sc.data_ptr(), n, ws.data_ptr(), out.data_ptr(), C.c_void_p(s.cuda_stream))
+    assert rc == abi.OK
+    s.synchronize()
+    v = sc.view(n, 3)
+    sums = (v[:, 0] + v[:, 1]) + v[:, 2]
+    want = torch.sort(sums).values[n // 2]
+    assert out.view(torch.int32).item() == want.view(torch.int32).item()
+    small = sc[: 3 * 4097].cpu().numpy()
+    rc = L.spz_amd_median_scale_sum_device(sc.data_ptr(), 4097, ws.data_ptr(), out.data_ptr(), None)
+    torch.cuda.synchronize()
+    import math
+    vol = np.float32((math.pi * 4 / 3) * float(np.exp(np.float32(out.item()), dtype=np.float32)))
+    assert rc == abi.OK and vol.tobytes() == np.float32(oracle.median_volume(small, 4097)).tobytes()

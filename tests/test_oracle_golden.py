@@ -187,3 +187,16 @@ def test_quaternion_golden_sets(oracle):
             L.spzo_unpack_quat_first_three(out[4 * i:].ctypes.data, r2[3 * i:].ctypes.data, conv)
         assert_bits_equal(out, g[f"dec2_to{to}"], f"v2 decode to={to}")
     assert np.isnan(g["dec3_to0"]).any(), "the set must exercise the NaN (sum > 1) branch"
+
+
+def test_median_volume_golden(oracle):
+    """spzo_median_volume == the reference's GaussianCloud::medianVolume (splat-types.h:170-185) on odd and
+    even counts, ties, signed zeros, infinities and a wide dynamic range, to the bit."""
+    g = load_golden("median.npz")
+    names = sorted(k[:-7] for k in g.files if k.endswith("_scales"))
+    assert len(names) >= 15
+    for name in names:
+        sc = g[f"{name}_scales"]
+        got = oracle.median_volume(sc, sc.size // 3)
+        assert np.float32(got).tobytes() == np.float32(g[f"{name}_volume"]).tobytes(), name
+    assert oracle.median_volume(np.zeros(0, np.float32), 0) == np.float32(0.01)

@@ -4,7 +4,6 @@ error texts, what the reference's suite pins for its nanobind shim
 (/root/reference/tests/python/load_spz_test.py; src/python/spz/spz.cc) — line numbers per test.
 Anything that quantises, dequantises or flips goes through the device and lives in
 test_gpu_python_module.py."""
-import math
 import os
 
 import numpy as np
@@ -106,21 +105,11 @@ def test_non_contiguous_and_2d_inputs():
     assert c.num_points == 2
 
 
-def test_median_volume():
-    """load_spz_test.py:403-441 and splat-types.h:170-185: 0.01 for an empty cloud, else
-    4/3*pi*exp(median of the per-point scale sums) with the upper median for even counts."""
+def test_median_volume_of_an_empty_cloud():
+    """load_spz_test.py:403-408 and splat-types.h:171-173: 0.01 for an empty cloud, no device involved
+    (the selection over a non-empty cloud runs on the GPU: test_gpu_python_module.py)."""
     c = spz.GaussianCloud()
     assert abs(c.median_volume() - 0.01) < 1e-6
-    c.positions = np.zeros(9, np.float32)
-    c.scales = np.array([-1, -1, -1, 0, 0, 0, 1, 1, 1], np.float32)
-    assert abs(c.median_volume() - 4.0 / 3.0 * math.pi) < 1e-5
-    c.positions = np.zeros(15, np.float32)
-    c.scales = np.repeat(np.array([1, -2, 0, 2, -1], np.float32), 3)      # unsorted on purpose
-    assert abs(c.median_volume() - 4.0 / 3.0 * math.pi) < 1e-5
-    c.positions = np.zeros(12, np.float32)
-    c.scales = np.repeat(np.array([0.5, -1, 0.25, -3], np.float32), 3)    # sums -9 -3 0.75 1.5 -> index 2
-    want = 4.0 / 3.0 * math.pi * math.exp(np.float32(0.75))
-    assert abs(c.median_volume() - want) < 1e-4 * want
 
 
 def test_empty_arrays_are_accepted():
