@@ -427,9 +427,9 @@ def test_median_volume_matches_the_reference(spz):
     assert abs(c.median_volume() - want) < 1e-4 * want
 
 
-def test_median_scale_sum_device_entry_point_10m(cuda, oracle):
+def test_median_scale_sum_device_entry_point_10m(cuda):
     """spz_amd_median_scale_sum_device on device-resident scales: 10 M points equal numpy's order statistic
-    of the f32 sums (the oracle restates the rest), and the call is asynchronous on the given stream."""
+    of the f32 sums, and the call is asynchronous on the given stream."""
     import torch
     from spz_amd import abi
     L = abi.load_library()
@@ -448,9 +448,8 @@ def test_median_scale_sum_device_entry_point_10m(cuda, oracle):
     sums = (v[:, 0] + v[:, 1]) + v[:, 2]
     want = torch.sort(sums).values[n // 2]
     assert out.view(torch.int32).item() == want.view(torch.int32).item()
-    small = sc[: 3 * 4097].cpu().numpy()
+    small = sc[: 3 * 4097].cpu().numpy().reshape(-1, 3)
     rc = L.spz_amd_median_scale_sum_device(sc.data_ptr(), 4097, ws.data_ptr(), out.data_ptr(), None)
     torch.cuda.synchronize()
-    import math
-    vol = np.float32((math.pi * 4 / 3) * float(np.exp(np.float32(out.item()), dtype=np.float32)))
-    assert rc == abi.OK and vol.tobytes() == np.float32(oracle.median_volume(small, 4097)).tobytes()
+    want = np.sort((small[:, 0] + small[:, 1]) + small[:, 2])[4097 // 2]
+    assert rc == abi.OK and np.float32(out.item()).tobytes() == np.float32(want).tobytes()
