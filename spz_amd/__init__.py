@@ -3,6 +3,7 @@
 Layout:
   csrc/spz_kernels.hip  hand-written HIP pack/unpack/flip kernels (gfx950)
   csrc/spz_ply_kernels.hip  .ply row <-> cloud shuffles
+  csrc/spz_median.hip   radix selection of the median scale sum (medianVolume)
   csrc/spz_abi.hip      the C ABI (include/spz_amd.h) over them
   csrc/spz_host.cpp     C++ drop-in layer: namespace spz saveSpz/loadSpz/... + host gzip
   csrc/spz_py.cpp       Python module `spz_amd.spz` with the reference nanobind shim's surface
