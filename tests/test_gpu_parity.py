@@ -817,3 +817,28 @@ def test_fuzz_sizes_degrees_and_coordinate_systems(dev, oracle):
         assert rc == 0 and h.antialiased == aa
         for k in FIELDS:
             assert_bits_equal(u[k], w[k], f"it={it} n={n} deg={deg} to={to} {k}")
+
+
+def test_bench_multi_rank_path_rehearsal_on_one_gpu(dev):
+    """bench.py's N>1 code path end to end (shard plan, encode_shard into the root's global stream,
+    double-buffered gatherv, per-fragment verification, the exchange-free leg, max-over-ranks timing)
+    with two ranks sharing this GPU over gloo (host-staged exchange).  RCCL itself needs two GPUs and
+    is the driver's to run; everything around it is exercised here."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29641", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--points", "300000", "--backend", "gloo"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 2 and res["steps"] == 3 and res["scaling"] == "weak"
+    assert res["gather_verified"] is True
+    assert res["config"]["points_per_gpu"] == 300000 and "REHEARSAL" in res["config"]["parallelism"]
+    assert res["shards_only"]["value"] > res["value"] > 0
+    assert res["shards_only"]["gatherv_bytes_into_root_per_step"] == 300000 * 65
+    assert "cpu_baseline" not in res        # rank 0 at N=1 only
