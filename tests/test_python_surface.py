@@ -178,3 +178,33 @@ def test_empty_cloud_saves_and_loads_without_a_device(tmp_path):
     back = spz.load_spz(fn, spz.UnpackOptions())
     assert back.num_points == 0 and back.sh_degree == 0 and len(back.positions) == 0
     assert spz.save_spz(c, spz.PackOptions(), "/invalid/path/that/does/not/exist/test.spz") is False
+
+
+def test_len_repr_and_sh_degree_range():
+    """spz.cc:177-197: __len__ and num_points derive from positions, __repr__ text, sh_degree in [0, 3]."""
+    c = spz.GaussianCloud()
+    assert len(c) == 0 and repr(c) == "GaussianCloud(num_points=0, sh_degree=0, antialiased=False)"
+    c.positions = np.zeros(6, np.float32)
+    c.antialiased = True
+    c.sh_degree = 3
+    assert len(c) == 2 and c.num_points == 2
+    assert repr(c) == "GaussianCloud(num_points=2, sh_degree=3, antialiased=True)"
+    for bad in (-1, 4, 100):
+        with pytest.raises(ValueError, match=r"sh_degree must be in \[0, 3\]"):
+            c.sh_degree = bad
+    assert c.sh_degree == 3
+    with pytest.raises(TypeError):
+        c.sh_degree = 1.5
+
+
+def test_function_signatures_accept_the_shim_keywords(tmp_path):
+    """spz.cc:347-361: keyword names and the defaulted `options` of the four module functions."""
+    fn = str(tmp_path / "kw.spz")
+    assert spz.save_spz(gaussians=spz.GaussianCloud(), options=spz.PackOptions(), filename=fn) is True
+    assert spz.load_spz(filename=fn).num_points == 0                       # options defaults to UnpackOptions()
+    assert spz.load_spz(fn, options=spz.UnpackOptions()).num_points == 0
+    assert spz.load_splat_from_ply(filename=str(tmp_path / "missing.ply")).num_points == 0
+    with pytest.raises(TypeError):
+        spz.save_spz(spz.GaussianCloud(), fn)                               # options is required
+    for name in ("load_spz", "save_spz", "load_splat_from_ply", "save_splat_to_ply"):
+        assert getattr(spz, name).__doc__
