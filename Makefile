@@ -70,4 +70,14 @@ clean:
 	rm -rf $(LIBDIR) $(ROOT)build $(ROOT)spz_amd/spz*.so $(ROOT)spz_amd/bin
 	$(MAKE) -C $(ROOT)oracle clean
 
-.PHONY: all device host python cli oracle asm clean
+.PHONY: fuzz all device host python cli oracle asm clean
+
+# Host-side robustness: the gzip readers and the .ply header parser under AddressSanitizer + UBSan
+# (CPU only; the GPU pool has no sanitizer support).  Mutated inputs; must finish without a report.
+fuzz: $(LIBDIR)/libspz_amd.so
+	mkdir -p $(ROOT)build
+	for t in gunzip_fuzz ply_fuzz; do \
+	  $(CXX) -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -std=gnu++17 -I$(INC) -o $(ROOT)build/$$t \
+	    $(ROOT)tools/fuzz/$$t.cpp $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp -L$(LIBDIR) -lspz_amd -lz -ldl -lpthread \
+	    -Wl,-rpath,$(abspath $(LIBDIR)) && ASAN_OPTIONS=detect_leaks=0 $(ROOT)build/$$t || exit 1; \
+	done
