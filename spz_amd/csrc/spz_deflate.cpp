@@ -1,0 +1,835 @@
+// spz_deflate.cpp — multi-threaded gzip writer with zlib's exact output.
+//
+// Why: the reference's container step (compressGzipped, /root/reference/src/cc/load-spz.cc:186-214:
+// zlib, default level, one deflate stream) is ~90 % of an end-to-end saveSpz once the quantise step
+// runs on the GPU, and the .spz bytes have to stay identical to the
+// reference's.  A pigz-style writer is fast but produces different bytes; this one produces the SAME
+// bytes as zlib 1.2.11 with deflateInit2(level 6, windowBits 15 + gzip, memLevel 9, default strategy),
+// in parallel.  zlib is a third-party dependency of the reference (system zlib 1.2.11);
+// what follows restates its published algorithm (RFC 1951/1952 format; deflate.c's lazy matcher
+// `deflate_slow` + `longest_match`, trees.c's block writer) and is pinned by byte comparison with the
+// system zlib in tests/test_exact_gzip.py and by a self-check against zlib at run time.
+//
+// How it can be parallel and exact:
+//  * zlib's LZ77 parse at a position depends only on (a) the previous 32 KiB of input, through hash
+//    chains that contain EVERY earlier position (level >= 4 inserts all of them), (b) the phase of its
+//    64 KiB sliding window, which is a pure function of the position, and (c) three words of lazy-match
+//    state (match_available, match_length, match_start).  A parse job that starts at a multiple of
+//    32 KiB with (a) and (b) rebuilt exactly and (c) reset therefore differs from the serial parse only
+//    until the two reach the same position with the same (c) — after that they are identical forever.
+//    Each job runs 32 KiB into its successor's range, both record (c) at every loop top there, and the
+//    symbol streams are spliced at the first common position with equal state.
+//  * Block boundaries are every 32767 symbols of the spliced stream (lit_bufsize - 1), and each block's
+//    bits are a deterministic function of its symbols (trees.c), so blocks are encoded independently and
+//    their bit strings concatenated.
+//  * Reads past the end of the input (the matcher looks up to 258 bytes ahead) see what zlib's window
+//    holds there: the bytes 32 KiB earlier (stale upper half of the window), reproduced in a padded tail.
+#include "spz_deflate.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <cstdio>
+#include <thread>
+
+namespace spz {
+namespace exactgz {
+namespace {
+
+// ---- deflate.c parameters for level 6, windowBits 15, memLevel 9 ----------------------------------
+constexpr uint32_t W = 32768, WMASK = W - 1;
+constexpr uint32_t HASH_SIZE = 65536, HASH_MASK = HASH_SIZE - 1;  // hash_bits = memLevel + 7, hash_shift = 6
+constexpr uint32_t MIN_MATCH = 3, MAX_MATCH = 258, MIN_LOOKAHEAD = MAX_MATCH + MIN_MATCH + 1;
+constexpr uint32_t MAX_DIST = W - MIN_LOOKAHEAD, TOO_FAR = 4096;
+constexpr uint32_t GOOD_MATCH = 8, MAX_LAZY = 16, NICE_MATCH = 128, MAX_CHAIN = 128;
+constexpr size_t BLOCK_SYMS = 32767;  // lit_bufsize - 1 with lit_bufsize = 1 << (memLevel + 6)
+constexpr uint32_t OVERLAP = W;
+
+inline uint32_t hash3(const uint8_t *p) {
+  return ((uint32_t(p[0]) << 12) ^ (uint32_t(p[1]) << 6) ^ uint32_t(p[2])) & HASH_MASK;
+}
+
+// Window base (absolute position of window[0]) that zlib has after fill_window at a loop top at
+// position s: the window slides by 32 KiB at the first loop top with lookahead < 262 and
+// strstart - base >= 32768 + MAX_DIST.
+uint64_t base_at(uint64_t s, uint64_t size) {
+  const uint64_t kfull = size / W;  // slides k with W*(k+1) <= size need s >= W*(k+1) - 261
+  uint64_t a = (s + 261) / W;
+  a = a >= 1 ? a - 1 : 0;
+  uint64_t k = std::min<uint64_t>(a, kfull >= 1 ? kfull - 1 : 0);
+  // the slide whose refill is cut short by the end of the input happens one position earlier
+  if (kfull >= 1 && k == kfull - 1 && s + 262 >= W * (kfull + 1)) k = kfull;
+  return k * W;
+}
+
+struct TopRec {  // lazy-match state at a loop top, after fill_window
+  uint32_t state = 0;     // bit 31 valid, bit 30 match_available, bits 0-8 match_length, bits 9-24 distance of match_start
+  uint32_t symcount = 0;  // symbols this job had emitted before this loop top
+};
+
+// ---- one parse job: deflate_slow over [begin, stop) ---------------------------------------------------
+struct Job {
+  const uint8_t *d = nullptr;  // d[abs] valid for every absolute position the job can touch
+  uint64_t size = 0, begin = 0, stop = 0;
+  bool last = false;
+  uint64_t rec_succ_lo = 0, rec_pred_lo = 0;  // first positions of the two record windows
+  std::vector<TopRec> rec_succ, rec_pred;     // as successor: [begin, ...); as predecessor: [next begin, ...)
+  std::vector<uint16_t> sym_dist;             // 0 = literal
+  std::vector<uint8_t> sym_lc;                // literal byte, or match length - 3
+  bool phase_ok = true;
+  bool check_phase = false;    // tests: compare the tracked window base with base_at() at every loop top
+  bool tail_literal = false;   // the last symbol was the pending literal tallied after the loop (no flush check there)
+
+  // Everything the loop touches lives in locals: the symbol stores go through uint8_t*, which may alias
+  // any member, and would otherwise force reloads of every pointer after each symbol.
+  void run() {
+    // head: absolute position of the newest string per hash (0 = none).  prev: distance from a position to
+    // the previous string with its hash, 0 when there is none within 64 KiB — a link that far back is beyond
+    // MAX_DIST for this and every later position, so it ends the chain exactly where zlib's does.  16-bit
+    // links keep the table the chain walk depends on at 64 KiB, like zlib's.
+    std::vector<uint32_t> head_v(HASH_SIZE, 0);
+    std::vector<uint16_t> prev_v(W, 0);
+    uint32_t *const head = head_v.data();
+    uint16_t *const prev = prev_v.data();
+    const uint8_t *const dd = d;
+    const uint64_t sz = size, stop_at = stop;
+    const bool is_last = last, check = check_phase;
+    uint64_t strstart = begin;
+    uint64_t base = begin == 0 ? 0 : begin - W;
+    uint64_t filled_end = std::min<uint64_t>(sz, base + 2 * W);
+    // zlib's rolling hash (UPDATE_HASH): positions are inserted in increasing order without gaps, so
+    // ins_h always holds the two bytes before the one INSERT_STRING shifts in.
+    uint32_t ins_h = ((uint32_t(dd[base]) << 6) ^ uint32_t(dd[base + 1])) & HASH_MASK;
+#define SPZ_INSERT_STRING(pos, old_head)                                   \
+  do {                                                                     \
+    ins_h = ((ins_h << 6) ^ uint32_t(dd[(pos) + 2])) & HASH_MASK;          \
+    (old_head) = head[ins_h];                                              \
+    {                                                                      \
+      const uint64_t gap_ = (pos) - (old_head);                            \
+      prev[(pos) & WMASK] = ((old_head) != 0 && gap_ <= 0xffffu) ? static_cast<uint16_t>(gap_) : 0; \
+    }                                                                      \
+    head[ins_h] = static_cast<uint32_t>(pos);                              \
+  } while (0)
+    uint32_t scratch;
+    for (uint64_t p = base; p < begin; ++p) SPZ_INSERT_STRING(p, scratch);  // every earlier position is in the chains
+    uint32_t match_available = 0, match_length = MIN_MATCH - 1;
+    uint64_t match_start = 0;
+    // at most one symbol per input byte; written by index, trimmed at the end
+    const size_t cap = static_cast<size_t>((is_last ? sz : stop_at + MAX_MATCH + 2) - begin) + 2;
+    sym_dist.resize(cap);
+    sym_lc.resize(cap);
+    uint16_t *const out_dist = sym_dist.data();
+    uint8_t *const out_lc = sym_lc.data();
+    size_t nsym = 0;
+    bool ok = true, tail = false;
+    TopRec *const rs = rec_succ.data();
+    TopRec *const rp = rec_pred.data();
+    const uint64_t rs_lo = rec_succ_lo, rp_lo = rec_pred_lo, rs_n = rec_succ.size(), rp_n = rec_pred.size();
+    // loop tops before rec_from need no record; past rec_to the job is done
+    const uint64_t rec_from = rs_n ? rs_lo : (rp_n ? rp_lo : ~uint64_t(0));
+    for (;;) {
+      uint64_t lookahead = filled_end - strstart;
+      if (lookahead < MIN_LOOKAHEAD) {  // fill_window
+        do {
+          if (strstart - base >= W + MAX_DIST) {
+            base += W;
+            if (base != base_at(strstart, sz)) ok = false;
+          }
+          if (filled_end == sz) break;
+          filled_end = std::min<uint64_t>(sz, base + 2 * W);
+          lookahead = filled_end - strstart;
+        } while (lookahead < MIN_LOOKAHEAD && filled_end != sz);
+        lookahead = filled_end - strstart;
+        if (lookahead == 0) break;
+        if (check && base != base_at(strstart, sz)) ok = false;
+      }
+      // ---- loop top: record the lazy state where a neighbour may want to splice
+      if (strstart >= rec_from) {
+        const uint32_t dist = match_length >= MIN_MATCH ? static_cast<uint32_t>(strstart - match_start) : 0;
+        const uint32_t st = 0x80000000u | (match_available << 30) | match_length | ((dist & 0xffffu) << 9);
+        if (strstart - rs_lo < rs_n) rs[strstart - rs_lo] = {st, static_cast<uint32_t>(nsym)};  // unsigned compare
+        if (strstart - rp_lo < rp_n) rp[strstart - rp_lo] = {st, static_cast<uint32_t>(nsym)};
+        if (check && base != base_at(strstart, sz)) ok = false;
+        if (!is_last && strstart >= stop_at) break;
+      }
+      uint32_t hash_head = 0;
+      if (lookahead >= MIN_MATCH) SPZ_INSERT_STRING(strstart, hash_head);
+      const uint32_t prev_length = match_length;
+      const uint64_t prev_match = match_start;
+      match_length = MIN_MATCH - 1;
+      if (hash_head > base && prev_length < MAX_LAZY && strstart - hash_head <= MAX_DIST) {
+        // longest_match
+        uint32_t chain = MAX_CHAIN, best_len = prev_length, nice = NICE_MATCH;
+        const uint64_t limit = (strstart - base > MAX_DIST) ? strstart - MAX_DIST : base;
+        const uint8_t *const scan = dd + strstart;
+        auto load16 = [](const uint8_t *q) {
+          uint16_t v;
+          std::memcpy(&v, q, 2);
+          return v;
+        };
+        uint16_t scan_end = load16(scan + best_len - 1);  // the bytes at best_len - 1 and best_len, as one compare
+        const uint16_t scan_start = load16(scan);
+        if (prev_length >= GOOD_MATCH) chain >>= 2;
+        if (nice > lookahead) nice = static_cast<uint32_t>(lookahead);
+        uint64_t cur = hash_head;
+        do {
+          const uint8_t *const match = dd + cur;
+          if (load16(match + best_len - 1) == scan_end && load16(match) == scan_start) {
+            uint32_t len = 2;  // bytes 0 and 1 are equal; MAX_MATCH - 2 = 32 * 8
+            for (; len < MAX_MATCH; len += 8) {
+              uint64_t a, b;
+              std::memcpy(&a, scan + len, 8);
+              std::memcpy(&b, match + len, 8);
+              const uint64_t x = a ^ b;
+              if (x != 0) {
+                len += static_cast<uint32_t>(__builtin_ctzll(x)) >> 3;
+                break;
+              }
+            }
+            if (len > best_len) {
+              match_start = cur;
+              best_len = len;
+              if (len >= nice) break;
+              scan_end = load16(scan + best_len - 1);
+            }
+          }
+          const uint32_t gap = prev[cur & WMASK];
+          if (gap == 0) break;
+          cur -= gap;
+        } while (cur > limit && --chain != 0);
+        match_length = best_len <= lookahead ? best_len : static_cast<uint32_t>(lookahead);
+        if (match_length == MIN_MATCH && strstart - match_start > TOO_FAR) match_length = MIN_MATCH - 1;
+      }
+      if (prev_length >= MIN_MATCH && match_length <= prev_length) {
+        const uint64_t max_insert = strstart + lookahead - MIN_MATCH;
+        out_dist[nsym] = static_cast<uint16_t>(strstart - 1 - prev_match);
+        out_lc[nsym++] = static_cast<uint8_t>(prev_length - MIN_MATCH);
+        uint32_t n = prev_length - 2;
+        do {
+          if (++strstart <= max_insert) SPZ_INSERT_STRING(strstart, scratch);
+        } while (--n != 0);
+        match_available = 0;
+        match_length = MIN_MATCH - 1;
+        ++strstart;
+      } else if (match_available) {
+        out_dist[nsym] = 0;
+        out_lc[nsym++] = dd[strstart - 1];
+        ++strstart;
+      } else {
+        match_available = 1;
+        ++strstart;
+      }
+    }
+    if (is_last && match_available) {  // end of input: the pending literal
+      out_dist[nsym] = 0;
+      out_lc[nsym++] = dd[strstart - 1];
+      tail = true;
+    }
+    sym_dist.resize(nsym);
+    sym_lc.resize(nsym);
+    tail_literal = tail;
+    if (!ok) phase_ok = false;
+#undef SPZ_INSERT_STRING
+  }
+};
+
+// ---- trees.c: static tables -----------------------------------------------------------------------
+constexpr int L_CODES = 286, D_CODES = 30, BL_CODES = 19, HEAP_SIZE = 2 * L_CODES + 1, LITERALS = 256, END_BLOCK = 256;
+constexpr int REP_3_6 = 16, REPZ_3_10 = 17, REPZ_11_138 = 18, MAX_BITS = 15, MAX_BL_BITS = 7;
+const int kExtraL[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+const int kExtraD[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+const int kExtraBl[19] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 2, 3, 7};
+const uint8_t kBlOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct StaticTables {
+  uint8_t length_code[256];
+  uint8_t dist_code[512];
+  int base_length[29];
+  int base_dist[30];
+  uint16_t sl_len[L_CODES + 2], sl_code[L_CODES + 2];  // static literal/length tree
+  uint16_t sd_code[D_CODES];                           // static distance tree: 5-bit codes
+  StaticTables() {
+    int length = 0;
+    for (int code = 0; code < 28; ++code) {
+      base_length[code] = length;
+      for (int n = 0; n < (1 << kExtraL[code]); ++n) length_code[length++] = static_cast<uint8_t>(code);
+    }
+    base_length[28] = 0;
+    length_code[255] = 28;  // length 258 has a code of its own
+    int dist = 0;
+    for (int code = 0; code < 16; ++code) {
+      base_dist[code] = dist;
+      for (int n = 0; n < (1 << kExtraD[code]); ++n) dist_code[dist++] = static_cast<uint8_t>(code);
+    }
+    dist >>= 7;
+    for (int code = 16; code < D_CODES; ++code) {
+      base_dist[code] = dist << 7;
+      for (int n = 0; n < (1 << (kExtraD[code] - 7)); ++n) dist_code[256 + dist++] = static_cast<uint8_t>(code);
+    }
+    uint16_t bl_count[MAX_BITS + 1] = {};
+    int n = 0;
+    while (n <= 143) sl_len[n++] = 8, bl_count[8]++;
+    while (n <= 255) sl_len[n++] = 9, bl_count[9]++;
+    while (n <= 279) sl_len[n++] = 7, bl_count[7]++;
+    while (n <= 287) sl_len[n++] = 8, bl_count[8]++;
+    gen_codes(sl_len, sl_code, L_CODES + 1, bl_count);
+    for (int c = 0; c < D_CODES; ++c) sd_code[c] = static_cast<uint16_t>(reverse(static_cast<unsigned>(c), 5));
+  }
+  static unsigned reverse(unsigned code, int len) {
+    unsigned res = 0;
+    do {
+      res |= code & 1;
+      code >>= 1;
+      res <<= 1;
+    } while (--len > 0);
+    return res >> 1;
+  }
+  static void gen_codes(const uint16_t *len, uint16_t *code_out, int max_code, const uint16_t *bl_count) {
+    uint16_t next_code[MAX_BITS + 1];
+    unsigned code = 0;
+    for (int bits = 1; bits <= MAX_BITS; ++bits) {
+      code = (code + bl_count[bits - 1]) << 1;
+      next_code[bits] = static_cast<uint16_t>(code);
+    }
+    for (int n = 0; n <= max_code; ++n) {
+      const int l = len[n];
+      if (l == 0) continue;
+      code_out[n] = static_cast<uint16_t>(reverse(next_code[l]++, l));
+    }
+  }
+  inline int d_code(unsigned dist) const { return dist < 256 ? dist_code[dist] : dist_code[256 + (dist >> 7)]; }
+};
+const StaticTables &tables() {
+  static const StaticTables t;
+  return t;
+}
+
+// ---- trees.c: build_tree / gen_bitlen / gen_codes for one tree --------------------------------------
+struct Tree {
+  uint16_t freq[HEAP_SIZE] = {};
+  uint16_t len[HEAP_SIZE] = {};
+  uint16_t dad[HEAP_SIZE] = {};
+  uint16_t code[HEAP_SIZE] = {};
+  int max_code = 0;
+};
+
+struct TreeBuilder {
+  int heap[HEAP_SIZE];
+  uint8_t depth[HEAP_SIZE];
+  int heap_len = 0, heap_max = 0;
+  uint16_t bl_count[MAX_BITS + 1];
+  int64_t opt_len = 0, static_len = 0;
+
+  bool smaller(const Tree &t, int n, int m) const {
+    return t.freq[n] < t.freq[m] || (t.freq[n] == t.freq[m] && depth[n] <= depth[m]);
+  }
+  void pqdownheap(const Tree &t, int k) {
+    const int v = heap[k];
+    int j = k << 1;
+    while (j <= heap_len) {
+      if (j < heap_len && smaller(t, heap[j + 1], heap[j])) j++;
+      if (smaller(t, v, heap[j])) break;
+      heap[k] = heap[j];
+      k = j;
+      j <<= 1;
+    }
+    heap[k] = v;
+  }
+  // elems: number of symbols; extra/base: extra bits table; stree: static lengths (nullptr for the bl tree)
+  void build(Tree &t, int elems, const int *extra, int base, int max_length, const uint16_t *stree) {
+    heap_len = 0;
+    heap_max = HEAP_SIZE;
+    int max_code = -1;
+    for (int n = 0; n < elems; ++n) {
+      if (t.freq[n] != 0) {
+        heap[++heap_len] = max_code = n;
+        depth[n] = 0;
+      } else {
+        t.len[n] = 0;
+      }
+    }
+    while (heap_len < 2) {
+      const int node = heap[++heap_len] = (max_code < 2 ? ++max_code : 0);
+      t.freq[node] = 1;
+      depth[node] = 0;
+      opt_len--;
+      if (stree) static_len -= stree[node];
+    }
+    t.max_code = max_code;
+    for (int n = heap_len / 2; n >= 1; --n) pqdownheap(t, n);
+    int node = elems;
+    do {
+      const int n = heap[1];
+      heap[1] = heap[heap_len--];
+      pqdownheap(t, 1);
+      const int m = heap[1];
+      heap[--heap_max] = n;
+      heap[--heap_max] = m;
+      t.freq[node] = static_cast<uint16_t>(t.freq[n] + t.freq[m]);
+      depth[node] = static_cast<uint8_t>((depth[n] >= depth[m] ? depth[n] : depth[m]) + 1);
+      t.dad[n] = t.dad[m] = static_cast<uint16_t>(node);
+      heap[1] = node++;
+      pqdownheap(t, 1);
+    } while (heap_len >= 2);
+    heap[--heap_max] = heap[1];
+    // gen_bitlen
+    for (int bits = 0; bits <= MAX_BITS; ++bits) bl_count[bits] = 0;
+    int overflow = 0, h;
+    t.len[heap[heap_max]] = 0;
+    for (h = heap_max + 1; h < HEAP_SIZE; ++h) {
+      const int n = heap[h];
+      int bits = t.len[t.dad[n]] + 1;
+      if (bits > max_length) bits = max_length, overflow++;
+      t.len[n] = static_cast<uint16_t>(bits);
+      if (n > max_code) continue;
+      bl_count[bits]++;
+      int xbits = 0;
+      if (n >= base) xbits = extra[n - base];
+      const int64_t f = t.freq[n];
+      opt_len += f * (bits + xbits);
+      if (stree) static_len += f * (stree[n] + xbits);
+    }
+    if (overflow != 0) {
+      do {
+        int bits = max_length - 1;
+        while (bl_count[bits] == 0) bits--;
+        bl_count[bits]--;
+        bl_count[bits + 1] += 2;
+        bl_count[max_length]--;
+        overflow -= 2;
+      } while (overflow > 0);
+      for (int bits = max_length; bits != 0; --bits) {
+        int n = bl_count[bits];
+        while (n != 0) {
+          const int m = heap[--h];
+          if (m > max_code) continue;
+          if (t.len[m] != static_cast<unsigned>(bits)) {
+            opt_len += (static_cast<int64_t>(bits) - t.len[m]) * t.freq[m];
+            t.len[m] = static_cast<uint16_t>(bits);
+          }
+          n--;
+        }
+      }
+    }
+    StaticTables::gen_codes(t.len, t.code, max_code, bl_count);
+  }
+};
+
+// Note on freq width: zlib's Freq is 16 bits as well; a block holds at most 32767 symbols + END_BLOCK and
+// internal nodes sum to at most 32768 per tree, so nothing overflows.
+
+struct BitWriter {
+  std::vector<uint8_t> out;
+  uint64_t acc = 0;
+  int nbits = 0;
+  uint64_t total = 0;
+  inline void put(uint32_t value, int length) {
+    acc |= static_cast<uint64_t>(value) << nbits;
+    nbits += length;
+    total += static_cast<uint64_t>(length);
+    while (nbits >= 8) {
+      out.push_back(static_cast<uint8_t>(acc));
+      acc >>= 8;
+      nbits -= 8;
+    }
+  }
+  void align() {  // bi_windup
+    if (nbits > 0) {
+      total += static_cast<uint64_t>(8 - nbits);
+      out.push_back(static_cast<uint8_t>(acc));
+      acc = 0;
+      nbits = 0;
+    }
+  }
+};
+
+struct Seg {
+  const uint16_t *dist;
+  const uint8_t *lc;
+  size_t n;
+};
+
+enum Choice { STORED = 0, STATIC = 1, DYNAMIC = 2 };
+
+struct Block {
+  std::vector<Seg> segs;
+  size_t nsyms = 0;
+  bool last = false;
+  uint64_t bytes = 0;          // input bytes the symbols cover (stored_len)
+  uint32_t last_sym_len = 0;   // input bytes of the last symbol
+  uint64_t start = 0;          // absolute input position of the first byte
+  Tree lt, dt, bt;
+  int max_blindex = 0;
+  int64_t opt_len = 0, static_len = 0;
+  Choice choice = DYNAMIC;
+  uint64_t bit_start = 0, bit_len = 0;
+  std::vector<uint8_t> bits;   // encoded block, first byte holds (bit_start & 7) leading zero bits
+};
+
+// scan_tree + send_tree share this walk; `emit(code, extra_value, extra_bits)` is called per bl symbol.
+template <class F>
+void walk_lengths(const Tree &t, int max_code, F emit) {
+  int prevlen = -1, nextlen = t.len[0], count = 0, max_count = 7, min_count = 4;
+  if (nextlen == 0) max_count = 138, min_count = 3;
+  for (int n = 0; n <= max_code; ++n) {
+    const int curlen = nextlen;
+    nextlen = (n == max_code) ? 0xffff : t.len[n + 1];  // the guard zlib stores at tree[max_code + 1]
+    if (++count < max_count && curlen == nextlen) continue;
+    if (count < min_count) {
+      for (int i = 0; i < count; ++i) emit(curlen, 0, 0);
+    } else if (curlen != 0) {
+      if (curlen != prevlen) {
+        emit(curlen, 0, 0);
+        count--;
+      }
+      emit(REP_3_6, count - 3, 2);
+    } else if (count <= 10) {
+      emit(REPZ_3_10, count - 3, 3);
+    } else {
+      emit(REPZ_11_138, count - 11, 7);
+    }
+    count = 0;
+    prevlen = curlen;
+    if (nextlen == 0) max_count = 138, min_count = 3;
+    else if (curlen == nextlen) max_count = 6, min_count = 3;
+    else max_count = 7, min_count = 4;
+  }
+}
+
+void plan_block(Block &b) {  // the tally loop + the first half of _tr_flush_block
+  const StaticTables &T = tables();
+  b.lt.freq[END_BLOCK] = 1;  // init_block
+  uint64_t bytes = 0;
+  uint32_t last_len = 0;
+  for (const Seg &s : b.segs) {
+    for (size_t i = 0; i < s.n; ++i) {
+      const unsigned dist = s.dist[i], lc = s.lc[i];
+      if (dist == 0) {
+        b.lt.freq[lc]++;
+        last_len = 1;
+      } else {
+        b.lt.freq[T.length_code[lc] + LITERALS + 1]++;
+        b.dt.freq[T.d_code(dist - 1)]++;
+        last_len = lc + MIN_MATCH;
+      }
+      bytes += last_len;
+    }
+  }
+  b.bytes = bytes;
+  b.last_sym_len = last_len;
+  TreeBuilder tb;
+  tb.build(b.lt, L_CODES, kExtraL, LITERALS + 1, MAX_BITS, T.sl_len);
+  static const uint16_t kStaticDLen[D_CODES] = {5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5,
+                                                5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5};
+  tb.build(b.dt, D_CODES, kExtraD, 0, MAX_BITS, kStaticDLen);
+  // build_bl_tree
+  auto count = [&](int code, int, int) { b.bt.freq[code]++; };
+  walk_lengths(b.lt, b.lt.max_code, count);
+  walk_lengths(b.dt, b.dt.max_code, count);
+  tb.build(b.bt, BL_CODES, kExtraBl, 0, MAX_BL_BITS, nullptr);
+  int max_blindex = BL_CODES - 1;
+  for (; max_blindex >= 3; --max_blindex) {
+    if (b.bt.len[kBlOrder[max_blindex]] != 0) break;
+  }
+  tb.opt_len += 3 * (static_cast<int64_t>(max_blindex) + 1) + 5 + 5 + 4;
+  b.max_blindex = max_blindex;
+  b.opt_len = tb.opt_len;
+  b.static_len = tb.static_len;
+}
+
+void encode_block(Block &b, const uint8_t *data) {  // the second half of _tr_flush_block
+  const StaticTables &T = tables();
+  BitWriter w;
+  w.out.reserve(static_cast<size_t>(b.bit_len / 8 + 16));
+  const int lead = static_cast<int>(b.bit_start & 7);
+  w.nbits = lead;  // leading zero bits: the block is OR-ed into place
+  const uint32_t last = b.last ? 1u : 0u;
+  if (b.choice == STORED) {
+    w.put((0u << 1) + last, 3);
+    w.align();
+    const uint32_t len = static_cast<uint32_t>(b.bytes);
+    w.put(len & 0xffffu, 16);
+    w.put(~len & 0xffffu, 16);
+    w.out.insert(w.out.end(), data + b.start, data + b.start + b.bytes);
+    w.total += 8 * b.bytes;
+  } else {
+    const uint16_t *llen, *lcode, *dcode;
+    uint16_t dlen_static[D_CODES];
+    const uint16_t *dlen;
+    if (b.choice == STATIC) {
+      w.put((1u << 1) + last, 3);
+      llen = T.sl_len;
+      lcode = T.sl_code;
+      for (int i = 0; i < D_CODES; ++i) dlen_static[i] = 5;
+      dlen = dlen_static;
+      dcode = T.sd_code;
+    } else {
+      w.put((2u << 1) + last, 3);
+      const int lcodes = b.lt.max_code + 1, dcodes = b.dt.max_code + 1, blcodes = b.max_blindex + 1;
+      w.put(static_cast<uint32_t>(lcodes - 257), 5);
+      w.put(static_cast<uint32_t>(dcodes - 1), 5);
+      w.put(static_cast<uint32_t>(blcodes - 4), 4);
+      for (int rank = 0; rank < blcodes; ++rank) w.put(b.bt.len[kBlOrder[rank]], 3);
+      auto send = [&](int code, int extra_value, int extra_bits) {
+        w.put(b.bt.code[code], b.bt.len[code]);
+        if (extra_bits) w.put(static_cast<uint32_t>(extra_value), extra_bits);
+      };
+      walk_lengths(b.lt, lcodes - 1, send);
+      walk_lengths(b.dt, dcodes - 1, send);
+      llen = b.lt.len;
+      lcode = b.lt.code;
+      dlen = b.dt.len;
+      dcode = b.dt.code;
+    }
+    for (const Seg &s : b.segs) {  // compress_block
+      for (size_t i = 0; i < s.n; ++i) {
+        unsigned dist = s.dist[i], lc = s.lc[i];
+        if (dist == 0) {
+          w.put(lcode[lc], llen[lc]);
+        } else {
+          unsigned code = T.length_code[lc];
+          w.put(lcode[code + LITERALS + 1], llen[code + LITERALS + 1]);
+          int extra = kExtraL[code];
+          if (extra) w.put(lc - static_cast<unsigned>(T.base_length[code]), extra);
+          dist--;
+          code = static_cast<unsigned>(T.d_code(dist));
+          w.put(dcode[code], dlen[code]);
+          extra = kExtraD[code];
+          if (extra) w.put(dist - static_cast<unsigned>(T.base_dist[code]), extra);
+        }
+      }
+    }
+    w.put(lcode[END_BLOCK], llen[END_BLOCK]);
+  }
+  if (b.last) w.align();
+  if (w.nbits > 0) w.out.push_back(static_cast<uint8_t>(w.acc));  // partial last byte, completed by the next block
+  b.bits.swap(w.out);
+  b.bit_len = w.total;  // compress() compares this with the planned length
+}
+
+template <class F>
+void parallel_for(size_t n, int threads, F fn) {
+  std::atomic<size_t> next{0};
+  auto worker = [&]() {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= n) return;
+      fn(i);
+    }
+  };
+  const int nt = static_cast<int>(std::min<size_t>(static_cast<size_t>(std::max(threads, 1)), n));
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto &t : pool) t.join();
+}
+
+}  // namespace
+
+bool compress(const uint8_t *data, size_t size, int threads, int windows_per_chunk, std::vector<uint8_t> *out,
+              size_t verify_prefix) {
+  if (data == nullptr || out == nullptr || threads < 1 || windows_per_chunk < 4) return false;
+  const uint64_t C = static_cast<uint64_t>(windows_per_chunk) * W;
+  if (size < 4 * W || size >= (uint64_t(1) << 32) - 2 * W) return false;
+  const size_t njobs = std::max<size_t>(1, static_cast<size_t>(size / C));  // the last job takes the remainder too
+
+  // The last job reads up to 258 + 1 bytes past the end; zlib's window holds there what was 32 KiB earlier.
+  const uint64_t last_begin = (njobs - 1) * C;
+  const uint64_t tail_lo = last_begin == 0 ? 0 : last_begin - W;
+  std::vector<uint8_t> tail(static_cast<size_t>(size - tail_lo) + MAX_MATCH + 8);
+  std::memcpy(tail.data(), data + tail_lo, static_cast<size_t>(size - tail_lo));
+  for (uint64_t abs = size; abs < size + MAX_MATCH + 8; ++abs) tail[static_cast<size_t>(abs - tail_lo)] = data[abs - W];
+
+  static const bool check_phase = [] {
+    const char *e = std::getenv("SPZ_AMD_EXACT_GZIP_CHECK");
+    return e && e[0] == '1';
+  }();
+  static const bool timing = std::getenv("SPZ_AMD_EXACT_GZIP_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[exactgz] %-10s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
+  std::vector<Job> jobs(njobs);
+  for (size_t i = 0; i < njobs; ++i) {
+    Job &j = jobs[i];
+    j.size = size;
+    j.begin = i * C;
+    j.last = (i + 1 == njobs);
+    j.stop = j.last ? size : (i + 1) * C + OVERLAP;
+    j.d = j.last ? tail.data() - tail_lo : data;
+    j.check_phase = check_phase;
+    if (i > 0) {
+      j.rec_succ_lo = j.begin;
+      j.rec_succ.assign(OVERLAP + MAX_MATCH + 2, TopRec{});
+    }
+    if (!j.last) {
+      j.rec_pred_lo = (i + 1) * C;
+      j.rec_pred.assign(OVERLAP + MAX_MATCH + 2, TopRec{});
+    }
+  }
+  // CRC-32 of the input rides along with the parse jobs (folded with crc32_combine afterwards).
+  std::vector<uLong> crcs(njobs);
+  parallel_for(njobs, threads, [&](size_t i) {
+    jobs[i].run();
+    const uint64_t lo = jobs[i].begin, hi = jobs[i].last ? size : (i + 1) * C;
+    uLong c = crc32(0L, Z_NULL, 0);
+    for (uint64_t p = lo; p < hi;) {
+      const uint64_t n = std::min<uint64_t>(hi - p, uint64_t(1) << 30);
+      c = crc32(c, data + p, static_cast<uInt>(n));
+      p += n;
+    }
+    crcs[i] = c;
+  });
+  lap("parse+crc");
+  for (const Job &j : jobs) {
+    if (!j.phase_ok) return false;
+  }
+
+  // ---- splice: job i contributes symbols [lo[i], hi[i])
+  std::vector<size_t> lo(njobs, 0), hi(njobs, 0);
+  for (size_t i = 0; i < njobs; ++i) hi[i] = jobs[i].sym_lc.size();
+  for (size_t i = 0; i + 1 < njobs; ++i) {
+    const Job &a = jobs[i], &b = jobs[i + 1];
+    bool found = false;
+    for (size_t k = 0; k < a.rec_pred.size() && k < b.rec_succ.size(); ++k) {
+      if (a.rec_pred[k].state != 0 && a.rec_pred[k].state == b.rec_succ[k].state) {
+        hi[i] = a.rec_pred[k].symcount;
+        lo[i + 1] = b.rec_succ[k].symcount;
+        found = true;
+        break;
+      }
+    }
+    if (!found || hi[i] < lo[i]) return false;
+  }
+  std::vector<uint64_t> goff(njobs + 1, 0);  // global symbol index of each job's first contributed symbol
+  for (size_t i = 0; i < njobs; ++i) goff[i + 1] = goff[i] + (hi[i] - lo[i]);
+  const uint64_t total_syms = goff[njobs];
+
+  // ---- blocks: a block is flushed when the symbol buffer fills (BLOCK_SYMS) and at Z_FINISH, where the
+  // final (possibly empty) block carries the last-block flag.  The literal that is still pending when the
+  // input ends is tallied without a buffer check, so if it is the one that fills the buffer, that full block
+  // is the final one.
+  size_t nblocks = static_cast<size_t>(total_syms / BLOCK_SYMS) + 1;
+  if (total_syms > 0 && total_syms % BLOCK_SYMS == 0 && jobs[njobs - 1].tail_literal) nblocks -= 1;
+  std::vector<Block> blocks(nblocks);
+  {
+    size_t job = 0;
+    for (size_t bi = 0; bi < nblocks; ++bi) {
+      Block &b = blocks[bi];
+      const uint64_t g0 = static_cast<uint64_t>(bi) * BLOCK_SYMS, g1 = std::min<uint64_t>(total_syms, g0 + BLOCK_SYMS);
+      b.nsyms = static_cast<size_t>(g1 - g0);
+      b.last = (bi + 1 == nblocks);
+      uint64_t g = g0;
+      while (g < g1) {
+        while (goff[job + 1] <= g) ++job;
+        const uint64_t take = std::min<uint64_t>(g1, goff[job + 1]) - g;
+        const size_t off = lo[job] + static_cast<size_t>(g - goff[job]);
+        b.segs.push_back({jobs[job].sym_dist.data() + off, jobs[job].sym_lc.data() + off, static_cast<size_t>(take)});
+        g += take;
+      }
+    }
+  }
+  lap("splice");
+  parallel_for(nblocks, threads, [&](size_t bi) { plan_block(blocks[bi]); });
+  lap("plan");
+
+  // ---- serial: positions, stored / static / dynamic, bit offsets (the rest of _tr_flush_block's decision)
+  uint64_t pos = 0, bit = 0;
+  for (size_t bi = 0; bi < nblocks; ++bi) {
+    Block &b = blocks[bi];
+    b.start = pos;
+    pos += b.bytes;
+    // loop top of the iteration that tallied the block's last symbol (Z_FINISH flush: the end of the input)
+    const uint64_t s_flush = b.last ? size : (pos - b.last_sym_len + 1);
+    const bool buf_in_window = b.start >= base_at(s_flush, size);
+    int64_t opt_lenb = (b.opt_len + 3 + 7) >> 3;
+    const int64_t static_lenb = (b.static_len + 3 + 7) >> 3;
+    if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+    b.bit_start = bit;
+    if (static_cast<int64_t>(b.bytes) + 4 <= opt_lenb && buf_in_window) {
+      if (b.bytes > 0xffff) return false;
+      b.choice = STORED;
+      const uint64_t after_type = bit + 3;
+      b.bit_len = 3 + ((8 - (after_type & 7)) & 7) + 32 + 8 * b.bytes;
+    } else if (static_lenb == opt_lenb) {
+      b.choice = STATIC;
+      b.bit_len = 3 + static_cast<uint64_t>(b.static_len);
+    } else {
+      b.choice = DYNAMIC;
+      b.bit_len = 3 + static_cast<uint64_t>(b.opt_len);
+    }
+    if (b.last) b.bit_len += (8 - ((bit + b.bit_len) & 7)) & 7;  // bi_windup
+    bit += b.bit_len;
+  }
+  if (pos != size) return false;
+  std::atomic<bool> bad{false};
+  parallel_for(nblocks, threads, [&](size_t bi) {
+    const uint64_t planned = blocks[bi].bit_len;
+    encode_block(blocks[bi], data);
+    if (blocks[bi].bit_len != planned) bad = true;
+  });
+  if (bad) return false;
+  lap("encode");
+
+  // ---- assemble: 10-byte header (deflate.c: no flags, mtime 0, xfl 0, OS_CODE 3), bit strings, CRC-32, ISIZE
+  const uint64_t deflate_bytes = bit / 8;
+  out->assign(static_cast<size_t>(10 + deflate_bytes + 8), 0);
+  const uint8_t header[10] = {0x1f, 0x8b, 0x08, 0x00, 0, 0, 0, 0, 0x00, 0x03};
+  std::memcpy(out->data(), header, 10);
+  uint8_t *body = out->data() + 10;
+  for (const Block &b : blocks) {
+    const size_t at = static_cast<size_t>(b.bit_start / 8);
+    if (b.bits.empty()) continue;
+    body[at] |= b.bits[0];
+    if (b.bits.size() > 1) std::memcpy(body + at + 1, b.bits.data() + 1, b.bits.size() - 1);
+  }
+  uLong crc = crcs[0];
+  for (size_t i = 1; i < njobs; ++i) {
+    const uint64_t n = (jobs[i].last ? size : (i + 1) * C) - jobs[i].begin;
+    crc = crc32_combine(crc, crcs[i], static_cast<z_off_t>(n));
+  }
+  uint8_t *trailer = body + deflate_bytes;
+  for (int k = 0; k < 4; ++k) trailer[k] = static_cast<uint8_t>(crc >> (8 * k));
+  for (int k = 0; k < 4; ++k) trailer[4 + k] = static_cast<uint8_t>((size & 0xffffffffu) >> (8 * k));
+  lap("assemble");
+
+  // ---- self-check against the linked zlib: deflate the first `verify` input bytes with zlib itself and
+  // compare every output byte that cannot depend on where that prefix ends (whole blocks that end at least
+  // 1 KiB before it).  Guards against a zlib whose algorithm differs from the one restated here.
+  if (verify_prefix > 0) {
+    const uint64_t verify = std::min<uint64_t>(size, verify_prefix);
+    uint64_t safe_bits = 0;
+    for (const Block &b : blocks) {
+      const uint64_t end_pos = b.start + b.bytes;
+      if (verify == size || end_pos + 1024 <= verify) safe_bits = b.bit_start + b.bit_len;
+      else break;
+    }
+    const size_t safe_bytes = 10 + static_cast<size_t>(safe_bits / 8) + (verify == size ? 8 : 0);
+    std::vector<uint8_t> z(compressBound(static_cast<uLong>(verify)) + 64);
+    z_stream zs = {};
+    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 9, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef *>(data);
+    zs.avail_in = static_cast<uInt>(verify);
+    zs.next_out = z.data();
+    zs.avail_out = static_cast<uInt>(z.size());
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t zn = zs.total_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END || zn < safe_bytes || out->size() < safe_bytes ||
+        std::memcmp(z.data(), out->data(), safe_bytes) != 0) {
+      return false;
+    }
+    lap("verify");
+  }
+  return true;
+}
+
+}  // namespace exactgz
+}  // namespace spz

@@ -22,6 +22,7 @@
 #include <thread>
 
 #include "spz_amd.h"
+#include "spz_deflate.hpp"
 
 namespace spz {
 namespace {
@@ -356,7 +357,26 @@ bool PackedGaussians::usesFloat16() const {  // load-spz.cc:465
 }
 
 // ---- gzip, load-spz.cc:141-214 -------------------------------------------------------------------
+namespace {
+// Threads for the byte-identical parallel writer (spz_deflate.cpp): SPZ_AMD_GZIP_EXACT_THREADS, default
+// min(cores, 32); 0 or 1 keeps everything in zlib.
+int exactGzipThreads() {
+  const char *e = std::getenv("SPZ_AMD_GZIP_EXACT_THREADS");
+  if (e) return std::max(0, std::atoi(e));
+  return static_cast<int>(std::min<unsigned>(std::thread::hardware_concurrency(), 32u));
+}
+}  // namespace
+
 bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out) {
+  // Large inputs: the multi-threaded writer that reproduces zlib's bytes exactly (it checks itself against
+  // zlib on a prefix, and declines inputs it cannot split); zlib itself otherwise and as the fallback.
+  constexpr size_t kExactMinBytes = size_t(8) << 20;
+  if (size >= kExactMinBytes && std::strcmp(zlibVersion(), "1.2.11") == 0) {
+    const int threads = exactGzipThreads();
+    if (threads > 1 && exactgz::compress(data, size, threads, /*windows_per_chunk=*/32, out, /*verify_prefix=*/size_t(256) << 10)) {
+      return true;
+    }
+  }
   z_stream stream = {};
   // Same parameters as load-spz.cc:190: default level, gzip wrapper, memLevel 9.
   if (deflateInit2(&stream, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 9, Z_DEFAULT_STRATEGY) != Z_OK) {

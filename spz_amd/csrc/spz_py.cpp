@@ -18,6 +18,7 @@
 
 #include "spz_amd.h"
 #include "spz_amd_host.hpp"
+#include "spz_deflate.hpp"
 
 namespace py = pybind11;
 
@@ -231,6 +232,19 @@ PYBIND11_MODULE(spz, m) {
     if (!ok) throw std::runtime_error("compressGzippedParallel failed");
     return py::bytes(reinterpret_cast<const char *>(out.data()), out.size());
   }, py::arg("data"), py::arg("threads"), "Opt-in multi-threaded gzip (one member, independent deflate blocks).");
+  m.def("_compress_gzipped_exact", [](const py::bytes &data, int threads, int windows_per_chunk, size_t verify_prefix) -> py::object {
+    const std::string in = data;
+    std::vector<uint8_t> out;
+    bool ok;
+    {
+      py::gil_scoped_release release;
+      ok = spz::exactgz::compress(reinterpret_cast<const uint8_t *>(in.data()), in.size(), threads, windows_per_chunk, &out,
+                                  verify_prefix);
+    }
+    if (!ok) return py::none();
+    return py::bytes(reinterpret_cast<const char *>(out.data()), out.size());
+  }, py::arg("data"), py::arg("threads") = 8, py::arg("windows_per_chunk") = 32, py::arg("verify_prefix") = 0,
+     "The multi-threaded writer with zlib's exact bytes (None when it declines the input).");
   m.def("_decompress_gzipped", [](const py::bytes &data) -> py::object {
     const std::string in = data;
     std::vector<uint8_t> out;
