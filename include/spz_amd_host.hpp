@@ -144,7 +144,7 @@ bool saveSplatToPly(const GaussianCloud &gaussians, const PackOptions &options, 
 GaussianCloud loadSplatFromPly(const std::string &filename, const UnpackOptions &options);
 void serializePackedGaussians(const PackedGaussians &packed, std::ostream *out);
 // load-spz.cc:186-214.  The bytes are zlib's (level 6, one deflate stream, gzip wrapper): for inputs of
-// 8 MiB and more they are produced by a multi-threaded writer that reproduces zlib 1.2.11's output exactly
+// 1 MiB and more they are produced by a multi-threaded writer that reproduces zlib 1.2.11's output exactly
 // (SPZ_AMD_GZIP_EXACT_THREADS, default min(cores, 32); 1 = zlib itself), otherwise by zlib.
 bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out);
 

@@ -370,12 +370,13 @@ int exactGzipThreads() {
 bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out) {
   // Large inputs: the multi-threaded writer that reproduces zlib's bytes exactly (it checks itself against
   // zlib on a prefix, and declines inputs it cannot split); zlib itself otherwise and as the fallback.
-  constexpr size_t kExactMinBytes = size_t(8) << 20;
+  constexpr size_t kExactMinBytes = size_t(1) << 20;
   if (size >= kExactMinBytes && std::strcmp(zlibVersion(), "1.2.11") == 0) {
     const int threads = exactGzipThreads();
-    if (threads > 1 && exactgz::compress(data, size, threads, /*windows_per_chunk=*/32, out, /*verify_prefix=*/size_t(256) << 10)) {
-      return true;
-    }
+    // parse jobs of 1 MiB; smaller ones (down to 128 KiB) when that is what it takes to give every thread two
+    const int windows = static_cast<int>(std::min<size_t>(32, std::max<size_t>(4, size / (size_t(threads > 0 ? threads : 1) * 2 * 32768))));
+    const size_t verify = std::min<size_t>(size_t(256) << 10, std::max<size_t>(size_t(64) << 10, size / 16));
+    if (threads > 1 && exactgz::compress(data, size, threads, windows, out, verify)) return true;
   }
   z_stream stream = {};
   // Same parameters as load-spz.cc:190: default level, gzip wrapper, memLevel 9.

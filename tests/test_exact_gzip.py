@@ -94,7 +94,7 @@ def test_self_check_against_zlib_prefix():
 
 
 def test_default_save_path_on_a_real_stream_equals_zlib_and_the_reference(reference):
-    """A 19.5 MB SH3 stream (above the 8 MiB switch-over of compressGzipped): the default container bytes
+    """A 19.5 MB SH3 stream and a 1.3 MB one (above the 1 MiB switch-over of compressGzipped): the default container bytes
     equal zlib's and the reference's own compressGzipped."""
     from spz_amd.synth import make_cloud_numpy
     n = 300_000
@@ -105,6 +105,8 @@ def test_default_save_path_on_a_real_stream_equals_zlib_and_the_reference(refere
     assert got == zlib_gzip(raw)
     assert got == reference.compress_gzipped(stream).tobytes()
     assert spz._decompress_gzipped(got) == raw
+    small = raw[: 16 + 65 * 20000]
+    assert spz._compress_gzipped(small) == zlib_gzip(small)
     os.environ["SPZ_AMD_GZIP_EXACT_THREADS"] = "1"                               # zlib only
     try:
         assert spz._compress_gzipped(raw) == got
