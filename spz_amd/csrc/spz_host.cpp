@@ -23,6 +23,7 @@
 
 #include "spz_amd.h"
 #include "spz_deflate.hpp"
+#include "spz_inflate.hpp"
 
 namespace spz {
 namespace {
@@ -658,6 +659,11 @@ bool decompressGzipped(const uint8_t *compressed, size_t size, std::vector<uint8
     const size_t headerLen = parseGzipHeader(compressed, size, &idx);
     if (headerLen != 0) {
       if (!idx.pieceBytes.empty() && inflateIndexed(compressed, size, headerLen, idx, out)) return true;
+      // an ordinary single deflate stream (what the reference writes): decoded in parallel when it is large
+      if (size >= (size_t(4) << 20)) {
+        const int threads = gunzipThreads(size_t(1) << 20);
+        if (threads > 1 && pinflate::inflate(compressed, size, headerLen, threads, out)) return true;
+      }
       if (inflateWholeBuffer(compressed, size, out)) return true;
     }
   }

@@ -1,0 +1,532 @@
+// spz_inflate.cpp — multi-threaded inflate of a single, ordinary deflate stream.
+//
+// Why: once the dequantise step runs on the GPU, gunzip is ~80 % of a loadSpz, and the
+// files the reference writes are one zlib deflate stream with no index.  A deflate stream can still be
+// decoded in parallel (the idea of pugz, Kerbiriou & Chikhi 2019), and here every result is verified
+// against the member's CRC-32, so the fast path can only ever be faster, not different:
+//   1. cut the compressed bytes into chunks; in each, search bit by bit for the start of a dynamic-Huffman
+//      block (header fields in range, both code-length sets complete, the block decodes to its end-of-block
+//      and a plausible header follows);
+//   2. pass 1, parallel: decode every chunk from its block start up to the next chunk's block start (they
+//      must link up bit-exactly) WITHOUT its 32 KiB of left context: only the sliding window is kept, in
+//      16-bit symbols, where 256 + k stands for "byte k of the predecessor's final window";
+//   3. serial, tiny: resolve each chunk's final window against its predecessor's, prefix-sum the lengths;
+//   4. pass 2, parallel: decode every chunk again, now with its resolved context, straight into place;
+//   5. CRC-32 (parallel, crc32_combine) and ISIZE must match the gzip trailer.
+// Any irregularity returns false and the caller's serial reader decides.
+#include "spz_inflate.hpp"
+
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+
+namespace spz {
+namespace pinflate {
+namespace {
+
+constexpr uint32_t W = 32768, WMASK = W - 1;
+constexpr int FAST_L = 11, FAST_D = 9;
+constexpr uint64_t NONE = ~uint64_t(0);
+
+const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+
+struct Bits {  // the deflate data of the member
+  const uint8_t *p;
+  uint64_t nbits;
+  size_t nbytes;
+  // >= 56 valid bits starting at bit position `at` (zeros past the end)
+  inline uint64_t peek(uint64_t at) const {
+    const size_t b = static_cast<size_t>(at >> 3);
+    uint64_t v = 0;
+    if (b + 8 <= nbytes) {
+      std::memcpy(&v, p + b, 8);
+    } else {
+      for (size_t k = 0; b + k < nbytes && k < 8; ++k) v |= static_cast<uint64_t>(p[b + k]) << (8 * k);
+    }
+    return v >> (at & 7);
+  }
+};
+
+// Canonical Huffman decoder: a direct table for codes up to `fast` bits, canonical walk for longer ones.
+struct Huff {
+  uint16_t fast[1 << FAST_L];
+  uint16_t count[16];
+  uint16_t symbol[288];
+  int fastbits = 0;
+  int ncodes = 0;
+
+  // returns false for an over-subscribed set, or an incomplete one that is not a single code
+  bool build(const uint8_t *lens, int n, int fast_bits) {
+    fastbits = fast_bits;
+    std::memset(count, 0, sizeof(count));
+    for (int i = 0; i < n; ++i) count[lens[i]]++;
+    ncodes = n - count[0];
+    count[0] = 0;
+    int left = 1;
+    for (int len = 1; len <= 15; ++len) {
+      left <<= 1;
+      left -= count[len];
+      if (left < 0) return false;
+    }
+    if (left > 0 && ncodes != 1 && ncodes != 0) return false;
+    uint16_t offs[16];
+    offs[1] = 0;
+    for (int len = 1; len < 15; ++len) offs[len + 1] = static_cast<uint16_t>(offs[len] + count[len]);
+    for (int i = 0; i < n; ++i) {
+      if (lens[i]) symbol[offs[lens[i]]++] = static_cast<uint16_t>(i);
+    }
+    std::memset(fast, 0, sizeof(uint16_t) << fastbits);
+    unsigned code = 0;
+    int idx = 0;
+    for (int len = 1; len <= fastbits; ++len) {
+      for (int k = 0; k < count[len]; ++k, ++code, ++idx) {
+        unsigned rev = 0;  // codes are sent most significant bit first
+        for (int b = 0; b < len; ++b) rev |= ((code >> b) & 1u) << (len - 1 - b);
+        const uint16_t e = static_cast<uint16_t>((symbol[idx] << 4) | len);
+        for (unsigned j = rev; j < (1u << fastbits); j += (1u << len)) fast[j] = e;
+      }
+      code <<= 1;
+    }
+    return true;
+  }
+  // returns the symbol and sets *len, or -1
+  inline int decode(uint64_t bits, int *len) const {
+    const uint16_t e = fast[bits & ((1u << fastbits) - 1)];
+    if (e) {
+      *len = e & 15;
+      return e >> 4;
+    }
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l <= 15; ++l) {
+      code |= static_cast<int>(bits & 1);
+      bits >>= 1;
+      const int c = count[l];
+      if (code - c < first) {
+        *len = l;
+        return symbol[index + (code - first)];
+      }
+      index += c;
+      first += c;
+      first <<= 1;
+      code <<= 1;
+    }
+    return -1;
+  }
+};
+
+struct StaticHuff {
+  Huff lit, dist;
+  StaticHuff() {
+    uint8_t l[288];
+    for (int i = 0; i < 144; ++i) l[i] = 8;
+    for (int i = 144; i < 256; ++i) l[i] = 9;
+    for (int i = 256; i < 280; ++i) l[i] = 7;
+    for (int i = 280; i < 288; ++i) l[i] = 8;
+    lit.build(l, 288, FAST_L);
+    uint8_t d[30];
+    for (int i = 0; i < 30; ++i) d[i] = 5;
+    dist.build(d, 30, FAST_D);
+  }
+};
+const StaticHuff &staticHuff() {
+  static const StaticHuff s;
+  return s;
+}
+
+// Reads a dynamic block's code lengths (after the 3 header bits) and builds both decoders.
+bool readDynamic(const Bits &in, uint64_t *at, Huff *lit, Huff *dist) {
+  uint64_t pos = *at;
+  if (pos + 14 > in.nbits) return false;
+  uint64_t v = in.peek(pos);
+  const int hlit = static_cast<int>(v & 31) + 257, hdist = static_cast<int>((v >> 5) & 31) + 1,
+            hclen = static_cast<int>((v >> 10) & 15) + 4;
+  if (hlit > 286 || hdist > 30) return false;
+  pos += 14;
+  uint8_t cl[19] = {};
+  if (pos + 3 * static_cast<uint64_t>(hclen) > in.nbits) return false;
+  v = in.peek(pos);
+  for (int i = 0; i < hclen; ++i) {  // 19 * 3 = 57 bits: one peek is not always enough
+    if (i == 16) v = in.peek(pos + 48);
+    cl[kClOrder[i]] = static_cast<uint8_t>((v >> (3 * (i & 15))) & 7);
+  }
+  pos += 3 * static_cast<uint64_t>(hclen);
+  Huff clh;
+  if (!clh.build(cl, 19, 7)) return false;
+  if (clh.ncodes < 1) return false;
+  uint8_t lens[286 + 30] = {};
+  int n = 0;
+  const int total = hlit + hdist;
+  while (n < total) {
+    if (pos >= in.nbits) return false;
+    v = in.peek(pos);
+    int len;
+    const int sym = clh.decode(v, &len);
+    if (sym < 0) return false;
+    v >>= len;
+    pos += static_cast<uint64_t>(len);
+    if (sym < 16) {
+      lens[n++] = static_cast<uint8_t>(sym);
+    } else {
+      int rep, val = 0;
+      if (sym == 16) {
+        if (n == 0) return false;
+        val = lens[n - 1];
+        rep = 3 + static_cast<int>(v & 3);
+        pos += 2;
+      } else if (sym == 17) {
+        rep = 3 + static_cast<int>(v & 7);
+        pos += 3;
+      } else {
+        rep = 11 + static_cast<int>(v & 127);
+        pos += 7;
+      }
+      if (n + rep > total) return false;
+      while (rep--) lens[n++] = static_cast<uint8_t>(val);
+    }
+  }
+  if (pos > in.nbits || lens[256] == 0) return false;
+  if (!lit->build(lens, hlit, FAST_L)) return false;
+  if (!dist->build(lens + hlit, hdist, FAST_D)) return false;
+  if (lit->ncodes < 2) return false;  // zlib never writes fewer; keeps the block-start search strict
+  *at = pos;
+  return true;
+}
+
+// ---- sinks ---------------------------------------------------------------------------------------------
+struct NullSink {  // block-start validation
+  uint64_t n = 0;
+  inline bool lit(uint8_t) { ++n; return true; }
+  inline bool match(uint32_t len, uint32_t) { n += len; return true; }
+  inline bool raw(const uint8_t *, uint32_t len) { n += len; return true; }
+};
+
+struct WindowSink {  // pass 1: only the sliding window, in symbols (256 + k = byte k of the predecessor's window)
+  uint16_t *ring;
+  uint64_t n = 0;
+  inline bool lit(uint8_t b) {
+    ring[n++ & WMASK] = b;
+    return true;
+  }
+  inline bool match(uint32_t len, uint32_t dist) {
+    for (uint32_t k = 0; k < len; ++k, ++n) ring[n & WMASK] = ring[(n - dist) & WMASK];
+    return true;
+  }
+  inline bool raw(const uint8_t *src, uint32_t len) {
+    for (uint32_t k = 0; k < len; ++k) ring[n++ & WMASK] = src[k];
+    return true;
+  }
+};
+
+struct ByteSink {  // pass 2: bytes into place; ctx = the 32 KiB before the chunk (nullptr for the first chunk)
+  uint8_t *dst;
+  uint64_t cap;
+  const uint8_t *ctx;
+  uint64_t n = 0;
+  inline bool lit(uint8_t b) {
+    if (n >= cap) return false;
+    dst[n++] = b;
+    return true;
+  }
+  inline bool match(uint32_t len, uint32_t dist) {
+    if (n + len > cap) return false;
+    if (dist > n) {
+      if (ctx == nullptr || dist - n > W) return false;  // reaches before the start of the data
+      while (len && dist > n) {
+        dst[n] = ctx[W - (dist - n)];
+        ++n;
+        --len;
+      }
+    }
+    if (dist >= 8 && len >= 8) {
+      while (len >= 8) {  // non-overlapping 8-byte steps
+        std::memcpy(dst + n, dst + n - dist, 8);
+        n += 8;
+        len -= 8;
+      }
+    }
+    for (; len; --len, ++n) dst[n] = dst[n - dist];
+    return true;
+  }
+  inline bool raw(const uint8_t *src, uint32_t len) {
+    if (n + len > cap) return false;
+    std::memcpy(dst + n, src, len);
+    n += len;
+    return true;
+  }
+};
+
+template <class Sink>
+bool decodeHuffBlock(const Bits &in, uint64_t *at, const Huff &L, const Huff &D, Sink &sink) {
+  uint64_t pos = *at;
+  for (;;) {
+    if (pos >= in.nbits) return false;
+    uint64_t bits = in.peek(pos);
+    int len;
+    int sym = L.decode(bits, &len);
+    if (sym < 0) return false;
+    if (sym < 256) {
+      if (!sink.lit(static_cast<uint8_t>(sym))) return false;
+      pos += static_cast<uint64_t>(len);
+      continue;
+    }
+    if (sym == 256) {
+      pos += static_cast<uint64_t>(len);
+      if (pos > in.nbits) return false;
+      *at = pos;
+      return true;
+    }
+    sym -= 257;
+    if (sym >= 29) return false;
+    bits >>= len;
+    int used = len;
+    const uint32_t length = kLenBase[sym] + static_cast<uint32_t>(bits & ((1u << kLenExtra[sym]) - 1));
+    bits >>= kLenExtra[sym];
+    used += kLenExtra[sym];
+    const int dsym = D.decode(bits, &len);
+    if (dsym < 0 || dsym >= 30) return false;
+    bits >>= len;
+    used += len;
+    const uint32_t dist = kDistBase[dsym] + static_cast<uint32_t>(bits & ((1u << kDistExtra[dsym]) - 1));
+    used += kDistExtra[dsym];
+    pos += static_cast<uint64_t>(used);
+    if (pos > in.nbits) return false;
+    if (!sink.match(length, dist)) return false;
+  }
+}
+
+enum Outcome { FAILED, LINKED, FINAL };
+
+// Decodes whole blocks from `start` until a block would start at `stop` (LINKED) or the final block ends
+// (FINAL, *end = first bit after it).
+template <class Sink>
+Outcome decodeBlocks(const Bits &in, uint64_t start, uint64_t stop, Sink &sink, uint64_t *end) {
+  uint64_t pos = start;
+  Huff lit, dist;
+  for (;;) {
+    if (pos == stop) return LINKED;
+    if (pos > stop || pos + 3 > in.nbits) return FAILED;
+    const uint64_t v = in.peek(pos);
+    const bool final_block = v & 1;
+    const int type = static_cast<int>((v >> 1) & 3);
+    pos += 3;
+    if (type == 0) {
+      pos = (pos + 7) & ~uint64_t(7);
+      if (pos + 32 > in.nbits) return FAILED;
+      const uint64_t h = in.peek(pos);
+      const uint32_t len = static_cast<uint32_t>(h & 0xffff), nlen = static_cast<uint32_t>((h >> 16) & 0xffff);
+      if ((len ^ nlen) != 0xffff) return FAILED;
+      pos += 32;
+      if (pos + 8 * static_cast<uint64_t>(len) > in.nbits) return FAILED;
+      if (!sink.raw(in.p + (pos >> 3), len)) return FAILED;
+      pos += 8 * static_cast<uint64_t>(len);
+    } else if (type == 1) {
+      const StaticHuff &s = staticHuff();
+      if (!decodeHuffBlock(in, &pos, s.lit, s.dist, sink)) return FAILED;
+    } else if (type == 2) {
+      if (!readDynamic(in, &pos, &lit, &dist)) return FAILED;
+      if (!decodeHuffBlock(in, &pos, lit, dist, sink)) return FAILED;
+    } else {
+      return FAILED;
+    }
+    if (final_block) {
+      *end = pos;
+      return FINAL;
+    }
+  }
+}
+
+// First bit position in [lo, hi) where a non-final dynamic block starts, decodes to its end-of-block and is
+// followed by a plausible header.
+uint64_t findBlockStart(const Bits &in, uint64_t lo, uint64_t hi) {
+  Huff lit, dist;
+  for (uint64_t p = lo; p < hi && p + 64 < in.nbits; ++p) {
+    const uint64_t v = in.peek(p);
+    if ((v & 7) != 4) continue;                          // BFINAL = 0, BTYPE = 2
+    if (((v >> 3) & 31) > 29 || ((v >> 8) & 31) > 29) continue;
+    {  // the code-length code must be complete (zlib's always is): Kraft sum over its 3-bit lengths
+      const int hclen = static_cast<int>((v >> 13) & 15) + 4;
+      uint64_t c = v >> 17;  // 39+ valid bits = 13 lengths; the rest from a second peek
+      unsigned kraft = 0;
+      for (int i = 0; i < hclen; ++i) {
+        if (i == 13) c = in.peek(p + 17 + 39);
+        const unsigned l = static_cast<unsigned>(c & 7);
+        c >>= 3;
+        if (l) kraft += 128u >> l;
+      }
+      if (kraft != 128) continue;
+    }
+    uint64_t pos = p + 3;
+    if (!readDynamic(in, &pos, &lit, &dist)) continue;
+    NullSink sink;
+    if (!decodeHuffBlock(in, &pos, lit, dist, sink)) continue;
+    if (sink.n < 64) continue;                           // real blocks carry thousands of bytes
+    if (pos + 3 > in.nbits || ((in.peek(pos) >> 1) & 3) == 3) continue;
+    return p;
+  }
+  return NONE;
+}
+
+template <class F>
+void parallel_for(size_t n, int threads, F fn) {
+  std::atomic<size_t> next{0};
+  auto worker = [&]() {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= n) return;
+      fn(i);
+    }
+  };
+  const int nt = static_cast<int>(std::min<size_t>(static_cast<size_t>(std::max(threads, 1)), n));
+  std::vector<std::thread> pool;
+  for (int t = 1; t < nt; ++t) pool.emplace_back(worker);
+  worker();
+  for (auto &t : pool) t.join();
+}
+
+}  // namespace
+
+bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std::vector<uint8_t> *out) {
+  if (gz == nullptr || out == nullptr || threads < 2 || size < header_len + 8 + (size_t(1) << 20)) return false;
+  const size_t dbytes = size - header_len - 8;
+  Bits in{gz + header_len, 8 * static_cast<uint64_t>(dbytes), dbytes};
+  auto le32 = [&](const uint8_t *q) {
+    return static_cast<uint32_t>(q[0]) | (static_cast<uint32_t>(q[1]) << 8) | (static_cast<uint32_t>(q[2]) << 16) |
+           (static_cast<uint32_t>(q[3]) << 24);
+  };
+  const uint32_t want_crc = le32(gz + size - 8);
+  const uint64_t isize = le32(gz + size - 4);
+  if (isize == 0 || isize > static_cast<uint64_t>(dbytes) * 1032 + 1024) return false;  // ISIZE is mod 2^32: larger members go serial
+
+  static const bool timing = std::getenv("SPZ_AMD_PINFLATE_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[pinflate] %-8s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
+  const size_t nchunks = std::min<size_t>(static_cast<size_t>(threads) * 2, dbytes / (size_t(256) << 10));
+  if (nchunks < 2) return false;
+  // ---- 1. block starts
+  std::vector<uint64_t> start(nchunks, NONE);
+  start[0] = 0;
+  parallel_for(nchunks - 1, threads, [&](size_t k) {
+    const size_t i = k + 1;
+    const uint64_t lo = 8 * static_cast<uint64_t>(dbytes / nchunks * i), hi = 8 * static_cast<uint64_t>(dbytes / nchunks * (i + 1));
+    // zlib's Huffman blocks are at most ~60 KiB of compressed data, so a start that exists is near; the cap
+    // keeps the cost of finding out that there is none (stored data) small
+    const uint64_t cap = lo + 8 * (uint64_t(128) << 10);
+    start[i] = findBlockStart(in, lo, std::min<uint64_t>(cap, i + 1 == nchunks ? in.nbits : hi));
+  });
+  lap("search");
+  std::vector<size_t> live;  // chunks that have a block start
+  for (size_t i = 0; i < nchunks; ++i) {
+    if (start[i] != NONE) live.push_back(i);
+  }
+  if (live.size() < 2 || live.size() * 2 < nchunks) return false;  // mostly stored / static data: no gain
+  const size_t n = live.size();
+  if (timing) {
+    uint64_t span = 0;
+    for (size_t j = 0; j < n; ++j) span = std::max<uint64_t>(span, (j + 1 < n ? start[live[j + 1]] : in.nbits) - start[live[j]]);
+    std::fprintf(stderr, "[pinflate] %zu chunks, %zu with a block start, largest span %.1f%% of the data\n", nchunks, n,
+                 100.0 * static_cast<double>(span) / static_cast<double>(in.nbits));
+  }
+
+  // ---- 2. pass 1: the first chunk decodes straight into place, the others keep only their window
+  out->resize(isize);
+  std::vector<uint64_t> length(n, 0);
+  std::vector<std::vector<uint16_t>> window(n);
+  std::vector<uint64_t> end_bit(n, 0);
+  std::atomic<bool> ok{true};
+  parallel_for(n, threads, [&](size_t j) {
+    const uint64_t from = start[live[j]], to = (j + 1 < n) ? start[live[j + 1]] : NONE;
+    uint64_t end = 0;
+    Outcome r;
+    if (j == 0) {
+      ByteSink sink{out->data(), isize, nullptr};
+      r = decodeBlocks(in, from, to, sink, &end);
+      length[j] = sink.n;
+    } else {
+      window[j].resize(W);
+      for (uint32_t k = 0; k < W; ++k) window[j][k] = static_cast<uint16_t>(256 + k);
+      WindowSink sink{window[j].data()};
+      r = decodeBlocks(in, from, to, sink, &end);
+      length[j] = sink.n;
+    }
+    end_bit[j] = end;
+    if (r != (j + 1 < n ? LINKED : FINAL)) ok = false;
+  });
+  lap("pass1");
+  if (!ok) return false;
+  if (((end_bit[n - 1] + 7) >> 3) != dbytes) return false;  // the member must end exactly at the trailer
+
+  // ---- 3. offsets and contexts
+  std::vector<uint64_t> offset(n + 1, 0);
+  for (size_t j = 0; j < n; ++j) offset[j + 1] = offset[j] + length[j];
+  if (offset[n] != isize) return false;
+  std::vector<std::vector<uint8_t>> ctx(n);  // ctx[j] = the W bytes before chunk j + 1's first byte
+  for (size_t j = 0; j + 1 < n; ++j) {
+    ctx[j].assign(W, 0);
+    if (j == 0) {
+      const uint64_t have = std::min<uint64_t>(W, length[0]);
+      std::memcpy(ctx[0].data() + (W - have), out->data() + (length[0] - have), static_cast<size_t>(have));
+      // bytes before the start of the data do not exist; a reference to them is caught in pass 2 by position
+    } else {
+      const uint16_t *ring = window[j].data();
+      for (uint32_t k = 0; k < W; ++k) {
+        const uint16_t s = ring[(length[j] + k) & WMASK];
+        ctx[j][k] = s < 256 ? static_cast<uint8_t>(s) : ctx[j - 1][s - 256];
+      }
+    }
+  }
+  // a chunk other than the first may only reach back as far as data exists
+  // (offset[j] >= W for all j >= 1 unless the first chunk is tiny; ByteSink checks distances against ctx)
+
+  // ---- 4. pass 2
+  parallel_for(n - 1, threads, [&](size_t k) {
+    const size_t j = k + 1;
+    const uint64_t from = start[live[j]], to = (j + 1 < n) ? start[live[j + 1]] : NONE;
+    ByteSink sink{out->data() + offset[j], length[j], ctx[j - 1].data()};
+    uint64_t end = 0;
+    const Outcome r = decodeBlocks(in, from, to, sink, &end);
+    if (r != (j + 1 < n ? LINKED : FINAL) || sink.n != length[j]) ok = false;
+  });
+  lap("pass2");
+  if (!ok) return false;
+  if (offset[1] < W) {
+    // references from later chunks into bytes before the start of the data would have read zeros from ctx:
+    // only the CRC can tell; it is checked next either way
+  }
+
+  // ---- 5. CRC-32 and ISIZE
+  const size_t pieces = std::min<size_t>(static_cast<size_t>(threads), static_cast<size_t>(isize / (size_t(1) << 20)) + 1);
+  std::vector<uLong> crcs(pieces);
+  std::vector<uint64_t> cut(pieces + 1);
+  for (size_t i = 0; i <= pieces; ++i) cut[i] = isize * i / pieces;
+  parallel_for(pieces, threads, [&](size_t i) {
+    uLong c = crc32(0L, Z_NULL, 0);
+    for (uint64_t p = cut[i]; p < cut[i + 1];) {
+      const uint64_t m = std::min<uint64_t>(cut[i + 1] - p, uint64_t(1) << 30);
+      c = crc32(c, out->data() + p, static_cast<uInt>(m));
+      p += m;
+    }
+    crcs[i] = c;
+  });
+  lap("crc");
+  uLong crc = crcs[0];
+  for (size_t i = 1; i < pieces; ++i) crc = crc32_combine(crc, crcs[i], static_cast<z_off_t>(cut[i + 1] - cut[i]));
+  return static_cast<uint32_t>(crc) == want_crc;
+}
+
+}  // namespace pinflate
+}  // namespace spz
