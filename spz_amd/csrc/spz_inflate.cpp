@@ -417,6 +417,7 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
   };
   const size_t nchunks = std::min<size_t>(static_cast<size_t>(threads) * 2, dbytes / (size_t(256) << 10));
   if (nchunks < 2) return false;
+  if (((in.peek(0) >> 1) & 3) == 0) return false;  // opens with a stored block: incompressible data, nothing to gain
   // ---- 1. block starts
   std::vector<uint64_t> start(nchunks, NONE);
   start[0] = 0;
