@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""gunzip of ordinary single-stream members (what the reference writes): the parallel reader against the
-serial one (libdeflate / zlib), per thread count.  Host-only; prints one JSON line per input."""
+"""gunzip of an ordinary single-stream member (what the reference writes) holding a real SH3 stream: the
+parallel reader against the serial one (libdeflate / zlib), per thread count.  Prints one JSON line."""
 import json
 import os
 import sys
@@ -16,14 +16,14 @@ import spz_amd.spz as spz  # noqa: E402
 
 
 def main():
-    n_mb = int(sys.argv[1]) if len(sys.argv) > 1 else 130
-    rng = np.random.default_rng(3)
-    # an SH3 stream look-alike: 9 B positions, 11 B small sections, 45 B bucketed sh per point
-    pts = n_mb * 1_000_000 // 65
-    pos = rng.integers(0, 256, 9 * pts, dtype=np.uint8)
-    mid = rng.integers(0, 256, 11 * pts, dtype=np.uint8)
-    sh = np.clip(np.round(rng.normal(128, 20, 45 * pts) / 8) * 8, 0, 255).astype(np.uint8)
-    raw = pos.tobytes() + mid.tobytes() + sh.tobytes()
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 2_000_000
+    from spz_amd.synth import FIELDS, make_cloud_numpy
+    c = make_cloud_numpy(n, 3, 3)
+    g = spz.GaussianCloud()
+    g.sh_degree = 3
+    for k in FIELDS:
+        setattr(g, k, c[k])
+    raw = spz._pack_to_stream(g, spz.PackOptions())      # the quantise step runs on the GPU
     os.environ["SPZ_AMD_GZIP_EXACT_THREADS"] = "32"
     gz = spz._compress_gzipped(raw)
     res = {"raw_MB": len(raw) / 1e6, "gz_MB": len(gz) / 1e6, "host_cores": os.cpu_count()}
