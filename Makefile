@@ -76,7 +76,7 @@ clean:
 # (CPU only; the GPU pool has no sanitizer support).  Mutated inputs; must finish without a report.
 fuzz: $(LIBDIR)/libspz_amd.so
 	mkdir -p $(ROOT)build
-	for t in gunzip_fuzz ply_fuzz deflate_fuzz; do \
+	for t in gunzip_fuzz ply_fuzz deflate_fuzz inflate_fuzz; do \
 	  $(CXX) -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -std=gnu++17 -I$(INC) -o $(ROOT)build/$$t \
 	    $(ROOT)tools/fuzz/$$t.cpp $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp $(CSRC)/spz_deflate.cpp $(CSRC)/spz_inflate.cpp -L$(LIBDIR) -lspz_amd -lz -ldl -lpthread \
 	    -Wl,-rpath,$(abspath $(LIBDIR)) && ASAN_OPTIONS=detect_leaks=0 $(ROOT)build/$$t || exit 1; \

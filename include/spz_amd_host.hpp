@@ -155,7 +155,8 @@ GaussianCloud unpackGaussians(const PackedGaussians &packed, const UnpackOptions
 PackedGaussians deserializePackedGaussians(std::istream &in);
 
 // Extras of this implementation -------------------------------------------------------------
-// Inverse of compressGzipped (the reference keeps it file-local, load-spz.cc:141-182).  Members written
+// Inverse of compressGzipped (the reference keeps it file-local, load-spz.cc:141-182).  Ordinary members of
+// 4 MiB and more are inflated in parallel and verified by CRC-32 (from 8 threads up).  Members written
 // by compressGzippedParallel are inflated piece-parallel (SPZ_AMD_GUNZIP_THREADS, default min(cores, 32));
 // other members go through libdeflate when the system has libdeflate.so.0 (SPZ_AMD_NO_LIBDEFLATE=1 turns
 // that off); zlib's streaming inflate, what the reference uses, is the fallback and decides every case

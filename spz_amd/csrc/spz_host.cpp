@@ -662,7 +662,8 @@ bool decompressGzipped(const uint8_t *compressed, size_t size, std::vector<uint8
       // an ordinary single deflate stream (what the reference writes): decoded in parallel when it is large
       if (size >= (size_t(4) << 20)) {
         const int threads = gunzipThreads(size_t(1) << 20);
-        if (threads > 1 && pinflate::inflate(compressed, size, headerLen, threads, out)) return true;
+        // two decoding passes with a plain decoder: pays off from about 8 threads (measured), see spz_inflate.cpp
+        if (threads >= 8 && pinflate::inflate(compressed, size, headerLen, threads, out)) return true;
       }
       if (inflateWholeBuffer(compressed, size, out)) return true;
     }

@@ -393,7 +393,11 @@ void parallel_for(size_t n, int threads, F fn) {
   for (auto &t : pool) t.join();
 }
 
+std::atomic<uint64_t> g_successes{0};
+
 }  // namespace
+
+uint64_t successCount() { return g_successes.load(); }
 
 bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std::vector<uint8_t> *out) {
   if (gz == nullptr || out == nullptr || threads < 2 || size < header_len + 8 + (size_t(1) << 20)) return false;
@@ -526,7 +530,9 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
   lap("crc");
   uLong crc = crcs[0];
   for (size_t i = 1; i < pieces; ++i) crc = crc32_combine(crc, crcs[i], static_cast<z_off_t>(cut[i + 1] - cut[i]));
-  return static_cast<uint32_t>(crc) == want_crc;
+  if (static_cast<uint32_t>(crc) != want_crc) return false;
+  g_successes.fetch_add(1);
+  return true;
 }
 
 }  // namespace pinflate

@@ -16,5 +16,8 @@ namespace pinflate {
 // invalid data, trailing bytes, a CRC mismatch.
 bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std::vector<uint8_t> *out);
 
+// Number of members this process has inflated through the parallel reader (for tests and diagnostics).
+uint64_t successCount();
+
 }  // namespace pinflate
 }  // namespace spz
