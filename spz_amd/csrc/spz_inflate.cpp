@@ -30,7 +30,7 @@ namespace spz {
 namespace pinflate {
 namespace {
 
-constexpr uint32_t W = 32768, WMASK = W - 1;
+constexpr uint32_t W = 32768;
 constexpr int FAST_L = 11, FAST_D = 9;
 constexpr uint64_t NONE = ~uint64_t(0);
 
@@ -211,20 +211,53 @@ struct NullSink {  // block-start validation
 };
 
 struct WindowSink {  // pass 1: only the sliding window, in symbols (256 + k = byte k of the predecessor's window)
-  uint16_t *ring;
+  // A linear buffer that is slid down by memmove when it fills (no per-element masking): buf[0, W) starts as
+  // the predecessor's window, `wp` is the write position, `n` the number of bytes produced so far.
+  static constexpr uint32_t CAP = 4 * W;
+  uint16_t *buf;  // CAP + MAX_MATCH entries
+  uint32_t wp = W;
   uint64_t n = 0;
+  inline void room(uint32_t need) {
+    if (wp + need > CAP) {
+      std::memmove(buf, buf + (wp - W), W * sizeof(uint16_t));
+      wp = W;
+    }
+  }
   inline bool lit(uint8_t b) {
-    ring[n++ & WMASK] = b;
+    room(1);
+    buf[wp++] = b;
+    ++n;
     return true;
   }
   inline bool match(uint32_t len, uint32_t dist) {
-    for (uint32_t k = 0; k < len; ++k, ++n) ring[n & WMASK] = ring[(n - dist) & WMASK];
+    room(len);
+    uint16_t *d = buf + wp;
+    const uint16_t *s = d - dist;
+    if (dist >= 4) {
+      uint32_t k = 0;
+      for (; k + 4 <= len; k += 4) std::memcpy(d + k, s + k, 8);  // 4 symbols at a time: dist >= 4 keeps source and target apart
+      for (; k < len; ++k) d[k] = s[k];
+    } else {
+      for (uint32_t k = 0; k < len; ++k) d[k] = s[k];
+    }
+    wp += len;
+    n += len;
     return true;
   }
   inline bool raw(const uint8_t *src, uint32_t len) {
-    for (uint32_t k = 0; k < len; ++k) ring[n++ & WMASK] = src[k];
+    while (len) {
+      const uint32_t m = std::min<uint32_t>(len, 2 * W);
+      room(m);
+      for (uint32_t k = 0; k < m; ++k) buf[wp + k] = src[k];
+      wp += m;
+      n += m;
+      src += m;
+      len -= m;
+    }
     return true;
   }
+  // symbol of the byte `back` positions before the end (1 <= back <= W)
+  inline uint16_t tail(uint32_t back) const { return buf[wp - back]; }
 };
 
 struct ByteSink {  // pass 2: bytes into place; ctx = the 32 KiB before the chunk (nullptr for the first chunk)
@@ -462,11 +495,13 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
       r = decodeBlocks(in, from, to, sink, &end);
       length[j] = sink.n;
     } else {
-      window[j].resize(W);
-      for (uint32_t k = 0; k < W; ++k) window[j][k] = static_cast<uint16_t>(256 + k);
-      WindowSink sink{window[j].data()};
+      std::vector<uint16_t> buf(WindowSink::CAP + 512);
+      for (uint32_t k = 0; k < W; ++k) buf[k] = static_cast<uint16_t>(256 + k);
+      WindowSink sink{buf.data()};
       r = decodeBlocks(in, from, to, sink, &end);
       length[j] = sink.n;
+      window[j].resize(W);  // the final window, oldest byte first
+      for (uint32_t k = 0; k < W; ++k) window[j][k] = sink.tail(W - k);
     }
     end_bit[j] = end;
     if (r != (j + 1 < n ? LINKED : FINAL)) ok = false;
@@ -487,9 +522,9 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
       std::memcpy(ctx[0].data() + (W - have), out->data() + (length[0] - have), static_cast<size_t>(have));
       // bytes before the start of the data do not exist; a reference to them is caught in pass 2 by position
     } else {
-      const uint16_t *ring = window[j].data();
+      const uint16_t *win = window[j].data();
       for (uint32_t k = 0; k < W; ++k) {
-        const uint16_t s = ring[(length[j] + k) & WMASK];
+        const uint16_t s = win[k];
         ctx[j][k] = s < 256 ? static_cast<uint8_t>(s) : ctx[j - 1][s - 256];
       }
     }
