@@ -345,6 +345,25 @@ int decode_impl(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr,
   add_section(&p, DecGeom::kTileUnits, KIND_SCALE, frag(SPZ_AMD_SEC_SCALES), cl->scales, count * 3u);
   add_section(&p, DecGeom::kTileUnits, KIND_COLOR, frag(SPZ_AMD_SEC_COLORS), cl->colors, count * 3u);
   add_section(&p, DecGeom::kTileUnits, KIND_ALPHA, frag(SPZ_AMD_SEC_ALPHAS), cl->alphas, count);
+#if SPZ_DEC_REVERSE && SPZ_DEC_HOT_MIB > 0
+  {  // tiles that cover the last-written SPZ_DEC_HOT_MIB of the stream, counted from the last tile
+    unsigned long long budget = (unsigned long long)SPZ_DEC_HOT_MIB << 20, plain = 0;
+    for (int k = (int)p.n_sec - 1; k >= 0 && budget > 0; --k) {
+      const SecDesc &sd_ = p.sec[k];
+      const unsigned long long tiles = (k + 1 < (int)p.n_sec ? p.sec[k + 1].tile_begin : p.total_tiles) - sd_.tile_begin;
+      const unsigned unit_bytes = sd_.kind == KIND_POS24 ? 12u : sd_.kind == KIND_POS16 ? 8u : sd_.kind == KIND_ROT_F3 ? 3u : 4u;
+      const unsigned long long bytes = sd_.n_units * unit_bytes;
+      if (bytes <= budget) {
+        plain += tiles;
+        budget -= bytes;
+      } else {
+        plain += tiles * budget / bytes;
+        budget = 0;
+      }
+    }
+    p.plain_tiles = (uint32_t)plain;
+  }
+#endif
   uint32_t grid = 1;
   rc = grid_for(device, p.total_tiles, &grid);
   if (rc != SPZ_AMD_OK) return rc;

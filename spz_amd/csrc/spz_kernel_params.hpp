@@ -63,6 +63,17 @@ namespace spz_amd_detail {
 #define SPZ_ENC_SCHED_BARRIER 1
 #endif
 // 1: XCD-contiguous tile assignment (flat grids only), see first_tile() in spz_kernels.hip.
+// Decode walks the tiles from the last to the first: the reverse of the order in which an encode launch
+// wrote the stream, so a decode that follows an encode meets the most recently written bytes first.
+#ifndef SPZ_DEC_REVERSE
+#define SPZ_DEC_REVERSE 0
+#endif
+// With SPZ_DEC_REVERSE: the part of the stream that was written last (this many MiB, counted from its end in
+// encode's writing order) is read with ordinary loads, which hit what is still in the caches; the rest
+// with the non-temporal loads of DecGeom.  0 = non-temporal everywhere.
+#ifndef SPZ_DEC_HOT_MIB
+#define SPZ_DEC_HOT_MIB 0
+#endif
 #ifndef SPZ_XCD_REMAP
 #define SPZ_XCD_REMAP 0
 #endif
@@ -85,6 +96,7 @@ struct Geom {
   }
 };
 using DecGeom = Geom<SPZ_DEC_BLOCK, SPZ_DEC_UNROLL, SPZ_DEC_WC != 0, SPZ_DEC_NTL != 0, SPZ_DEC_NTS != 0>;
+using DecGeomHot = Geom<SPZ_DEC_BLOCK, SPZ_DEC_UNROLL, SPZ_DEC_WC != 0, false, SPZ_DEC_NTS != 0>;  // ordinary loads
 using EncGeom = Geom<SPZ_ENC_BLOCK, SPZ_ENC_UNROLL, SPZ_ENC_WC != 0, SPZ_ENC_NTL != 0, SPZ_ENC_NTS != 0>;
 using FlipGeom = Geom<256, 4, false, false, false>;
 constexpr int kMaxBlocksPerCU = SPZ_BLOCKS_PER_CU;
@@ -124,6 +136,7 @@ struct KParams {
   const float *tables;            // device tables, see kTable* below
   uint8_t *header_dst;            // encode: where the 16 header bytes go (nullptr: none)
   uint32_t header_words[4];
+  uint32_t plain_tiles;           // decode: this many tiles, counted from the last one, use ordinary loads
 };
 
 constexpr int kTableAlphaDec = 0;    // 256 floats

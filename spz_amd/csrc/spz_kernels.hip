@@ -455,12 +455,12 @@ __device__ __forceinline__ void decode_tile(const SecDesc &s, uint32_t tile_loca
   }
 }
 
-template <int KIND>
+template <int KIND, class G>
 __device__ __forceinline__ void decode_tile_sh_dispatch(const SecDesc &s, uint32_t tile_local, const DecodeCtx &c,
                                                         uint32_t sh_d) {
-  if (sh_d == 45u) decode_tile<KIND, 45, DecGeom>(s, tile_local, c);
-  else if (sh_d == 24u) decode_tile<KIND, 24, DecGeom>(s, tile_local, c);
-  else decode_tile<KIND, 9, DecGeom>(s, tile_local, c);
+  if (sh_d == 45u) decode_tile<KIND, 45, G>(s, tile_local, c);
+  else if (sh_d == 24u) decode_tile<KIND, 24, G>(s, tile_local, c);
+  else decode_tile<KIND, 9, G>(s, tile_local, c);
 }
 
 // First tile of a block.  Default: block b takes tile b (the dispatcher deals consecutive blocks
@@ -495,6 +495,29 @@ __device__ __forceinline__ void stage_tables(float *lut, const float *__restrict
 
 }  // namespace
 
+template <class G>
+__device__ __forceinline__ void decode_one_tile(const KParams &p, const SecDesc &s, uint32_t tl, const DecodeCtx &c,
+                                                float *lut, bool &lut_ready) {
+  switch (s.kind) {
+    case KIND_POS24: decode_tile<KIND_POS24, 0, G>(s, tl, c); break;
+    case KIND_POS16: decode_tile<KIND_POS16, 0, G>(s, tl, c); break;
+    case KIND_ALPHA:
+    case KIND_COLOR:
+      if (!lut_ready) {
+        stage_tables<G>(lut, p.tables);
+        lut_ready = true;
+      }
+      if (s.kind == KIND_ALPHA) decode_tile<KIND_ALPHA, 0, G>(s, tl, c);
+      else decode_tile<KIND_COLOR, 0, G>(s, tl, c);
+      break;
+    case KIND_SCALE: decode_tile<KIND_SCALE, 0, G>(s, tl, c); break;
+    case KIND_ROT_S3: decode_tile<KIND_ROT_S3, 0, G>(s, tl, c); break;
+    case KIND_ROT_F3: decode_tile<KIND_ROT_F3, 0, G>(s, tl, c); break;
+    case KIND_SH: decode_tile_sh_dispatch<KIND_SH, G>(s, tl, c, p.sh_d); break;
+    default: break;
+  }
+}
+
 __global__ __launch_bounds__(DecGeom::kBlock) void spz_decode_kernel(const KParams p) {
   __shared__ float lut[kTableFloats];
   bool lut_ready = false;
@@ -504,28 +527,13 @@ __global__ __launch_bounds__(DecGeom::kBlock) void spz_decode_kernel(const KPara
   c.sh_mask_ext = p.sh_mask_ext;
   c.pos_scale = p.pos_scale;
   c.lut = lut;
-  for (uint32_t tile = first_tile(p); tile < p.total_tiles; tile = SPZ_XCD_REMAP ? 0xffffffffu : tile + gridDim.x) {
+  for (uint32_t t0 = first_tile(p); t0 < p.total_tiles; t0 = SPZ_XCD_REMAP ? 0xffffffffu : t0 + gridDim.x) {
+    const uint32_t tile = SPZ_DEC_REVERSE ? p.total_tiles - 1u - t0 : t0;
     const uint32_t si = find_section(p, tile);
     const SecDesc &s = p.sec[si];
     const uint32_t tl = tile - s.tile_begin;
-    switch (s.kind) {
-      case KIND_POS24: decode_tile<KIND_POS24, 0, DecGeom>(s, tl, c); break;
-      case KIND_POS16: decode_tile<KIND_POS16, 0, DecGeom>(s, tl, c); break;
-      case KIND_ALPHA:
-      case KIND_COLOR:
-        if (!lut_ready) {
-          stage_tables<DecGeom>(lut, p.tables);
-          lut_ready = true;
-        }
-        if (s.kind == KIND_ALPHA) decode_tile<KIND_ALPHA, 0, DecGeom>(s, tl, c);
-        else decode_tile<KIND_COLOR, 0, DecGeom>(s, tl, c);
-        break;
-      case KIND_SCALE: decode_tile<KIND_SCALE, 0, DecGeom>(s, tl, c); break;
-      case KIND_ROT_S3: decode_tile<KIND_ROT_S3, 0, DecGeom>(s, tl, c); break;
-      case KIND_ROT_F3: decode_tile<KIND_ROT_F3, 0, DecGeom>(s, tl, c); break;
-      case KIND_SH: decode_tile_sh_dispatch<KIND_SH>(s, tl, c, p.sh_d); break;
-      default: break;
-    }
+    if (SPZ_DEC_REVERSE && SPZ_DEC_NTL && t0 < p.plain_tiles) decode_one_tile<DecGeomHot>(p, s, tl, c, lut, lut_ready);
+    else decode_one_tile<DecGeom>(p, s, tl, c, lut, lut_ready);
   }
 }
 

@@ -30,10 +30,12 @@ _S = dict(E(wc=1, ntl=1), SPZ_ENC_SCHED_BARRIER=1)
 _SN = dict(E(wc=1, ntl=1, nts=1), SPZ_ENC_SCHED_BARRIER=1)
 # pairs: what one kernel leaves in the write-back caches changes the NEXT kernel's time, so an
 # (encode, decode) pair is timed in its own steady state (run() executes every pair twice, timing the second)
-ENC = {"E_ntl/D_plain": dict(_S), "E_ntl/D_nt": dict(_S), "E_nt/D_nt": dict(_SN), "E_nt/D_plain": dict(_SN),
-       "E_ntl/D_nts": dict(_S), "E_nt/D_nts": dict(_SN), "E_ntl/D_plain_b": dict(_S), "E_ntl/D_nt_b": dict(_S)}
-DEC = {"E_ntl/D_plain": D(), "E_ntl/D_nt": D(ntl=1, nts=1), "E_nt/D_nt": D(ntl=1, nts=1), "E_nt/D_plain": D(),
-       "E_ntl/D_nts": D(nts=1), "E_nt/D_nts": D(nts=1), "E_ntl/D_plain_b": D(), "E_ntl/D_nt_b": D(ntl=1, nts=1)}
+_R = dict(D(ntl=1, nts=1), SPZ_DEC_REVERSE=1)
+ENC = {"fwd_nt": dict(_S), "rev_hot128": dict(_S), "rev_hot200": dict(_S), "rev_hot256": dict(_S),
+       "rev_hot384": dict(_S), "rev_allplain": dict(_S), "fwd_nt_b": dict(_S)}
+DEC = {"fwd_nt": D(ntl=1, nts=1), "rev_hot128": dict(_R, SPZ_DEC_HOT_MIB=128), "rev_hot200": dict(_R, SPZ_DEC_HOT_MIB=200),
+       "rev_hot256": dict(_R, SPZ_DEC_HOT_MIB=256), "rev_hot384": dict(_R, SPZ_DEC_HOT_MIB=384),
+       "rev_allplain": dict(D(ntl=0, nts=1), SPZ_DEC_REVERSE=1), "fwd_nt_b": D(ntl=1, nts=1)}
 VARIANTS = {}
 for _i, (_e, _d) in enumerate(zip(ENC.items(), DEC.items())):
     VARIANTS[f"v{_i:02d}"] = {"enc": _e[0], "dec": _d[0], "defs": {**_e[1], **_d[1]}}
@@ -88,7 +90,8 @@ def run(points, rounds, names, deg=3):
         rc = L.spz_amd_decode_device(stream.data_ptr(), stream.numel(), C.byref(hdr), 6, C.byref(pout), s)
         assert rc == 0, rc
 
-    times = {n: {"enc": [], "dec": []} for n in libs}
+    times = {n: {"enc": [], "dec": [], "dec_cold": []} for n in libs}
+    scrub = torch.empty(1 << 30, dtype=torch.uint8, device=dev)   # evicts the stream from the caches
     for name, L in libs.items():   # warm-up + cross-variant parity
         enc(L); dec(L)
         torch.cuda.synchronize()
@@ -107,12 +110,17 @@ def run(points, rounds, names, deg=3):
             torch.cuda.synchronize()
             times[name]["enc"].append(e[0].elapsed_time(e[1]))
             times[name]["dec"].append(e[1].elapsed_time(e[2]))
+            scrub.fill_(1)
+            c = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+            c[0].record(); dec(L); c[1].record()
+            torch.cuda.synchronize()
+            times[name]["dec_cold"].append(c[0].elapsed_time(c[1]))
     bpp = {0: 76, 1: 121, 2: 196, 3: 301}[deg]
     gb = points * bpp / 1e9
     rows = []
     for name in libs:
         r = {"variant": name, "enc_cfg": VARIANTS[name]["enc"], "dec_cfg": VARIANTS[name]["dec"]}
-        for k in ("enc", "dec"):
+        for k in ("enc", "dec", "dec_cold"):
             med, mn = statistics.median(times[name][k]), min(times[name][k])
             r[f"{k}_ms_med"] = round(med, 4)
             r[f"{k}_ms_min"] = round(mn, 4)
