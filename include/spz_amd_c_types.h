@@ -1,7 +1,10 @@
-/* spz_amd_c_types.h — the plain-C view of a GaussianCloud used to hand clouds to C, Swift or C# hosts.
- * Same type names, field names, field order and ownership rule as the reference's bridge header
- * (/root/reference/src/cc/splat-c-types.h:11-27, filled by GaussianCloud::data(), splat-types.h:117-130):
- * every buffer is allocated with new float[] by the library and freed by the caller. */
+/* spz_amd_c_types.h — the plain-C view of a GaussianCloud, for handing clouds to C, Swift or C# hosts.
+ *
+ * Layout contract (binary-compatible with the reference's bridge types, /root/reference/src/cc/
+ * splat-c-types.h:11-27, which GaussianCloud::data() fills, splat-types.h:117-130): a float buffer is a
+ * {count, pointer} pair; a cloud is three scalars followed by six float buffers in the order positions,
+ * scales, rotations, alphas, colors, sh.  Ownership: every buffer is allocated with new float[] by the
+ * library and released by the caller with delete[]. */
 #ifndef SPZ_AMD_C_TYPES_H_
 #define SPZ_AMD_C_TYPES_H_
 
@@ -9,21 +12,23 @@
 #include <stddef.h>
 #include <stdint.h>
 
-typedef struct {
-  size_t count; /* number of floats */
-  float *data;  /* NULL when count == 0 */
-} SpzFloatBuffer;
+struct SpzFloatBuffer_ {
+  size_t count; /* number of floats behind `data` */
+  float *data;  /* NULL when count is 0 */
+};
+typedef struct SpzFloatBuffer_ SpzFloatBuffer;
 
-typedef struct {
-  int32_t numPoints;
-  int32_t shDegree;
-  bool antialiased;
-  SpzFloatBuffer positions;
-  SpzFloatBuffer scales;
-  SpzFloatBuffer rotations;
-  SpzFloatBuffer alphas;
-  SpzFloatBuffer colors;
-  SpzFloatBuffer sh;
-} GaussianCloudData;
+struct GaussianCloudData_ {
+  int32_t numPoints;        /* Gaussians in the cloud */
+  int32_t shDegree;         /* 0..3 */
+  bool antialiased;         /* mip-splatting flag */
+  SpzFloatBuffer positions; /* 3 per point: x y z */
+  SpzFloatBuffer scales;    /* 3 per point: log scale per axis */
+  SpzFloatBuffer rotations; /* 4 per point: x y z w */
+  SpzFloatBuffer alphas;    /* 1 per point: pre-sigmoid opacity */
+  SpzFloatBuffer colors;    /* 3 per point: SH DC term, rgb */
+  SpzFloatBuffer sh;        /* 3 * shDim per point: [coefficient][rgb] */
+};
+typedef struct GaussianCloudData_ GaussianCloudData;
 
 #endif /* SPZ_AMD_C_TYPES_H_ */
