@@ -6,6 +6,8 @@ Layout:
   csrc/spz_median.hip   radix selection of the median scale sum (medianVolume)
   csrc/spz_abi.hip      the C ABI (include/spz_amd.h) over them
   csrc/spz_host.cpp     C++ drop-in layer: namespace spz saveSpz/loadSpz/... + host gzip
+  csrc/spz_deflate.cpp  multi-threaded gzip writer with zlib's exact bytes (the default container stage)
+  csrc/spz_inflate.cpp  multi-threaded, CRC-verified inflate of ordinary single-stream members
   csrc/spz_py.cpp       Python module `spz_amd.spz` with the reference nanobind shim's surface
   abi.py                ctypes binding of the C ABI
   device.py             device-resident encode/decode on torch-owned HBM
