@@ -155,6 +155,7 @@ struct GatherParams {
   uint32_t version;               // 1, 2, 3
   uint32_t sh_dim;                // 0, 3, 8, 15
   uint32_t flip_p, flip_q, flip_sh15;
+  unsigned long long sh_elem_mask;  // bit j: element j of a point's D sh floats is negated
   float pos_scale;
   const float *tables;
 };

@@ -775,14 +775,10 @@ __global__ __launch_bounds__(FlipGeom::kBlock) void spz_flip_kernel(const KParam
 
 namespace {
 
-// One gathered value of an element-wise section: element e of the output is float (e % FPP) of the
-// point indices[e / FPP].  Same arithmetic as the bulk decode (decode_unit), one element at a time.
-template <int KIND, int FPP>
-__device__ __forceinline__ float gather_element(const GatherParams &p, unsigned long long e) {
-  const unsigned long long g = e / (unsigned)FPP;
-  const uint32_t o = (uint32_t)(e - g * (unsigned)FPP);
-  uint32_t i = p.indices[g];
-  i = i < p.num_points ? i : p.num_points - 1u;
+// Random access (spz_amd_decode_gather_device): component `o` of point `i` of one section, with the
+// arithmetic of the bulk decode (decode_unit), one element at a time.
+template <int KIND>
+__device__ __forceinline__ float gather_element(const GatherParams &p, uint32_t i, uint32_t o) {
   if constexpr (KIND == KIND_POS24) {
     const uint8_t *b = p.positions + ((unsigned long long)i * 3u + o) * 3u;
     const uint32_t v = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
@@ -799,36 +795,77 @@ __device__ __forceinline__ float gather_element(const GatherParams &p, unsigned 
   }
 }
 
+__device__ __forceinline__ uint32_t gather_index(const GatherParams &p, unsigned long long g) {
+  const uint32_t i = p.indices[g];
+  return i < p.num_points ? i : p.num_points - 1u;
+}
+
+__device__ __forceinline__ float sh_value(uint32_t byte, unsigned long long mask, uint32_t o) {
+  return xor_sign(((float)byte - 128.0f) / 128.0f, (uint32_t)(mask >> o) & 1u);  // load-spz.cc:83, then flipSh
+}
+
+// sh of the gathered points: the output is one flat float array, cut into units of 4 floats like the bulk
+// decode, so every thread does one 16-byte store; its 4 source bytes are consecutive in one point's sh
+// record (one unaligned dword load) unless the unit straddles two points.  IDX: uint32_t while the float
+// count fits 32 bits (division by the constant D is then a multiply-high).
+template <uint32_t D, class IDX>
+__device__ __forceinline__ void gather_sh(const GatherParams &p) {
+  const unsigned long long total = p.count * D;
+  const unsigned long long units = (total + 3ull) / 4ull;
+  const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
+  const unsigned long long mask = p.sh_elem_mask;
+  for (unsigned long long u = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; u < units; u += stride) {
+    const IDX f = (IDX)(u * 4ull);
+    const IDX g = f / (IDX)D;
+    const uint32_t o = (uint32_t)(f - g * (IDX)D);
+    const uint32_t i = gather_index(p, g);
+    const uint8_t *src = p.sh + (unsigned long long)i * D + o;
+    if (o + 4u <= D && (unsigned long long)f + 4ull <= total) {
+      const uint32_t w = reinterpret_cast<const U32x1 *>(src)->a;
+      F32x4 v = {sh_value(w & 0xffu, mask, o), sh_value((w >> 8) & 0xffu, mask, o + 1u),
+                 sh_value((w >> 16) & 0xffu, mask, o + 2u), sh_value(w >> 24, mask, o + 3u)};
+      store_f4<false>(p.out_sh, u, v);
+    } else {
+      const uint8_t *next = nullptr;  // the unit runs into the next point (or off the end)
+      for (uint32_t k = 0; k < 4u && (unsigned long long)f + k < total; ++k) {
+        float v;
+        if (o + k < D) {
+          v = sh_value(src[k], mask, o + k);
+        } else {
+          if (next == nullptr) next = p.sh + (unsigned long long)gather_index(p, (unsigned long long)g + 1ull) * D;
+          v = sh_value(next[o + k - D], mask, o + k - D);
+        }
+        p.out_sh[(unsigned long long)f + k] = v;
+      }
+    }
+  }
+}
+
 }  // namespace
 
 __global__ __launch_bounds__(256) void spz_decode_gather_kernel(const GatherParams p) {
-  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
-  const unsigned long long t0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
-  const unsigned long long c = p.count;
+  const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
+  const unsigned long long t0 = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
   const uint32_t d = p.sh_dim * 3u;
-  // sh: element e -> point e / d, coefficient (e % d) / 3
-  for (unsigned long long e = t0; e < c * d; e += stride) {
-    const unsigned long long g = e / d;
-    const uint32_t o = (uint32_t)(e - g * d);
-    uint32_t i = p.indices[g];
-    i = i < p.num_points ? i : p.num_points - 1u;
-    const float v = ((float)p.sh[(unsigned long long)i * d + o] - 128.0f) / 128.0f;
-    p.out_sh[e] = xor_sign(v, (p.flip_sh15 >> (o / 3u)) & 1u);
-  }
-  for (unsigned long long e = t0; e < c * 3u; e += stride) {
-    p.out_positions[e] = (p.version == 1u) ? gather_element<KIND_POS16, 3>(p, e) : gather_element<KIND_POS24, 3>(p, e);
-    p.out_scales[e] = gather_element<KIND_SCALE, 3>(p, e);
-    p.out_colors[e] = gather_element<KIND_COLOR, 3>(p, e);
-  }
-  for (unsigned long long g = t0; g < c; g += stride) {
-    p.out_alphas[g] = gather_element<KIND_ALPHA, 1>(p, g);
-    uint32_t i = p.indices[g];
-    i = i < p.num_points ? i : p.num_points - 1u;
+  const bool small = p.count * 45ull <= 0xffffffffull;
+  if (d == 45u) small ? gather_sh<45u, uint32_t>(p) : gather_sh<45u, unsigned long long>(p);
+  else if (d == 24u) small ? gather_sh<24u, uint32_t>(p) : gather_sh<24u, unsigned long long>(p);
+  else if (d == 9u) small ? gather_sh<9u, uint32_t>(p) : gather_sh<9u, unsigned long long>(p);
+  // the other five sections: one thread per point
+  for (unsigned long long g = t0; g < p.count; g += stride) {
+    const uint32_t i = gather_index(p, g);
+    float *pos = p.out_positions + g * 3ull, *sc = p.out_scales + g * 3ull, *col = p.out_colors + g * 3ull;
+#pragma unroll
+    for (uint32_t o = 0; o < 3u; ++o) {
+      pos[o] = (p.version == 1u) ? gather_element<KIND_POS16>(p, i, o) : gather_element<KIND_POS24>(p, i, o);
+      sc[o] = gather_element<KIND_SCALE>(p, i, o);
+      col[o] = gather_element<KIND_COLOR>(p, i, o);
+    }
+    p.out_alphas[g] = gather_element<KIND_ALPHA>(p, i, 0u);
     F32x4 q;
     if (p.version >= 3u) {
-      const uint8_t *b = p.rotations + (unsigned long long)i * 4u;
-      q = unpack_quat_smallest_three((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24),
-                                     p.flip_q);
+      const uint32_t w = reinterpret_cast<const U32x1 *>(p.rotations + (unsigned long long)i * 4u)->a;
+      q = unpack_quat_smallest_three(w, p.flip_q);
     } else {
       const uint8_t *b = p.rotations + (unsigned long long)i * 3u;
       q = unpack_quat_first_three((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16), p.flip_q);
