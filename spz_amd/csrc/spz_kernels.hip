@@ -804,39 +804,57 @@ __device__ __forceinline__ float sh_value(uint32_t byte, unsigned long long mask
   return xor_sign(((float)byte - 128.0f) / 128.0f, (uint32_t)(mask >> o) & 1u);  // load-spz.cc:83, then flipSh
 }
 
-// sh of the gathered points: the output is one flat float array, cut into units of 4 floats like the bulk
-// decode, so every thread does one 16-byte store; its 4 source bytes are consecutive in one point's sh
-// record (one unaligned dword load) unless the unit straddles two points.  IDX: uint32_t while the float
-// count fits 32 bits (division by the constant D is then a multiply-high).
-template <uint32_t D, class IDX>
-__device__ __forceinline__ void gather_sh(const GatherParams &p) {
-  const unsigned long long total = p.count * D;
-  const unsigned long long units = (total + 3ull) / 4ull;
+// A group of LPP lanes serves one gathered point, so that all of a point's scattered reads are in flight at
+// once and each is a single load: lanes 0 .. ceil(D/4)-1 take one dword of the point's sh record each
+// (consecutive lanes read consecutive bytes: one or two sectors per point) and store 4 floats; the next
+// lane takes positions and alpha, the one after it scales, colours and the rotation.
+template <uint32_t D, uint32_t LPP>
+__device__ __forceinline__ void gather_points(const GatherParams &p) {
+  constexpr uint32_t SHL = (D + 3u) / 4u;
+  static_assert(SHL + 2u <= LPP, "not enough lanes per point");
+  const unsigned long long lanes = p.count * LPP;
   const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
   const unsigned long long mask = p.sh_elem_mask;
-  for (unsigned long long u = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; u < units; u += stride) {
-    const IDX f = (IDX)(u * 4ull);
-    const IDX g = f / (IDX)D;
-    const uint32_t o = (uint32_t)(f - g * (IDX)D);
+  for (unsigned long long t = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; t < lanes; t += stride) {
+    const unsigned long long g = t / LPP;
+    const uint32_t role = (uint32_t)(t % LPP);
     const uint32_t i = gather_index(p, g);
-    const uint8_t *src = p.sh + (unsigned long long)i * D + o;
-    if (o + 4u <= D && (unsigned long long)f + 4ull <= total) {
-      const uint32_t w = reinterpret_cast<const U32x1 *>(src)->a;
-      F32x4 v = {sh_value(w & 0xffu, mask, o), sh_value((w >> 8) & 0xffu, mask, o + 1u),
-                 sh_value((w >> 16) & 0xffu, mask, o + 2u), sh_value(w >> 24, mask, o + 3u)};
-      store_f4<false>(p.out_sh, u, v);
-    } else {
-      const uint8_t *next = nullptr;  // the unit runs into the next point (or off the end)
-      for (uint32_t k = 0; k < 4u && (unsigned long long)f + k < total; ++k) {
-        float v;
-        if (o + k < D) {
-          v = sh_value(src[k], mask, o + k);
-        } else {
-          if (next == nullptr) next = p.sh + (unsigned long long)gather_index(p, (unsigned long long)g + 1ull) * D;
-          v = sh_value(next[o + k - D], mask, o + k - D);
-        }
-        p.out_sh[(unsigned long long)f + k] = v;
+    if (role < SHL) {
+      const uint32_t o = role * 4u;
+      const uint8_t *src = p.sh + (unsigned long long)i * D + o;
+      float *dst = p.out_sh + g * D + o;
+      if (o + 4u <= D) {
+        const uint32_t w = reinterpret_cast<const U32x1 *>(src)->a;
+        const F32x4 v = {sh_value(w & 0xffu, mask, o), sh_value((w >> 8) & 0xffu, mask, o + 1u),
+                         sh_value((w >> 16) & 0xffu, mask, o + 2u), sh_value(w >> 24, mask, o + 3u)};
+        *reinterpret_cast<F32x4 *>(dst) = v;
+      } else {
+#pragma unroll
+        for (uint32_t k = 0; k < D % 4u; ++k) dst[k] = sh_value(src[k], mask, o + k);
       }
+    } else if (role == SHL) {
+      float *pos = p.out_positions + g * 3ull;
+#pragma unroll
+      for (uint32_t o = 0; o < 3u; ++o) {
+        pos[o] = (p.version == 1u) ? gather_element<KIND_POS16>(p, i, o) : gather_element<KIND_POS24>(p, i, o);
+      }
+      p.out_alphas[g] = gather_element<KIND_ALPHA>(p, i, 0u);
+    } else if (role == SHL + 1u) {
+      float *sc = p.out_scales + g * 3ull, *col = p.out_colors + g * 3ull;
+#pragma unroll
+      for (uint32_t o = 0; o < 3u; ++o) {
+        sc[o] = gather_element<KIND_SCALE>(p, i, o);
+        col[o] = gather_element<KIND_COLOR>(p, i, o);
+      }
+      F32x4 q;
+      if (p.version >= 3u) {
+        const uint32_t w = reinterpret_cast<const U32x1 *>(p.rotations + (unsigned long long)i * 4u)->a;
+        q = unpack_quat_smallest_three(w, p.flip_q);
+      } else {
+        const uint8_t *b = p.rotations + (unsigned long long)i * 3u;
+        q = unpack_quat_first_three((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16), p.flip_q);
+      }
+      store_f4<false>(p.out_rotations, g, q);
     }
   }
 }
@@ -844,34 +862,11 @@ __device__ __forceinline__ void gather_sh(const GatherParams &p) {
 }  // namespace
 
 __global__ __launch_bounds__(256) void spz_decode_gather_kernel(const GatherParams p) {
-  const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
-  const unsigned long long t0 = (unsigned long long)blockIdx.x * 256ull + threadIdx.x;
   const uint32_t d = p.sh_dim * 3u;
-  const bool small = p.count * 45ull <= 0xffffffffull;
-  if (d == 45u) small ? gather_sh<45u, uint32_t>(p) : gather_sh<45u, unsigned long long>(p);
-  else if (d == 24u) small ? gather_sh<24u, uint32_t>(p) : gather_sh<24u, unsigned long long>(p);
-  else if (d == 9u) small ? gather_sh<9u, uint32_t>(p) : gather_sh<9u, unsigned long long>(p);
-  // the other five sections: one thread per point
-  for (unsigned long long g = t0; g < p.count; g += stride) {
-    const uint32_t i = gather_index(p, g);
-    float *pos = p.out_positions + g * 3ull, *sc = p.out_scales + g * 3ull, *col = p.out_colors + g * 3ull;
-#pragma unroll
-    for (uint32_t o = 0; o < 3u; ++o) {
-      pos[o] = (p.version == 1u) ? gather_element<KIND_POS16>(p, i, o) : gather_element<KIND_POS24>(p, i, o);
-      sc[o] = gather_element<KIND_SCALE>(p, i, o);
-      col[o] = gather_element<KIND_COLOR>(p, i, o);
-    }
-    p.out_alphas[g] = gather_element<KIND_ALPHA>(p, i, 0u);
-    F32x4 q;
-    if (p.version >= 3u) {
-      const uint32_t w = reinterpret_cast<const U32x1 *>(p.rotations + (unsigned long long)i * 4u)->a;
-      q = unpack_quat_smallest_three(w, p.flip_q);
-    } else {
-      const uint8_t *b = p.rotations + (unsigned long long)i * 3u;
-      q = unpack_quat_first_three((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16), p.flip_q);
-    }
-    store_f4<false>(p.out_rotations, g, q);
-  }
+  if (d == 45u) gather_points<45u, 16u>(p);
+  else if (d == 24u) gather_points<24u, 8u>(p);
+  else if (d == 9u) gather_points<9u, 8u>(p);
+  else gather_points<0u, 2u>(p);
 }
 
 namespace {
