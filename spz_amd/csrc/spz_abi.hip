@@ -580,8 +580,7 @@ int spz_amd_decode_gather_device(const uint8_t *d_stream, size_t size, const spz
   p.flip_sh15 = fm.sh15;
   p.sh_elem_mask = sh_elem_mask_ext(fm.sh15, sd);
   p.pos_scale = (float)(1.0 / (double)(int32_t)(1u << (hdr->fractional_bits & 31)));
-  // 16 / 8 / 8 / 2 lanes per point for sh degree 3 / 2 / 1 / 0 (see gather_points); the kernel grid-strides past the cap
-  const unsigned long long items = count * (unsigned long long)(sd == 15 ? 16 : sd > 0 ? 8 : 2);
+  const unsigned long long items = count * (unsigned long long)(sd > 0 ? sd * 3 : 3);
   unsigned long long blocks = (items + 255) / 256;
   if (blocks > 65536ull * 16) blocks = 65536ull * 16;  // grid-stride beyond that
   hipLaunchKernelGGL(spz_decode_gather_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(hip_stream), p);

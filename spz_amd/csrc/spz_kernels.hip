@@ -775,10 +775,14 @@ __global__ __launch_bounds__(FlipGeom::kBlock) void spz_flip_kernel(const KParam
 
 namespace {
 
-// Random access (spz_amd_decode_gather_device): component `o` of point `i` of one section, with the
-// arithmetic of the bulk decode (decode_unit), one element at a time.
-template <int KIND>
-__device__ __forceinline__ float gather_element(const GatherParams &p, uint32_t i, uint32_t o) {
+// One gathered value of an element-wise section: element e of the output is float (e % FPP) of the
+// point indices[e / FPP].  Same arithmetic as the bulk decode (decode_unit), one element at a time.
+template <int KIND, int FPP>
+__device__ __forceinline__ float gather_element(const GatherParams &p, unsigned long long e) {
+  const unsigned long long g = e / (unsigned)FPP;
+  const uint32_t o = (uint32_t)(e - g * (unsigned)FPP);
+  uint32_t i = p.indices[g];
+  i = i < p.num_points ? i : p.num_points - 1u;
   if constexpr (KIND == KIND_POS24) {
     const uint8_t *b = p.positions + ((unsigned long long)i * 3u + o) * 3u;
     const uint32_t v = (uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16);
@@ -795,78 +799,60 @@ __device__ __forceinline__ float gather_element(const GatherParams &p, uint32_t 
   }
 }
 
-__device__ __forceinline__ uint32_t gather_index(const GatherParams &p, unsigned long long g) {
-  const uint32_t i = p.indices[g];
-  return i < p.num_points ? i : p.num_points - 1u;
-}
+}  // namespace
 
-__device__ __forceinline__ float sh_value(uint32_t byte, unsigned long long mask, uint32_t o) {
-  return xor_sign(((float)byte - 128.0f) / 128.0f, (uint32_t)(mask >> o) & 1u);  // load-spz.cc:83, then flipSh
-}
-
-// A group of LPP lanes serves one gathered point, so that all of a point's scattered reads are in flight at
-// once and each is a single load: lanes 0 .. ceil(D/4)-1 take one dword of the point's sh record each
-// (consecutive lanes read consecutive bytes: one or two sectors per point) and store 4 floats; the next
-// lane takes positions and alpha, the one after it scales, colours and the rotation.
-template <uint32_t D, uint32_t LPP>
-__device__ __forceinline__ void gather_points(const GatherParams &p) {
-  constexpr uint32_t SHL = (D + 3u) / 4u;
-  static_assert(SHL + 2u <= LPP, "not enough lanes per point");
-  const unsigned long long lanes = p.count * LPP;
-  const unsigned long long stride = (unsigned long long)gridDim.x * 256ull;
+// IDX: 32-bit while the element count fits, so that the division by the constant D is one multiply-high.
+template <uint32_t D, class IDX>
+__device__ __forceinline__ void gather_sh(const GatherParams &p, unsigned long long t0, unsigned long long stride) {
+  const unsigned long long total = p.count * D;
   const unsigned long long mask = p.sh_elem_mask;
-  for (unsigned long long t = (unsigned long long)blockIdx.x * 256ull + threadIdx.x; t < lanes; t += stride) {
-    const unsigned long long g = t / LPP;
-    const uint32_t role = (uint32_t)(t % LPP);
-    const uint32_t i = gather_index(p, g);
-    if (role < SHL) {
-      const uint32_t o = role * 4u;
-      const uint8_t *src = p.sh + (unsigned long long)i * D + o;
-      float *dst = p.out_sh + g * D + o;
-      if (o + 4u <= D) {
-        const uint32_t w = reinterpret_cast<const U32x1 *>(src)->a;
-        const F32x4 v = {sh_value(w & 0xffu, mask, o), sh_value((w >> 8) & 0xffu, mask, o + 1u),
-                         sh_value((w >> 16) & 0xffu, mask, o + 2u), sh_value(w >> 24, mask, o + 3u)};
-        *reinterpret_cast<F32x4 *>(dst) = v;
-      } else {
-#pragma unroll
-        for (uint32_t k = 0; k < D % 4u; ++k) dst[k] = sh_value(src[k], mask, o + k);
-      }
-    } else if (role == SHL) {
-      float *pos = p.out_positions + g * 3ull;
-#pragma unroll
-      for (uint32_t o = 0; o < 3u; ++o) {
-        pos[o] = (p.version == 1u) ? gather_element<KIND_POS16>(p, i, o) : gather_element<KIND_POS24>(p, i, o);
-      }
-      p.out_alphas[g] = gather_element<KIND_ALPHA>(p, i, 0u);
-    } else if (role == SHL + 1u) {
-      float *sc = p.out_scales + g * 3ull, *col = p.out_colors + g * 3ull;
-#pragma unroll
-      for (uint32_t o = 0; o < 3u; ++o) {
-        sc[o] = gather_element<KIND_SCALE>(p, i, o);
-        col[o] = gather_element<KIND_COLOR>(p, i, o);
-      }
-      F32x4 q;
-      if (p.version >= 3u) {
-        const uint32_t w = reinterpret_cast<const U32x1 *>(p.rotations + (unsigned long long)i * 4u)->a;
-        q = unpack_quat_smallest_three(w, p.flip_q);
-      } else {
-        const uint8_t *b = p.rotations + (unsigned long long)i * 3u;
-        q = unpack_quat_first_three((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16), p.flip_q);
-      }
-      store_f4<false>(p.out_rotations, g, q);
-    }
+  for (unsigned long long e = t0; e < total; e += stride) {
+    const IDX g = (IDX)e / (IDX)D;
+    const uint32_t o = (uint32_t)((IDX)e - g * (IDX)D);
+    uint32_t i = p.indices[g];
+    i = i < p.num_points ? i : p.num_points - 1u;
+    const float v = ((float)p.sh[(unsigned long long)i * D + o] - 128.0f) / 128.0f;
+    p.out_sh[e] = xor_sign(v, (uint32_t)(mask >> o) & 1u);
   }
 }
 
-}  // namespace
-
 __global__ __launch_bounds__(256) void spz_decode_gather_kernel(const GatherParams p) {
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  const unsigned long long t0 = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const unsigned long long c = p.count;
   const uint32_t d = p.sh_dim * 3u;
-  if (d == 45u) gather_points<45u, 16u>(p);
-  else if (d == 24u) gather_points<24u, 8u>(p);
-  else if (d == 9u) gather_points<9u, 8u>(p);
-  else gather_points<0u, 2u>(p);
+  // sh: element e -> point e / d, element e % d of its record.  One byte and one float per thread keeps every
+  // lane busy and a point's 45 reads in one or two sectors (measured against 4-float units per thread and
+  // against a lane group per point: both lose on random indices, profiles/r01_gather_bench.jsonl).
+  if (c * 45ull <= 0xffffffffull) {
+    if (d == 45u) gather_sh<45u, uint32_t>(p, t0, stride);
+    else if (d == 24u) gather_sh<24u, uint32_t>(p, t0, stride);
+    else if (d == 9u) gather_sh<9u, uint32_t>(p, t0, stride);
+  } else {
+    if (d == 45u) gather_sh<45u, unsigned long long>(p, t0, stride);
+    else if (d == 24u) gather_sh<24u, unsigned long long>(p, t0, stride);
+    else if (d == 9u) gather_sh<9u, unsigned long long>(p, t0, stride);
+  }
+  for (unsigned long long e = t0; e < c * 3u; e += stride) {
+    p.out_positions[e] = (p.version == 1u) ? gather_element<KIND_POS16, 3>(p, e) : gather_element<KIND_POS24, 3>(p, e);
+    p.out_scales[e] = gather_element<KIND_SCALE, 3>(p, e);
+    p.out_colors[e] = gather_element<KIND_COLOR, 3>(p, e);
+  }
+  for (unsigned long long g = t0; g < c; g += stride) {
+    p.out_alphas[g] = gather_element<KIND_ALPHA, 1>(p, g);
+    uint32_t i = p.indices[g];
+    i = i < p.num_points ? i : p.num_points - 1u;
+    F32x4 q;
+    if (p.version >= 3u) {
+      const uint8_t *b = p.rotations + (unsigned long long)i * 4u;
+      q = unpack_quat_smallest_three((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16) | ((uint32_t)b[3] << 24),
+                                     p.flip_q);
+    } else {
+      const uint8_t *b = p.rotations + (unsigned long long)i * 3u;
+      q = unpack_quat_first_three((uint32_t)b[0] | ((uint32_t)b[1] << 8) | ((uint32_t)b[2] << 16), p.flip_q);
+    }
+    store_f4<false>(p.out_rotations, g, q);
+  }
 }
 
 namespace {
