@@ -442,7 +442,7 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
   };
   const uint32_t want_crc = le32(gz + size - 8);
   const uint64_t isize = le32(gz + size - 4);
-  if (isize == 0 || isize > static_cast<uint64_t>(dbytes) * 1032 + 1024) return false;  // ISIZE is mod 2^32: larger members go serial
+  // ISIZE is the length modulo 2^32; it is compared with what the decode produced, never used to allocate
 
   static const bool timing = std::getenv("SPZ_AMD_PINFLATE_TIMING") != nullptr;
   auto t_prev = std::chrono::steady_clock::now();
@@ -480,8 +480,8 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
                  100.0 * static_cast<double>(span) / static_cast<double>(in.nbits));
   }
 
-  // ---- 2. pass 1: the first chunk decodes straight into place, the others keep only their window
-  out->resize(isize);
+  // ---- 2. pass 1: every chunk, window only.  Nothing is allocated from the trailer's ISIZE: the output size is
+  // what the decode itself produces.
   std::vector<uint64_t> length(n, 0);
   std::vector<std::vector<uint16_t>> window(n);
   std::vector<uint64_t> end_bit(n, 0);
@@ -489,20 +489,13 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
   parallel_for(n, threads, [&](size_t j) {
     const uint64_t from = start[live[j]], to = (j + 1 < n) ? start[live[j + 1]] : NONE;
     uint64_t end = 0;
-    Outcome r;
-    if (j == 0) {
-      ByteSink sink{out->data(), isize, nullptr};
-      r = decodeBlocks(in, from, to, sink, &end);
-      length[j] = sink.n;
-    } else {
-      std::vector<uint16_t> buf(WindowSink::CAP + 512);
-      for (uint32_t k = 0; k < W; ++k) buf[k] = static_cast<uint16_t>(256 + k);
-      WindowSink sink{buf.data()};
-      r = decodeBlocks(in, from, to, sink, &end);
-      length[j] = sink.n;
-      window[j].resize(W);  // the final window, oldest byte first
-      for (uint32_t k = 0; k < W; ++k) window[j][k] = sink.tail(W - k);
-    }
+    std::vector<uint16_t> buf(WindowSink::CAP + 512);
+    for (uint32_t k = 0; k < W; ++k) buf[k] = static_cast<uint16_t>(256 + k);
+    WindowSink sink{buf.data()};
+    const Outcome r = decodeBlocks(in, from, to, sink, &end);
+    length[j] = sink.n;
+    window[j].resize(W);  // the final window, oldest byte first
+    for (uint32_t k = 0; k < W; ++k) window[j][k] = sink.tail(W - k);
     end_bit[j] = end;
     if (r != (j + 1 < n ? LINKED : FINAL)) ok = false;
   });
@@ -513,46 +506,38 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
   // ---- 3. offsets and contexts
   std::vector<uint64_t> offset(n + 1, 0);
   for (size_t j = 0; j < n; ++j) offset[j + 1] = offset[j] + length[j];
-  if (offset[n] != isize) return false;
+  if ((offset[n] & 0xffffffffull) != isize) return false;  // ISIZE is the length modulo 2^32
+  out->resize(static_cast<size_t>(offset[n]));
   std::vector<std::vector<uint8_t>> ctx(n);  // ctx[j] = the W bytes before chunk j + 1's first byte
   for (size_t j = 0; j + 1 < n; ++j) {
     ctx[j].assign(W, 0);
-    if (j == 0) {
-      const uint64_t have = std::min<uint64_t>(W, length[0]);
-      std::memcpy(ctx[0].data() + (W - have), out->data() + (length[0] - have), static_cast<size_t>(have));
-      // bytes before the start of the data do not exist; a reference to them is caught in pass 2 by position
-    } else {
-      const uint16_t *win = window[j].data();
-      for (uint32_t k = 0; k < W; ++k) {
-        const uint16_t s = win[k];
-        ctx[j][k] = s < 256 ? static_cast<uint8_t>(s) : ctx[j - 1][s - 256];
-      }
+    const uint16_t *win = window[j].data();
+    for (uint32_t k = 0; k < W; ++k) {
+      const uint16_t s = win[k];
+      // the first chunk has no predecessor: what it leaves unresolved lies before the start of the data; a
+      // reference to it is invalid, and the CRC-32 is what notices (pass 2 catches it by position where it can)
+      ctx[j][k] = s < 256 ? static_cast<uint8_t>(s) : (j == 0 ? uint8_t(0) : ctx[j - 1][s - 256]);
     }
   }
-  // a chunk other than the first may only reach back as far as data exists
-  // (offset[j] >= W for all j >= 1 unless the first chunk is tiny; ByteSink checks distances against ctx)
 
-  // ---- 4. pass 2
-  parallel_for(n - 1, threads, [&](size_t k) {
-    const size_t j = k + 1;
+  // ---- 4. pass 2: every chunk again, with its context, straight into place
+  parallel_for(n, threads, [&](size_t j) {
     const uint64_t from = start[live[j]], to = (j + 1 < n) ? start[live[j + 1]] : NONE;
-    ByteSink sink{out->data() + offset[j], length[j], ctx[j - 1].data()};
+    ByteSink sink{out->data() + offset[j], length[j], j == 0 ? nullptr : ctx[j - 1].data()};
     uint64_t end = 0;
     const Outcome r = decodeBlocks(in, from, to, sink, &end);
     if (r != (j + 1 < n ? LINKED : FINAL) || sink.n != length[j]) ok = false;
   });
   lap("pass2");
   if (!ok) return false;
-  if (offset[1] < W) {
-    // references from later chunks into bytes before the start of the data would have read zeros from ctx:
-    // only the CRC can tell; it is checked next either way
-  }
 
   // ---- 5. CRC-32 and ISIZE
-  const size_t pieces = std::min<size_t>(static_cast<size_t>(threads), static_cast<size_t>(isize / (size_t(1) << 20)) + 1);
+  const uint64_t total = offset[n];
+  const size_t pieces = std::min<size_t>(static_cast<size_t>(threads), static_cast<size_t>(total / (size_t(1) << 20)) + 1);
   std::vector<uLong> crcs(pieces);
   std::vector<uint64_t> cut(pieces + 1);
-  for (size_t i = 0; i <= pieces; ++i) cut[i] = isize * i / pieces;
+  for (size_t i = 0; i <= pieces; ++i) cut[i] = total / pieces * i;
+  cut[pieces] = total;
   parallel_for(pieces, threads, [&](size_t i) {
     uLong c = crc32(0L, Z_NULL, 0);
     for (uint64_t p = cut[i]; p < cut[i + 1];) {
