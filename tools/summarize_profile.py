@@ -72,20 +72,25 @@ def main():
         for s, vals in per.items():
             traffic.setdefault(s, {})[counter + "_KB_median"] = statistics.median(vals)
             traffic[s][counter + "_launches"] = len(vals)
-    # corrections (MI355X_MICROARCH.md §HBM): counters are in KiB; FETCH_SIZE reads exactly half the
-    # bytes of a 16-B-per-lane streaming read -> doubled where the kernel reads 16 B per lane (encode's
-    # float reads); WRITE_SIZE is exact for 16-B-per-lane stores (decode's float writes).  The
-    # 4-B-per-lane side of each kernel is an uncalibrated width: reported as counted.
+    # corrections (MI355X_MICROARCH.md §HBM): counters are in KiB; FETCH_SIZE reads exactly half the bytes of
+    # a streaming read -> doubled.  The guide states that for 16-B-per-lane reads; for this chip it was
+    # calibrated for 4-B-per-lane reads too (profiles/r01_pmc_calibration.jsonl: tools/membench.hip's shapes
+    # with known byte counts give FETCH_SIZE = 0.500 x bytes for both widths, WRITE_SIZE = 1.000 x bytes for
+    # 16-B and 4-B stores), so the same factor applies to the decode kernel's packed-byte reads.
     for s, t in traffic.items():
         f = t.get("FETCH_SIZE_KB_median")
         w = t.get("WRITE_SIZE_KB_median")
         if f is None or w is None:
             continue
+        fetch_b = f * 1024 * 2
         if s == "spz_encode_kernel":
-            fetch_b, note = f * 1024 * 2, "FETCH_SIZE x2 (16 B/lane streaming reads); WRITE_SIZE as counted (4 B/lane stores, uncalibrated width)"
+            note = "FETCH_SIZE x2 (16 B/lane streaming reads); WRITE_SIZE exact (4 B/lane stores, calibrated)"
             alg_r, alg_w = float_bytes, packed_bytes
+        elif s == "spz_flip_kernel":   # in-place pass over positions, rotations and sh
+            note = "FETCH_SIZE x2; WRITE_SIZE exact (16 B/lane both ways)"
+            alg_r = alg_w = a.points * (3 + 4 + d) * 4
         else:
-            fetch_b, note = f * 1024, "FETCH_SIZE as counted (4 B/lane reads, uncalibrated width; x2 would be the 16-B rule); WRITE_SIZE exact (16 B/lane stores)"
+            note = "FETCH_SIZE x2 (4 B/lane streaming reads, calibrated: r01_pmc_calibration.jsonl); WRITE_SIZE exact (16 B/lane stores)"
             alg_r, alg_w = packed_bytes, float_bytes
         t.update({"hbm_read_bytes": fetch_b, "hbm_write_bytes": w * 1024, "hbm_bytes_per_launch": fetch_b + w * 1024,
                   "algorithmic_read_bytes": alg_r, "algorithmic_write_bytes": alg_w,
