@@ -187,8 +187,6 @@ def main():
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world == 1:
-        abi.wait_for_device()   # fresh box: let a child process see the device before this one touches HIP
     assert torch.cuda.is_available(), "bench.py needs a GPU (there is no CPU fallback)"
     if args.backend == "gloo":
         local_rank %= torch.cuda.device_count()   # rehearsal: ranks may share a card

@@ -229,6 +229,20 @@ int spz_amd_cloud_to_ply_rows_host(const spz_amd_cloud_in *h_cloud, uint64_t num
  *      returns the host copies (for tests); any pointer may be NULL. ------------------------ */
 int spz_amd_get_tables(float alpha_decode[256], float color_decode[256], float alpha_thresholds[255]);
 
+/* ---- self test of the kernels' arithmetic.  Inside an exponent window the quaternion kernels divide
+ *      without the IEEE expansion's operand scaling (reciprocal multiply + fma residual corrections,
+ *      spz_kernels.hip); this runs, on the device, the comparison of each such form with the plain IEEE
+ *      operation it replaces over inputs begin .. begin+count of `mode`:
+ *        0  x / 0.70710677f (load-spz.cc:46,244)   x = the float with bit pattern i, window [2^-100, 2^126] and 0
+ *        1  x / 511.0f      (load-spz.cc:366)      likewise
+ *        2  sqrt            (splat-types.cc:72)    x = bit pattern i, window [2^-80, 2^82]
+ *        3  x_i / norm      (splat-types.cc:73)    operand pair hashed from i
+ *        4  packQuaternionSmallestThree, 5 the v2 first-three encoder: quaternion hashed from i
+ *        6  unpackQuaternionSmallestThree: comp = low 32 bits of i, flips = bits 32..34
+ *      result[0] = inputs whose bits differ (must be 0), result[1] = the smallest such i (~0 if none),
+ *      result[2] = inputs actually compared (those inside the mode's window).  Blocking. -------------- */
+int spz_amd_selftest_device(int mode, uint64_t begin, uint64_t count, uint64_t result[3], void *hip_stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -42,6 +42,7 @@ EXPORTS = (
     "spz_amd_ply_default_columns", "spz_amd_ply_rows_to_cloud_device", "spz_amd_cloud_to_ply_rows_device",
     "spz_amd_ply_rows_to_cloud_host", "spz_amd_cloud_to_ply_rows_host",
     "spz_amd_median_scale_sum_device", "spz_amd_median_scale_sum_host",
+    "spz_amd_selftest_device",
 )
 
 
@@ -79,34 +80,6 @@ class SpzAmdError(RuntimeError):
 MEDIAN_WORKSPACE_BYTES = 8192   # SPZ_AMD_MEDIAN_WORKSPACE_BYTES
 
 _lib = None
-
-
-def wait_for_device(timeout_s=30.0, poll_s=2.0):
-    """Readiness probe for a freshly provisioned GPU box: asks a short-lived CHILD process whether the
-    HIP runtime sees a device (spz_amd_device_count), polling until it does or `timeout_s` passes.
-    A process whose own first HIP call fails stays without a device for its lifetime, so this is
-    meant to be called before the caller touches HIP.  Returns (device_count, last_hip_error); never
-    raises for "no device" and does not wait at all on a machine without /dev/kfd."""
-    import subprocess
-    import sys
-    import time
-    if not os.path.exists(LIB_PATH) or not os.path.exists("/dev/kfd"):
-        return 0, 0
-    code = ("import ctypes, sys; L = ctypes.CDLL(sys.argv[1]); "
-            "print(L.spz_amd_device_count(), L.spz_amd_last_hip_error())")
-    deadline = time.monotonic() + timeout_s
-    count, err = 0, 0
-    while True:
-        try:
-            r = subprocess.run([sys.executable, "-c", code, LIB_PATH], capture_output=True, text=True, timeout=120)
-            parts = r.stdout.split()
-            if r.returncode == 0 and len(parts) == 2:
-                count, err = int(parts[0]), int(parts[1])
-        except (OSError, subprocess.SubprocessError, ValueError):
-            pass
-        if count >= 1 or time.monotonic() >= deadline:
-            return count, err
-        time.sleep(poll_s)
 
 
 def load_library():
@@ -181,6 +154,8 @@ def bind(L):
     L.spz_amd_ply_rows_to_cloud_host.argtypes = [vp, u64, C.POINTER(PlyColumns), i32, C.POINTER(CloudPtrs), i32]
     L.spz_amd_cloud_to_ply_rows_host.restype = i32
     L.spz_amd_cloud_to_ply_rows_host.argtypes = [C.POINTER(CloudPtrs), u64, i32, i32, vp, i32]
+    L.spz_amd_selftest_device.restype = i32
+    L.spz_amd_selftest_device.argtypes = [i32, u64, u64, C.POINTER(u64 * 3), vp]
     return L
 
 

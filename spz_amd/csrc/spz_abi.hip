@@ -224,8 +224,58 @@ void add_section(KParams *p, uint32_t tile_units, uint32_t kind, uint8_t *bytes,
   s.n_elems = n_elems;
   s.n_units = (n_elems + 3) / 4;
   s.tile_begin = p->total_tiles;
+  s.tile_skip = 0;
   s.kind = kind;
   p->total_tiles += (uint32_t)((s.n_units + tile_units - 1) / tile_units);
+}
+
+// Turns the sequential grid (section after section) into: an interleaved part, in which every period of
+// kIlPeriod tiles holds each section's slots in proportion to its tile count and evenly spread, followed by
+// a sequential part with what is left of each section.
+void interleave_sections(KParams *p) {
+  const uint32_t n = p->n_sec, total = p->total_tiles;
+  if (n < 2 || total < 4 * kIlPeriod) return;
+  uint32_t tiles[SPZ_AMD_NUM_SECTIONS], count[SPZ_AMD_NUM_SECTIONS], used = 0;
+  for (uint32_t k = 0; k < n; ++k) {
+    tiles[k] = (k + 1 < n ? p->sec[k + 1].tile_begin : total) - p->sec[k].tile_begin;
+    count[k] = (uint32_t)(((unsigned long long)tiles[k] * kIlPeriod + total / 2) / total);
+    used += count[k];
+  }
+  // make the slot counts add up to the period: give to / take from the largest section
+  uint32_t big = 0;
+  for (uint32_t k = 1; k < n; ++k) big = tiles[k] > tiles[big] ? k : big;
+  if (used > kIlPeriod && count[big] <= used - kIlPeriod) return;
+  count[big] = count[big] + kIlPeriod - used;
+  uint32_t reps = 0xffffffffu;
+  for (uint32_t k = 0; k < n; ++k) {
+    if (count[k]) reps = tiles[k] / count[k] < reps ? tiles[k] / count[k] : reps;
+  }
+  if (reps == 0 || reps == 0xffffffffu) return;
+  // slot order: the i-th slot of section k wants position (i + 1/2) * period / count[k]
+  uint32_t given[SPZ_AMD_NUM_SECTIONS] = {};
+  for (uint32_t slot = 0; slot < kIlPeriod; ++slot) {
+    uint32_t best = n;
+    unsigned long long best_pos = ~0ull;
+    for (uint32_t k = 0; k < n; ++k) {
+      if (given[k] >= count[k]) continue;
+      const unsigned long long pos = (2ull * given[k] + 1ull) * kIlPeriod * 1024ull / (2ull * count[k]);
+      if (pos < best_pos) {
+        best_pos = pos;
+        best = k;
+      }
+    }
+    p->il_sec[slot] = (uint8_t)best;
+    p->il_rank[slot] = (uint8_t)given[best];
+    ++given[best];
+  }
+  p->il_tiles = reps * kIlPeriod;
+  uint32_t begin = p->il_tiles;
+  for (uint32_t k = 0; k < n; ++k) {
+    p->il_count[k] = (uint8_t)count[k];
+    p->sec[k].tile_skip = reps * count[k];
+    p->sec[k].tile_begin = begin;
+    begin += tiles[k] - reps * count[k];
+  }
 }
 
 int layout_impl(uint64_t n, int sh_degree, int version, spz_amd_layout *out) {
@@ -290,6 +340,7 @@ int encode_impl(const spz_amd_cloud_in *cl, uint64_t first, uint64_t count, uint
     p.header_words[3] = (uint32_t)sh_degree | (12u << 8) | ((antialiased ? 1u : 0u) << 16);
   }
   if (p.total_tiles == 0 && !write_header) return SPZ_AMD_OK;
+  if (SPZ_ENC_INTERLEAVE) interleave_sections(&p);
   uint32_t grid = 1;
   rc = grid_for(device, p.total_tiles, &grid);
   if (rc != SPZ_AMD_OK) return rc;
@@ -364,6 +415,7 @@ int decode_impl(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr,
     p.plain_tiles = (uint32_t)plain;
   }
 #endif
+  if (SPZ_DEC_INTERLEAVE && !SPZ_DEC_REVERSE) interleave_sections(&p);
   uint32_t grid = 1;
   rc = grid_for(device, p.total_tiles, &grid);
   if (rc != SPZ_AMD_OK) return rc;
@@ -765,6 +817,35 @@ int spz_amd_convert_coordinates_host(float *h_positions, float *h_rotations, flo
     if (b[i]) SPZ_HIP_TRY(hipMemcpyAsync(hp[i], b[i], cnt[i] * sizeof(float), hipMemcpyDeviceToHost, nullptr));
   }
   SPZ_HIP_TRY(hipStreamSynchronize(nullptr));
+  return SPZ_AMD_OK;
+}
+
+int spz_amd_selftest_device(int mode, uint64_t begin, uint64_t count, uint64_t result[3], void *hip_stream) {
+  if (result == nullptr || mode < 0 || mode > (int)SELFTEST_UNPACK_S3) return SPZ_AMD_ERR_INVALID_ARG;
+  int device = 0;
+  int rc = current_device(&device);
+  if (rc != SPZ_AMD_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(hip_stream);
+  unsigned long long *d = nullptr;
+  SPZ_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&d), 3 * sizeof(unsigned long long)));
+  const unsigned long long init[3] = {0ull, ~0ull, 0ull};
+  hipError_t e = hipMemcpyAsync(d, init, sizeof(init), hipMemcpyHostToDevice, st);
+  if (e == hipSuccess && count > 0) {
+    SelfTestParams p = {(uint32_t)mode, begin, count, d};
+    unsigned long long blocks = (count + 255) / 256;
+    if (blocks > 256ull * 64) blocks = 256ull * 64;  // grid-stride beyond that
+    hipLaunchKernelGGL(spz_selftest_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p);
+    e = hipGetLastError();
+  }
+  unsigned long long out[3] = {0, 0, 0};
+  if (e == hipSuccess) e = hipMemcpyAsync(out, d, sizeof(out), hipMemcpyDeviceToHost, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  (void)hipFree(d);
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    return SPZ_AMD_ERR_HIP;
+  }
+  for (int i = 0; i < 3; ++i) result[i] = out[i];
   return SPZ_AMD_OK;
 }
 

@@ -77,6 +77,20 @@ namespace spz_amd_detail {
 #ifndef SPZ_XCD_REMAP
 #define SPZ_XCD_REMAP 0
 #endif
+// 1: quaternion divisions without the IEEE expansion's operand scaling inside the exponent window where
+// that is exact (spz_kernels.hip, "Correctly rounded divisions ..."); 0: the plain `/` everywhere.
+// 1: the tiles of the sections are dealt out in a repeating pattern (each section gets slots in proportion
+// to its tile count) instead of section after section, so that at any moment the resident blocks are the
+// launch's average mix of arithmetic-heavy (rotations) and traffic-heavy (sh) tiles.
+#ifndef SPZ_ENC_INTERLEAVE
+#define SPZ_ENC_INTERLEAVE 0
+#endif
+#ifndef SPZ_DEC_INTERLEAVE
+#define SPZ_DEC_INTERLEAVE 0
+#endif
+#ifndef SPZ_QUAT_FAST
+#define SPZ_QUAT_FAST 1
+#endif
 #ifndef SPZ_BLOCKS_PER_CU
 #define SPZ_BLOCKS_PER_CU 0
 #endif
@@ -120,9 +134,15 @@ struct SecDesc {
   float *floats;               // float side
   unsigned long long n_elems;  // float elements in this section
   unsigned long long n_units;  // ceil(n_elems / 4)
-  uint32_t tile_begin;         // first tile of this section in the fused grid
+  uint32_t tile_begin;         // first tile of this section in the sequential part of the fused grid
+  uint32_t tile_skip;          // tiles of this section that the interleaved part of the grid covers
   uint32_t kind;
 };
+
+// Interleaved part of the grid: tiles [0, il_tiles) repeat a pattern of kIlPeriod slots; slot k belongs to
+// section il_sec[k] and is that section's il_rank[k]-th slot of the period.  The period is odd, so a
+// section's slots move over all eight XCDs (blocks b and b + 8 share one).
+constexpr uint32_t kIlPeriod = 61;
 
 struct KParams {
   SecDesc sec[SPZ_AMD_NUM_SECTIONS];
@@ -137,6 +157,10 @@ struct KParams {
   uint8_t *header_dst;            // encode: where the 16 header bytes go (nullptr: none)
   uint32_t header_words[4];
   uint32_t plain_tiles;           // decode: this many tiles, counted from the last one, use ordinary loads
+  uint32_t il_tiles;              // 0: no interleaved part
+  uint8_t il_count[8];            // slots per period of section k
+  uint8_t il_sec[64];
+  uint8_t il_rank[64];
 };
 
 constexpr int kTableAlphaDec = 0;    // 256 floats
@@ -160,7 +184,26 @@ struct GatherParams {
   const float *tables;
 };
 
+// Proof obligations of the fast quaternion arithmetic, checked on the device itself (spz_selftest_kernel):
+// every mode compares the fast form with the plain IEEE form it replaces over a range of inputs and
+// counts the inputs on which the bits differ.
+enum SelfTestMode : uint32_t {
+  SELFTEST_DIV_SQRT1_2 = 0,  // x / 0.70710677f, x = every float bit pattern in [begin, begin + count) inside the window
+  SELFTEST_DIV_511 = 1,      // x / 511.0f, likewise
+  SELFTEST_SQRT = 2,         // sqrt_cr(x) vs sqrtf, x in [2^-80, 2^82]
+  SELFTEST_QUOTIENT = 3,     // quat_quotient(a, b) vs a / b on hashed operand pairs inside the window
+  SELFTEST_PACK_S3 = 4,      // whole smallest-three encoder, fast vs general, hashed quaternions inside the window
+  SELFTEST_PACK_F3 = 5,      // whole first-three encoder, likewise
+  SELFTEST_UNPACK_S3 = 6,    // v3 decoder with div_by_const vs with `/ 511.0f`, comp = every 32-bit word in range
+};
+struct SelfTestParams {
+  uint32_t mode;
+  unsigned long long begin, count;
+  unsigned long long *mismatches;  // [0] = count, [1] = smallest mismatching index (init ~0), [2] = inputs compared
+};
+
 // The kernels (spz_kernels.hip).
+__global__ void spz_selftest_kernel(const SelfTestParams p);
 __global__ void spz_decode_gather_kernel(const GatherParams p);
 __global__ void spz_decode_kernel(const KParams p);
 __global__ void spz_encode_kernel(const KParams p);

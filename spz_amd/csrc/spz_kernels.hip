@@ -153,15 +153,109 @@ __device__ __forceinline__ uint32_t pack_u8x4(float a, float b, float c, float d
 
 constexpr float kSqrt1_2 = (float)0.707106781186547524401;  // load-spz.cc:46
 
-// packQuaternionSmallestThree (load-spz.cc:216-255) incl. normalized() (splat-types.cc:71-74).
-__device__ __forceinline__ uint32_t pack_quat_smallest_three(F32x4 r, uint32_t flip_q) {
+// ------------------------------------------------------------------------------------------
+// Correctly rounded divisions without the IEEE expansion's operand scaling.
+//
+// hipcc expands an f32 `a / b` into v_div_scale x2, v_rcp, five fma/mul, v_div_fmas, v_div_fixup
+// (11 VALU operations); a quaternion costs seven of them.  Inside the exponent window where
+// v_div_scale does not scale and v_div_fixup passes its operand through, the same arithmetic is
+// (a) for the four quotients x_i / norm: ONE refined reciprocal shared by all four, then the
+//     expansion's own two residual corrections (quat_quotient);
+// (b) for the divisions by the constants 0.70710677f and 511.0f: reciprocal multiply + one fma
+//     residual correction (div_by_const), which equals the IEEE quotient for every dividend that
+//     is zero or in [2^-100, 2^126] — checked over ALL such floats by spz_selftest_kernel
+//     (tests/test_gpu_parity.py::test_fast_divisions_exhaustive), as are (a) on 2^31 operand pairs
+//     and sqrt_cr on every float of its window.
+// Operands outside the window (quat_fast_ok) take the general forms below, unchanged from the
+// reference-shaped arithmetic; both forms give identical bits wherever the fast one is used.
+// ------------------------------------------------------------------------------------------
+constexpr uint32_t kFastLoBits = 0x2b800000u;  // 2^-40
+constexpr uint32_t kFastHiBits = 0x53800000u;  // 2^40
+
+// Every component is zero or has 2^-40 <= |x| <= 2^40, and at least one is not zero: then no square
+// under/overflows, norm is in [2^-40, 2^41], every quotient is zero or >= 2^-81 and every residual
+// of the corrections below is exactly representable.
+__device__ __forceinline__ bool quat_fast_ok(F32x4 r) {
+  const uint32_t a0 = __float_as_uint(r.x) & 0x7fffffffu, a1 = __float_as_uint(r.y) & 0x7fffffffu;
+  const uint32_t a2 = __float_as_uint(r.z) & 0x7fffffffu, a3 = __float_as_uint(r.w) & 0x7fffffffu;
+  // a - 1 wraps a zero to 0xffffffff, so zeros pass the lower bound
+  const uint32_t lo = min(min(a0 - 1u, a1 - 1u), min(a2 - 1u, a3 - 1u));
+  const uint32_t hi = max(max(a0, a1), max(a2, a3));
+  return lo >= kFastLoBits - 1u && hi <= kFastHiBits && hi != 0u;
+}
+
+// Correctly rounded sqrt for 2^-80 <= x <= 2^82 (no denormal scaling, no zero / inf fix-up): v_sqrt_f32
+// is within one ulp, the two neighbours are tried with exact residuals (the IEEE expansion's own step).
+__device__ __forceinline__ float sqrt_cr(float x) {
+  const float s = __builtin_amdgcn_sqrtf(x);
+  const float dn = __uint_as_float(__float_as_uint(s) - 1u);
+  const float up = __uint_as_float(__float_as_uint(s) + 1u);
+  const float r_dn = __builtin_fmaf(-dn, s, x);
+  const float r_up = __builtin_fmaf(-up, s, x);
+  float o = (r_dn <= 0.0f) ? dn : s;
+  o = (r_up > 0.0f) ? up : o;
+  return o;
+}
+
+// 1 / b refined once (v_rcp_f32 + one Newton step): the reciprocal the IEEE expansion uses.
+__device__ __forceinline__ float refined_rcp(float b) {
+  const float y0 = __builtin_amdgcn_rcpf(b);
+  const float e = __builtin_fmaf(-b, y0, 1.0f);
+  return __builtin_fmaf(e, y0, y0);
+}
+
+// a / b for a >= 0 (zero or >= 2^-100), b > 0, quotient zero or normal; y = refined_rcp(b).
+__device__ __forceinline__ float quat_quotient(float a, float b, float y) {
+  const float m = a * y;
+  const float r0 = __builtin_fmaf(-b, m, a);
+  const float q1 = __builtin_fmaf(r0, y, m);
+  const float r1 = __builtin_fmaf(-b, q1, a);
+  return __builtin_fmaf(r1, y, q1);
+}
+
+// x / c for a constant c with rc = RN(1 / c); x zero or in [2^-100, 2^126].
+__device__ __forceinline__ float div_by_const(float x, float c, float rc) {
+  const float m = x * rc;
+  const float rem = __builtin_fmaf(-m, c, x);
+  return __builtin_fmaf(rem, rc, m);
+}
+constexpr float kRcpSqrt1_2 = 1.0f / kSqrt1_2;
+constexpr float kRcp511 = 1.0f / 511.0f;
+
+struct Quat4 { float q0, q1, q2, q3; };
+
+// normalized() (splat-types.cc:71-74) followed by the xyz flip (load-spz.cc:224-227), general operands.
+__device__ __forceinline__ Quat4 normalized_flipped(F32x4 r, uint32_t flip_q) {
   float n2 = fadd_sep(fadd_sep(fadd_sep(fmul_sep(r.x, r.x), fmul_sep(r.y, r.y)), fmul_sep(r.z, r.z)),
                       fmul_sep(r.w, r.w));
   float norm = __builtin_sqrtf(n2);
-  float q0 = xor_sign(r.x / norm, flip_q & 1u);
-  float q1 = xor_sign(r.y / norm, (flip_q >> 1) & 1u);
-  float q2 = xor_sign(r.z / norm, (flip_q >> 2) & 1u);
-  float q3 = r.w / norm;
+  Quat4 q;
+  q.q0 = xor_sign(r.x / norm, flip_q & 1u);
+  q.q1 = xor_sign(r.y / norm, (flip_q >> 1) & 1u);
+  q.q2 = xor_sign(r.z / norm, (flip_q >> 2) & 1u);
+  q.q3 = r.w / norm;
+  return q;
+}
+
+// The same for operands inside the quat_fast_ok window: same bits, 4 + 9 + 20 operations instead of 4 + 15 + 44.
+__device__ __forceinline__ Quat4 normalized_flipped_fast(F32x4 r, uint32_t flip_q) {
+  float n2 = fadd_sep(fadd_sep(fadd_sep(fmul_sep(r.x, r.x), fmul_sep(r.y, r.y)), fmul_sep(r.z, r.z)),
+                      fmul_sep(r.w, r.w));
+  const float norm = sqrt_cr(n2);
+  const float y = refined_rcp(norm);
+  const uint32_t sx = (__float_as_uint(r.x) >> 31) ^ (flip_q & 1u), sy = (__float_as_uint(r.y) >> 31) ^ ((flip_q >> 1) & 1u);
+  const uint32_t sz = (__float_as_uint(r.z) >> 31) ^ ((flip_q >> 2) & 1u), sw = __float_as_uint(r.w) >> 31;
+  Quat4 q;
+  q.q0 = xor_sign(quat_quotient(__builtin_fabsf(r.x), norm, y), sx);
+  q.q1 = xor_sign(quat_quotient(__builtin_fabsf(r.y), norm, y), sy);
+  q.q2 = xor_sign(quat_quotient(__builtin_fabsf(r.z), norm, y), sz);
+  q.q3 = xor_sign(quat_quotient(__builtin_fabsf(r.w), norm, y), sw);
+  return q;
+}
+
+// The bit-field assembly of packQuaternionSmallestThree (load-spz.cc:229-254), general operands.
+__device__ __forceinline__ uint32_t smallest_three_fields(Quat4 q) {
+  const float q0 = q.q0, q1 = q.q1, q2 = q.q2, q3 = q.q3;
   // argmax |q|, strict >, first wins
   uint32_t iL = 0;
   float best = __builtin_fabsf(q0);
@@ -183,25 +277,61 @@ __device__ __forceinline__ uint32_t pack_quat_smallest_three(F32x4 r, uint32_t f
   return comp;
 }
 
+// The same for |q_i| zero or in [2^-100, 2]: only the three kept components are quantised, the
+// divisions by sqrt(1/2) are reciprocal multiplies with a residual correction, and 511 t + 0.5 < 2^31
+// converts with one instruction.
+__device__ __forceinline__ uint32_t smallest_three_fields_fast(Quat4 q) {
+  const float a0 = __builtin_fabsf(q.q0), a1 = __builtin_fabsf(q.q1), a2 = __builtin_fabsf(q.q2), a3 = __builtin_fabsf(q.q3);
+  uint32_t iL = 0;
+  float best = a0;
+  if (a1 > best) { iL = 1; best = a1; }
+  if (a2 > best) { iL = 2; best = a2; }
+  if (a3 > best) { iL = 3; best = a3; }
+  const float qL = (iL == 0) ? q.q0 : (iL == 1) ? q.q1 : (iL == 2) ? q.q2 : q.q3;
+  const uint32_t negate = (qL < 0.0f) ? 1u : 0u;
+  // the components other than iL, in index order
+  const float c0 = (iL == 0) ? q.q1 : q.q0;
+  const float c1 = (iL <= 1) ? q.q2 : q.q1;
+  const float c2 = (iL <= 2) ? q.q3 : q.q2;
+  uint32_t comp = iL;
+  const float cs[3] = {c0, c1, c2};
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const uint32_t negbit = ((cs[i] < 0.0f) ? 1u : 0u) ^ negate;
+    const float t = div_by_const(__builtin_fabsf(cs[i]), kSqrt1_2, kRcpSqrt1_2);
+    const float m = fmul_sep(511.0f, t) + 0.5f;
+    comp = (comp << 10) | (negbit << 9) | (uint32_t)m;
+  }
+  return comp;
+}
+
+// packQuaternionSmallestThree (load-spz.cc:216-255) incl. normalized() (splat-types.cc:71-74).
+__device__ __forceinline__ uint32_t pack_quat_smallest_three(F32x4 r, uint32_t flip_q) {
+#if SPZ_QUAT_FAST
+  if (quat_fast_ok(r)) return smallest_three_fields_fast(normalized_flipped_fast(r, flip_q));
+#endif
+  return smallest_three_fields(normalized_flipped(r, flip_q));
+}
+
 // PARITY UNPINNED (no v2 encoder in the reference): upstream nianticlabs/spz v1.x
 // first-three encoder — normalise, flip, scale by +-127.5 so that w >= 0, offset, toUint8.
 __device__ __forceinline__ uint32_t pack_quat_first_three(F32x4 r, uint32_t flip_q) {
-  float n2 = fadd_sep(fadd_sep(fadd_sep(fmul_sep(r.x, r.x), fmul_sep(r.y, r.y)), fmul_sep(r.z, r.z)),
-                      fmul_sep(r.w, r.w));
-  float norm = __builtin_sqrtf(n2);
-  float q0 = xor_sign(r.x / norm, flip_q & 1u);
-  float q1 = xor_sign(r.y / norm, (flip_q >> 1) & 1u);
-  float q2 = xor_sign(r.z / norm, (flip_q >> 2) & 1u);
-  float q3 = r.w / norm;
-  float s = (q3 < 0.0f) ? -127.5f : 127.5f;
-  uint32_t b0 = to_uint8(fmul_sep(q0, s) + 127.5f);
-  uint32_t b1 = to_uint8(fmul_sep(q1, s) + 127.5f);
-  uint32_t b2 = to_uint8(fmul_sep(q2, s) + 127.5f);
+  Quat4 q;
+#if SPZ_QUAT_FAST
+  if (quat_fast_ok(r)) q = normalized_flipped_fast(r, flip_q);
+  else
+#endif
+    q = normalized_flipped(r, flip_q);
+  float s = (q.q3 < 0.0f) ? -127.5f : 127.5f;
+  uint32_t b0 = to_uint8(fmul_sep(q.q0, s) + 127.5f);
+  uint32_t b1 = to_uint8(fmul_sep(q.q1, s) + 127.5f);
+  uint32_t b2 = to_uint8(fmul_sep(q.q2, s) + 127.5f);
   return b0 | (b1 << 8) | (b2 << 16);
 }
 
 // unpackQuaternionSmallestThree (load-spz.cc:347-381) followed by the flip pass.
-__device__ __forceinline__ F32x4 unpack_quat_smallest_three(uint32_t comp, uint32_t flip_q) {
+template <bool FAST>
+__device__ __forceinline__ F32x4 unpack_quat_smallest_three_t(uint32_t comp, uint32_t flip_q) {
   const uint32_t iL = comp >> 30;
   float v[4] = {0.0f, 0.0f, 0.0f, 0.0f};
   float sum = 0.0f;
@@ -210,7 +340,10 @@ __device__ __forceinline__ F32x4 unpack_quat_smallest_three(uint32_t comp, uint3
     const bool take = ((uint32_t)i != iL);
     uint32_t mag = comp & 511u;
     uint32_t neg = (comp >> 9) & 1u;
-    float c = fmul_sep(kSqrt1_2, (float)mag) / 511.0f;
+    // (sqrt1_2 * mag) / 511.f: the dividend is zero or in [0.707, 361.4] for the 512 magnitudes
+    float c = fmul_sep(kSqrt1_2, (float)mag);
+    if constexpr (FAST) c = div_by_const(c, 511.0f, kRcp511);
+    else c = c / 511.0f;
     c = __uint_as_float(__float_as_uint(c) ^ (neg << 31));
     float s2 = sum + fmul_sep(c, c);
     v[i] = take ? c : 0.0f;
@@ -231,6 +364,9 @@ __device__ __forceinline__ F32x4 unpack_quat_smallest_three(uint32_t comp, uint3
   o.z = mul_pm1(z, (flip_q >> 2) & 1u);
   o.w = w;
   return o;
+}
+__device__ __forceinline__ F32x4 unpack_quat_smallest_three(uint32_t comp, uint32_t flip_q) {
+  return unpack_quat_smallest_three_t<SPZ_QUAT_FAST != 0>(comp, flip_q);
 }
 
 // unpackQuaternionFirstThree (load-spz.cc:333-345) followed by the flip pass.
@@ -487,6 +623,21 @@ __device__ __forceinline__ uint32_t find_section(const KParams &p, uint32_t tile
   return si;
 }
 
+// Tile of the fused grid -> (section, tile within the section).
+struct TileRef { uint32_t si, tl; };
+__device__ __forceinline__ TileRef locate_tile(const KParams &p, uint32_t tile) {
+  TileRef t;
+  if (tile < p.il_tiles) {
+    const uint32_t rep = tile / kIlPeriod, k = tile - rep * kIlPeriod;
+    t.si = p.il_sec[k];
+    t.tl = rep * p.il_count[t.si] + p.il_rank[k];
+  } else {
+    t.si = find_section(p, tile);
+    t.tl = tile - p.sec[t.si].tile_begin + p.sec[t.si].tile_skip;
+  }
+  return t;
+}
+
 template <class G>
 __device__ __forceinline__ void stage_tables(float *lut, const float *__restrict__ tables) {
   for (uint32_t i = threadIdx.x; i < kTableFloats; i += G::kBlock) lut[i] = tables[i];
@@ -529,9 +680,9 @@ __global__ __launch_bounds__(DecGeom::kBlock) void spz_decode_kernel(const KPara
   c.lut = lut;
   for (uint32_t t0 = first_tile(p); t0 < p.total_tiles; t0 = SPZ_XCD_REMAP ? 0xffffffffu : t0 + gridDim.x) {
     const uint32_t tile = SPZ_DEC_REVERSE ? p.total_tiles - 1u - t0 : t0;
-    const uint32_t si = find_section(p, tile);
-    const SecDesc &s = p.sec[si];
-    const uint32_t tl = tile - s.tile_begin;
+    const TileRef ref = locate_tile(p, tile);
+    const SecDesc &s = p.sec[ref.si];
+    const uint32_t tl = ref.tl;
     if (SPZ_DEC_REVERSE && SPZ_DEC_NTL && t0 < p.plain_tiles) decode_one_tile<DecGeomHot>(p, s, tl, c, lut, lut_ready);
     else decode_one_tile<DecGeom>(p, s, tl, c, lut, lut_ready);
   }
@@ -682,9 +833,9 @@ __global__ __launch_bounds__(EncGeom::kBlock, SPZ_ENC_MIN_WAVES) void spz_encode
     p.header_dst[threadIdx.x] = (uint8_t)(p.header_words[threadIdx.x >> 2] >> ((threadIdx.x & 3u) * 8u));
   }
   for (uint32_t tile = first_tile(p); tile < p.total_tiles; tile = SPZ_XCD_REMAP ? 0xffffffffu : tile + gridDim.x) {
-    const uint32_t si = find_section(p, tile);
-    const SecDesc &s = p.sec[si];
-    const uint32_t tl = tile - s.tile_begin;
+    const TileRef ref = locate_tile(p, tile);
+    const SecDesc &s = p.sec[ref.si];
+    const uint32_t tl = ref.tl;
     switch (s.kind) {
       case KIND_POS24: encode_tile<KIND_POS24, 0, EncGeom>(s, tl, c); break;
       case KIND_ALPHA:
@@ -857,5 +1008,121 @@ __global__ __launch_bounds__(256) void spz_decode_gather_kernel(const GatherPara
 
 namespace {
 
+// ------------------------------------------------------------------------------------------
+// Self test of the fast quaternion arithmetic (SelfTestMode in spz_kernel_params.hpp)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long mix64(unsigned long long z) {  // splitmix64 finaliser
+  z += 0x9e3779b97f4a7c15ull;
+  z = (z ^ (z >> 30)) * 0xbf58476d1ce4e5b9ull;
+  z = (z ^ (z >> 27)) * 0x94d049bb133111ebull;
+  return z ^ (z >> 31);
+}
+
+// A float inside the quat_fast_ok window from 32 hashed bits: sign, exponent 2^-40 .. 2^39, mantissa;
+// about one in sixteen is a zero.
+__device__ __forceinline__ float window_float(uint32_t h) {
+  const uint32_t sign = h & 0x80000000u;
+  if (((h >> 23) & 0xfu) == 0u && (h & 0x40000000u)) return __uint_as_float(sign);
+  const uint32_t e = 87u + ((h >> 23) & 0xffu) % 80u;
+  return __uint_as_float(sign | (e << 23) | (h & 0x7fffffu));
+}
+
+// Quaternions whose components are close in magnitude (near-ties of the arg-max) or spread over the window.
+__device__ __forceinline__ F32x4 window_quat(unsigned long long i) {
+  const unsigned long long h0 = mix64(i * 2ull), h1 = mix64(i * 2ull + 1ull);
+  F32x4 r;
+  r.x = window_float((uint32_t)h0);
+  r.y = window_float((uint32_t)(h0 >> 32));
+  r.z = window_float((uint32_t)h1);
+  r.w = window_float((uint32_t)(h1 >> 32));
+  if ((i & 3ull) != 0ull) {  // three of four: every component within a few ulp .. a factor 2 of the first
+    const uint32_t base = __float_as_uint(r.x) & 0x7fffffffu;
+    const uint32_t spread = (i & 4ull) ? 0x7u : 0x7fffffu;
+    auto near = [&](float v, uint32_t h) {
+      const uint32_t b = base == 0u ? 0x3f800000u : base;
+      return __uint_as_float((__float_as_uint(v) & 0x80000000u) | ((b & ~spread) | (h & spread)));
+    };
+    r.y = near(r.y, (uint32_t)(h0 >> 40));
+    r.z = near(r.z, (uint32_t)(h1 >> 8));
+    r.w = near(r.w, (uint32_t)(h1 >> 40));
+  }
+  return r;
+}
+
 }  // namespace
+
+__global__ __launch_bounds__(256) void spz_selftest_kernel(const SelfTestParams p) {
+  const unsigned long long stride = (unsigned long long)gridDim.x * blockDim.x;
+  unsigned long long bad = 0, first = ~0ull, seen = 0;
+  for (unsigned long long k = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x; k < p.count; k += stride) {
+    const unsigned long long i = p.begin + k;
+    bool differs = false, used = true;
+    if (p.mode == SELFTEST_DIV_SQRT1_2 || p.mode == SELFTEST_DIV_511) {
+      const float x = __uint_as_float((uint32_t)i);
+      used = i <= 0x7f800000ull && (i == 0ull || (x >= 0x1p-100f && x <= 0x1p126f));
+      if (used) {
+        float fast, plain;
+        if (p.mode == SELFTEST_DIV_SQRT1_2) {
+          fast = div_by_const(x, kSqrt1_2, kRcpSqrt1_2);
+          plain = x / kSqrt1_2;
+        } else {
+          fast = div_by_const(x, 511.0f, kRcp511);
+          plain = x / 511.0f;
+        }
+        differs = __float_as_uint(fast) != __float_as_uint(plain);
+      }
+    } else if (p.mode == SELFTEST_SQRT) {
+      const float x = __uint_as_float((uint32_t)i);
+      used = i <= 0x7f800000ull && x >= 0x1p-80f && x <= 0x1p82f;
+      if (used) differs = __float_as_uint(sqrt_cr(x)) != __float_as_uint(__builtin_sqrtf(x));
+    } else if (p.mode == SELFTEST_QUOTIENT) {
+      // b: exponent 2^-40 .. 2^41; a: zero or 2^-40 <= a <= 2 b
+      const unsigned long long h = mix64(i);
+      const uint32_t eb = 87u + (uint32_t)(h & 0xffu) % 82u;
+      const float b = __uint_as_float((eb << 23) | (uint32_t)((h >> 8) & 0x7fffffu));
+      uint32_t ea = eb + 1u - (uint32_t)((h >> 31) & 0xffu) % (eb + 2u - 87u);
+      float a = __uint_as_float((ea << 23) | (uint32_t)((h >> 40) & 0x7fffffu));
+      if ((i & 1ull) != 0ull) a = __uint_as_float((__float_as_uint(b) & ~0xfu) | (uint32_t)((h >> 60) & 0xfu));  // a ~ b
+      if (a > 2.0f * b) a = b;
+      const float fast = quat_quotient(a, b, refined_rcp(b));
+      const float plain = a / b;
+      differs = __float_as_uint(fast) != __float_as_uint(plain);
+    } else if (p.mode == SELFTEST_PACK_S3 || p.mode == SELFTEST_PACK_F3) {
+      const F32x4 r = window_quat(i);
+      const uint32_t flip_q = (uint32_t)(mix64(~i) & 7u);
+      used = quat_fast_ok(r);
+      if (used) {
+        const Quat4 qf = normalized_flipped_fast(r, flip_q), qg = normalized_flipped(r, flip_q);
+        differs = __float_as_uint(qf.q0) != __float_as_uint(qg.q0) || __float_as_uint(qf.q1) != __float_as_uint(qg.q1) ||
+                  __float_as_uint(qf.q2) != __float_as_uint(qg.q2) || __float_as_uint(qf.q3) != __float_as_uint(qg.q3);
+        if (p.mode == SELFTEST_PACK_S3) differs = differs || smallest_three_fields_fast(qf) != smallest_three_fields(qg);
+      }
+    } else if (p.mode == SELFTEST_UNPACK_S3) {
+      const uint32_t flip_q = (uint32_t)(i >> 32) & 7u;
+      const F32x4 f = unpack_quat_smallest_three_t<true>((uint32_t)i, flip_q), g = unpack_quat_smallest_three_t<false>((uint32_t)i, flip_q);
+      differs = __float_as_uint(f.x) != __float_as_uint(g.x) || __float_as_uint(f.y) != __float_as_uint(g.y) ||
+                __float_as_uint(f.z) != __float_as_uint(g.z) || __float_as_uint(f.w) != __float_as_uint(g.w);
+    } else {
+      used = false;
+    }
+    seen += used ? 1ull : 0ull;
+    if (differs) {
+      ++bad;
+      first = i < first ? i : first;
+    }
+  }
+  // one atomic per wave
+  for (int off = 32; off >= 1; off >>= 1) {
+    bad += __shfl_down(bad, off);
+    seen += __shfl_down(seen, off);
+    const unsigned long long o = __shfl_down(first, off);
+    first = o < first ? o : first;
+  }
+  if ((threadIdx.x & 63u) == 0u) {
+    if (bad) atomicAdd(&p.mismatches[0], bad);
+    if (first != ~0ull) atomicMin(&p.mismatches[1], first);
+    atomicAdd(&p.mismatches[2], seen);
+  }
+}
+
 }  // namespace spz_amd_detail

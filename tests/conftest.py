@@ -63,13 +63,10 @@ def reference():
 
 @pytest.fixture(scope="session")
 def cuda():
-    # a box that has only just been provisioned may need a moment before HIP sees its device: probe from
-    # a child process first, because a failed first HIP call sticks to the process that made it
-    from spz_amd import abi
-    count, err = abi.wait_for_device()
-    if os.path.exists("/dev/kfd") and count < 1:
-        pytest.fail(f"test marked gpu but the HIP runtime reports no device (hipError {err})")
+    # one non-polling check: a missing device fails at once, with the HIP error code
     import torch
-    if not torch.cuda.is_available():
-        pytest.fail("test marked gpu but no GPU is visible")
+    from spz_amd import abi
+    if abi.load_library().spz_amd_device_count() < 1 or not torch.cuda.is_available():
+        pytest.fail("test marked gpu but the HIP runtime reports no device "
+                    f"(hipError {abi.load_library().spz_amd_last_hip_error()})")
     return torch.device("cuda:0")

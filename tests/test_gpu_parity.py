@@ -234,6 +234,37 @@ def test_alpha_thresholds_every_step(dev, oracle):
     assert_bytes_equal(gpu_encode(c, n, 0, False, 0, dev), oracle.pack(c, n, 0, False, 0), "alpha thresholds")
 
 
+def _selftest(mode, begin, count):
+    from spz_amd import abi
+    res = (C.c_uint64 * 3)()
+    rc = abi.load_library().spz_amd_selftest_device(mode, begin, count, C.byref(res), None)
+    assert rc == 0, rc
+    return int(res[0]), int(res[1]), int(res[2])
+
+
+def test_fast_divisions_exhaustive(dev):
+    """The quaternion kernels divide without the IEEE expansion's operand scaling inside an exponent window
+    (spz_kernels.hip: div_by_const, quat_quotient, sqrt_cr).  Proof obligations, run on the device that
+    ships them: x / 0.70710677f (load-spz.cc:244) and x / 511.f (:366) against the IEEE quotient for EVERY
+    non-negative float in the window, sqrt for every float in its window, the shared-reciprocal quotient on
+    2^32 hashed operand pairs, and the whole encoders / the v3 decoder fast-vs-general (2^31 hashed
+    quaternions, all 2^32 rotation words)."""
+    top = 0x7f800000 + 1
+    for mode, name in ((0, "x / sqrt1_2"), (1, "x / 511"), (2, "sqrt")):
+        bad, first, seen = _selftest(mode, 0, top)
+        assert bad == 0, f"{name}: {bad} floats differ, first bit pattern {first:#010x}"
+        assert seen > (200 << 23), f"{name}: only {seen} inputs were inside the window"
+    for mode, name, count in ((3, "x / norm", 1 << 32), (4, "smallest-three encoder", 1 << 31),
+                              (5, "first-three encoder", 1 << 30), (6, "smallest-three decoder", 1 << 35)):
+        bad, first, seen = _selftest(mode, 0, count)
+        assert bad == 0, f"{name}: {bad} inputs differ, first index {first}"
+        assert seen > count // 2, f"{name}: only {seen} of {count} inputs were inside the window"
+    # the 512 dividends the decoder actually meets
+    sq = np.float32(0.707106781186547524401)
+    t = (sq * np.arange(512, dtype=np.float32)).astype(np.float32)
+    assert all(_selftest(1, int(b), 1) == (0, 2**64 - 1, 1) for b in t.view(np.uint32))
+
+
 def test_v2_encode_round_trip_unpinned(dev, oracle):
     """v2 ENCODE is 'parity unpinned' (the reference has no v2 encoder).  Checked by: identical
     bytes to the oracle's restatement of the published upstream formula, decode through the
@@ -257,12 +288,14 @@ def test_v2_encode_round_trip_unpinned(dev, oracle):
     # quantised components already have norm >= 1 the decoder clamps w to 0 (load-spz.cc:344), the
     # re-encode renormalises, and a byte can move by one: a property of the v2 format itself.
     again = gpu_encode(u, n, deg, False, 6, dev, version=2)
+    # the parity statement: the re-encode is, byte for byte, what the oracle makes of the oracle's decode
+    assert_bytes_equal(again, oracle.pack(w, n, deg, False, 6, version=2), "v2 re-encode vs oracle.pack(oracle.unpack(.))")
     o_rot = 16 + 16 * n
     a = again[o_rot:o_rot + 3 * n].reshape(-1, 3)
     b = got[o_rot:o_rot + 3 * n].reshape(-1, 3)
     moved = (a != b).any(axis=1)
     assert np.abs(a.astype(int) - b.astype(int)).max() <= 1
-    assert moved.sum() <= n // 1000
+    assert moved.sum() <= n // 1000   # sanity net only; the equality above is what guards parity
     assert np.all(d[moved, 3] < 0.13), "a rotation moved on re-encode although w was not near the clamp"
 
 
@@ -401,7 +434,8 @@ def test_full_size_properties_10m_sh3(dev, oracle):
     diff = (s1[o_rot:e_rot].reshape(-1, 4) != s2[o_rot:e_rot].reshape(-1, 4)).any(dim=1)
     ndiff = int(diff.sum())
     # measured: 0.26 % of N(0,1)^4 quaternions have their two largest components within one
-    # quantisation step (0.707/511) of each other
+    # quantisation step (0.707/511) of each other.  Sanity net only: WHICH words change is pinned below,
+    # where the window of s2 must equal oracle.pack(oracle.unpack(window)) byte for byte.
     assert ndiff <= n // 100, f"{ndiff} rotations changed on re-encode"
     if ndiff:
         d2 = D.decode(s2, h, abi.RDF)
@@ -415,7 +449,9 @@ def test_full_size_properties_10m_sh3(dev, oracle):
     torch.cuda.synchronize()
     for k in FIELDS:
         assert torch.equal(two[k].view(torch.int32), d1[k].view(torch.int32)), k
-    del two, s2
+    del two
+    s2_np = s2.cpu().numpy()
+    del s2
     a, w = 7_654_321, 65_536
     sub = {k: t[k][a * floats_per_point(k, deg):(a + w) * floats_per_point(k, deg)].cpu().numpy() for k in FIELDS}
     want = oracle.pack(sub, w, deg, False, abi.RDF)
@@ -430,6 +466,16 @@ def test_full_size_properties_10m_sh3(dev, oracle):
     for k in FIELDS:
         f = floats_per_point(k, deg)
         assert_bits_equal(d1[k][a * f:(a + w) * f].cpu().numpy(), uw[k], f"decode window {k}")
+    # (1) as an equality, rotation section included: the re-encoded window is what the oracle re-encodes
+    # from its own decode of the window (load-spz.cc:216-255 applied to the output of :347-381)
+    again = oracle.pack(uw, w, deg, False, abi.RDF)
+    for sec in range(6):
+        bpp = lay.bytes_per_point[sec]
+        got = s2_np[lay.offset[sec] + a * bpp:lay.offset[sec] + (a + w) * bpp]
+        assert_bytes_equal(got, again[lay_w.offset[sec]:lay_w.offset[sec] + w * bpp], f"re-encode, section {sec} window")
+    o_w = lay_w.offset[abi.SEC_ROTATIONS]
+    changed = (want[o_w:o_w + 4 * w].reshape(-1, 4) != again[o_w:o_w + 4 * w].reshape(-1, 4)).any(axis=1)
+    assert 0 < int(changed.sum()) <= w // 100, "the window holds no near-tie: pick another window"
 
 
 def test_baseline_config2_1m_sh0_v2(dev, oracle):

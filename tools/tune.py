@@ -24,21 +24,23 @@ def D(block=256, unroll=4, wc=0, ntl=0, nts=0):
     return {"SPZ_DEC_BLOCK": block, "SPZ_DEC_UNROLL": unroll, "SPZ_DEC_WC": wc, "SPZ_DEC_NTL": ntl, "SPZ_DEC_NTS": nts}
 
 
-# Encode and decode geometries are independent; library i carries encode config i and decode config i
-# (the two columns of a row are unrelated experiments).  All are "flat" (one tile per block).
-_S = dict(E(wc=1, ntl=1), SPZ_ENC_SCHED_BARRIER=1)
-_SN = dict(E(wc=1, ntl=1, nts=1), SPZ_ENC_SCHED_BARRIER=1)
-# pairs: what one kernel leaves in the write-back caches changes the NEXT kernel's time, so an
-# (encode, decode) pair is timed in its own steady state (run() executes every pair twice, timing the second)
-_R = dict(D(ntl=1, nts=1), SPZ_DEC_REVERSE=1)
-ENC = {"fwd_nt": dict(_S), "rev_hot128": dict(_S), "rev_hot200": dict(_S), "rev_hot256": dict(_S),
-       "rev_hot384": dict(_S), "rev_allplain": dict(_S), "fwd_nt_b": dict(_S)}
-DEC = {"fwd_nt": D(ntl=1, nts=1), "rev_hot128": dict(_R, SPZ_DEC_HOT_MIB=128), "rev_hot200": dict(_R, SPZ_DEC_HOT_MIB=200),
-       "rev_hot256": dict(_R, SPZ_DEC_HOT_MIB=256), "rev_hot384": dict(_R, SPZ_DEC_HOT_MIB=384),
-       "rev_allplain": dict(D(ntl=0, nts=1), SPZ_DEC_REVERSE=1), "fwd_nt_b": D(ntl=1, nts=1)}
-VARIANTS = {}
-for _i, (_e, _d) in enumerate(zip(ENC.items(), DEC.items())):
-    VARIANTS[f"v{_i:02d}"] = {"enc": _e[0], "dec": _d[0], "defs": {**_e[1], **_d[1]}}
+# Round-2 experiments (the round-1 geometry / non-temporal / reverse-order tables are in git history and
+# profiles/r01_tune_*.jsonl).  Every variant is the shipped configuration plus the listed macros.
+VARIANTS = {
+    "quat_ieee": {"enc": "plain IEEE divisions in the quaternion code", "dec": "same", "defs": {"SPZ_QUAT_FAST": 0}},
+    "quat_fast": {"enc": "shipped (fast exact divisions)", "dec": "same", "defs": {"SPZ_QUAT_FAST": 1}},
+    "il_enc": {"enc": "sections interleaved", "dec": "shipped", "defs": {"SPZ_ENC_INTERLEAVE": 1}},
+    "il_both": {"enc": "sections interleaved", "dec": "sections interleaved",
+                "defs": {"SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 1}},
+    "il_ieee": {"enc": "sections interleaved, IEEE divisions", "dec": "interleaved, IEEE",
+                "defs": {"SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 1, "SPZ_QUAT_FAST": 0}},
+    "u2": {"enc": "256 x 2 units", "dec": "256 x 2 units", "defs": {"SPZ_ENC_UNROLL": 2, "SPZ_DEC_UNROLL": 2}},
+    "u1": {"enc": "256 x 1 unit", "dec": "256 x 1 unit", "defs": {"SPZ_ENC_UNROLL": 1, "SPZ_DEC_UNROLL": 1}},
+    "u8": {"enc": "256 x 8 units", "dec": "256 x 8 units", "defs": {"SPZ_ENC_UNROLL": 8, "SPZ_DEC_UNROLL": 8}},
+    "u2_il": {"enc": "256 x 2, interleaved", "dec": "256 x 2, interleaved",
+              "defs": {"SPZ_ENC_UNROLL": 2, "SPZ_DEC_UNROLL": 2, "SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 1}},
+    "quat_fast_b": {"enc": "shipped, second copy (noise floor)", "dec": "same", "defs": {"SPZ_QUAT_FAST": 1}},
+}
 
 
 def build(names):
@@ -54,7 +56,7 @@ def build(names):
         subprocess.run(cmd, check=True)
 
 
-def run(points, rounds, names, deg=3):
+def run(points, rounds, names, deg=3, version=3):
     import statistics
 
     import torch
@@ -64,12 +66,12 @@ def run(points, rounds, names, deg=3):
     dev = torch.device("cuda:0")
     cloud = make_cloud_torch(points, deg, 3, dev)
     out = {k: torch.empty_like(cloud[k]) for k in FIELDS}
-    lay = abi.stream_layout(points, deg, 3)
+    lay = abi.stream_layout(points, deg, version)
     stream = torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev)
     ref_stream = None
     pin = abi.CloudPtrs(*[cloud[k].data_ptr() for k in FIELDS])
     pout = abi.CloudPtrs(*[out[k].data_ptr() for k in FIELDS])
-    hdr = abi.Header(3, points, deg, 12, 0, 0)
+    hdr = abi.Header(version, points, deg, 12, 0, 0)
     libs = {}
     VARIANTS["prod"] = {"enc": "shipped defaults", "dec": "shipped defaults", "defs": {}}
     for name in names:
@@ -83,7 +85,7 @@ def run(points, rounds, names, deg=3):
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def enc(L):
-        rc = L.spz_amd_encode_device(C.byref(pin), points, deg, 0, 6, 3, stream.data_ptr(), stream.numel(), s)
+        rc = L.spz_amd_encode_device(C.byref(pin), points, deg, 0, 6, version, stream.data_ptr(), stream.numel(), s)
         assert rc == 0, rc
 
     def dec(L):
@@ -92,7 +94,10 @@ def run(points, rounds, names, deg=3):
 
     times = {n: {"enc": [], "dec": [], "dec_cold": []} for n in libs}
     scrub = torch.empty(1 << 30, dtype=torch.uint8, device=dev)   # evicts the stream from the caches
-    for name, L in libs.items():   # warm-up + cross-variant parity
+    for name, L in libs.items():   # warm-up + cross-variant parity (outputs cleared first: a tile nobody wrote must show)
+        stream.zero_()
+        for k in FIELDS:
+            out[k].fill_(float("nan"))
         enc(L); dec(L)
         torch.cuda.synchronize()
         if ref_stream is None:
@@ -115,16 +120,18 @@ def run(points, rounds, names, deg=3):
             c[0].record(); dec(L); c[1].record()
             torch.cuda.synchronize()
             times[name]["dec_cold"].append(c[0].elapsed_time(c[1]))
-    bpp = {0: 76, 1: 121, 2: 196, 3: 301}[deg]
+    bpp = {0: 76, 1: 121, 2: 196, 3: 301}[deg] - (1 if version == 2 else 0)
     gb = points * bpp / 1e9
     rows = []
     for name in libs:
-        r = {"variant": name, "enc_cfg": VARIANTS[name]["enc"], "dec_cfg": VARIANTS[name]["dec"]}
+        r = {"variant": name, "points": points, "sh_degree": deg, "version": version,
+             "enc_cfg": VARIANTS[name]["enc"], "dec_cfg": VARIANTS[name]["dec"]}
         for k in ("enc", "dec", "dec_cold"):
             med, mn = statistics.median(times[name][k]), min(times[name][k])
             r[f"{k}_ms_med"] = round(med, 4)
             r[f"{k}_ms_min"] = round(mn, 4)
             r[f"{k}_GBps_med"] = round(gb / (med * 1e-3), 1)
+            r[f"{k}_frac_of_8TBps"] = round(gb / (med * 1e-3) / 8000.0, 3)
         r["pair_ms_med"] = round(r["enc_ms_med"] + r["dec_ms_med"], 4)
         rows.append(r)
         print(json.dumps(r), flush=True)
@@ -137,10 +144,12 @@ if __name__ == "__main__":
     ap.add_argument("mode", choices=["build", "run"])
     ap.add_argument("--points", type=int, default=10_000_000)
     ap.add_argument("--rounds", type=int, default=15)
+    ap.add_argument("--deg", type=int, default=3)
+    ap.add_argument("--version", type=int, default=3)
     ap.add_argument("--variants", default=",".join(VARIANTS))
     a = ap.parse_args()
     names = [v for v in a.variants.split(",") if v]
     if a.mode == "build":
         build(names)
     else:
-        run(a.points, a.rounds, names)
+        run(a.points, a.rounds, names, a.deg, a.version)
