@@ -29,14 +29,14 @@ all: device host python cli oracle
 device: $(LIBDIR)/libspz_amd.so
 host:   $(LIBDIR)/libspz_host.so
 python: $(ROOT)spz_amd/spz$(PYEXT)
-cli:    $(ROOT)spz_amd/bin/spz_tool $(ROOT)spz_amd/bin/dropin_user_test
+cli:    $(ROOT)spz_amd/bin/spz_tool $(ROOT)spz_amd/bin/dropin_user_test $(ROOT)spz_amd/bin/host_bench
 
 DEVICE_SRCS := $(CSRC)/spz_kernels.hip $(CSRC)/spz_abi.hip $(CSRC)/spz_ply_kernels.hip $(CSRC)/spz_median.hip
 $(LIBDIR)/libspz_amd.so: $(DEVICE_SRCS) $(CSRC)/spz_common.hpp $(CSRC)/spz_kernel_params.hpp $(INC)/spz_amd.h
 	mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(DEVICE_SRCS)
 
-$(LIBDIR)/libspz_host.so: $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp $(CSRC)/spz_deflate.cpp $(CSRC)/spz_deflate.hpp $(CSRC)/spz_inflate.cpp $(CSRC)/spz_inflate.hpp $(INC)/spz_amd_host.hpp $(INC)/spz_amd.h $(LIBDIR)/libspz_amd.so
+$(LIBDIR)/libspz_host.so: $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp $(CSRC)/spz_deflate.cpp $(CSRC)/spz_deflate.hpp $(CSRC)/spz_inflate.cpp $(CSRC)/spz_inflate.hpp $(CSRC)/spz_host_util.hpp $(INC)/spz_amd_host.hpp $(INC)/spz_amd.h $(LIBDIR)/libspz_amd.so
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp $(CSRC)/spz_deflate.cpp $(CSRC)/spz_inflate.cpp -L$(LIBDIR) -lspz_amd -lz -ldl -lpthread \
 	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
@@ -55,6 +55,12 @@ $(ROOT)spz_amd/bin/spz_tool: $(CSRC)/spz_cli.cpp $(INC)/spz_amd_host.hpp $(LIBDI
 $(ROOT)spz_amd/bin/dropin_user_test: $(ROOT)tests/cpp/dropin_user.cpp $(INC)/compat/load-spz.h $(LIBDIR)/libspz_host.so
 	mkdir -p $(ROOT)spz_amd/bin
 	$(CXX) $(CXXFLAGS) -I$(INC)/compat -o $@ $(ROOT)tests/cpp/dropin_user.cpp -L$(LIBDIR) -lspz_host -lspz_amd \
+	    -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
+
+# The C++ boundary (host vectors in and out) timed without a language binding in the way.
+$(ROOT)spz_amd/bin/host_bench: $(ROOT)tools/host_bench.cpp $(INC)/spz_amd_host.hpp $(LIBDIR)/libspz_host.so
+	mkdir -p $(ROOT)spz_amd/bin
+	$(CXX) $(CXXFLAGS) -o $@ $(ROOT)tools/host_bench.cpp -L$(LIBDIR) -lspz_host -lspz_amd -lpthread \
 	    -Wl,-rpath,'$$ORIGIN/../lib' -Wl,-rpath,/opt/rocm/lib
 
 oracle:

@@ -52,6 +52,20 @@ def parse():
     return ap.parse_args()
 
 
+KERNEL_SOURCES = ("spz_amd/csrc/spz_kernels.hip", "spz_amd/csrc/spz_kernel_params.hpp", "spz_amd/csrc/spz_abi.hip")
+
+
+def kernel_source_sha256():
+    """Hash of the sources that decide the kernels' memory traffic; profiles/pmc_traffic.json carries the hash
+    of the tree its PMC passes ran on, so a traffic figure is only repeated for the kernels it was measured on."""
+    import hashlib
+    h = hashlib.sha256()
+    for rel in KERNEL_SOURCES:
+        with open(os.path.join(ROOT, rel), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
 def algorithmic_bytes_per_point(sh_degree, version):
     """float bytes + packed bytes moved per Gaussian per direction."""
     d = {0: 0, 1: 9, 2: 24, 3: 45}[sh_degree]
@@ -366,12 +380,20 @@ def main():
     if rank == 0:
         bpp = algorithmic_bytes_per_point(deg, ver)
         total_points = n * world
-        traffic = None
+        # roofline.traffic is NOT measured by this run (PMC counters need rocprofv3 around the process): it is the
+        # figure of the committed PMC passes, repeated only when they ran on these same kernel sources and workload
+        traffic, traffic_source = None, {"measured_in_this_run": False, "file": os.path.relpath(args.traffic_file, ROOT)}
         if os.path.exists(args.traffic_file):
             try:
                 with open(args.traffic_file) as f:
                     tj = json.load(f)
-                if tj.get("points") == n and tj.get("sh_degree") == deg:
+                traffic_source.update({"tag": tj.get("tag"), "passes": tj.get("source"),
+                                       "kernel_source_sha256": tj.get("kernel_source_sha256")})
+                same_workload = tj.get("points") == n and tj.get("sh_degree") == deg
+                same_kernels = tj.get("kernel_source_sha256") == kernel_source_sha256()
+                traffic_source["matches_this_workload"] = same_workload
+                traffic_source["matches_current_kernel_sources"] = same_kernels
+                if same_workload and same_kernels:
                     traffic = tj.get("decode_hbm_bytes_per_launch")
             except (OSError, ValueError):
                 traffic = None
@@ -403,7 +425,7 @@ def main():
                 "bound": "hbm", "kernel": "spz_decode_kernel",
                 "achieved": n * bpp / (dec_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": n * bpp / (dec_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS,
-                "traffic": traffic,
+                "traffic": traffic, "traffic_source": traffic_source,
                 "algorithmic_bytes_per_launch": n * bpp, "avg_launch_ms": dec_ms,
             },
             "roofline_encode": {

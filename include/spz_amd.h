@@ -164,18 +164,27 @@ int spz_amd_convert_coordinates_device(float *d_positions, float *d_rotations, f
                                        uint64_t num_points, int sh_degree, int from_coord,
                                        int to_coord, void *hip_stream);
 
-/* ---- host-pointer conveniences: H2D, kernel, D2H on `device`; blocking. ------------------ */
+/* ---- host-pointer entry points: H2D, kernel, D2H on `device`; blocking.  Calls of more than ~96 MB of
+ *      floats run as a pipeline of point-range chunks (upload of chunk k+1, kernel on chunk k and
+ *      download of chunk k-1 overlap; environment SPZ_AMD_HOST_CHUNK_MIB sets the chunk size).  The device
+ *      staging memory is one grow-only allocation per device, kept until spz_amd_release_device_memory().
+ *      spz_amd_decode_host applies the reference reader's 10 M point limit (load-spz.cc:549,561), which
+ *      belongs to deserializePackedGaussians; the _ex form takes the limit (0 = none), for callers that
+ *      mirror unpackGaussians (:467-531), which has none. --------------------------------------------- */
 int spz_amd_encode_host(const spz_amd_cloud_in *h_cloud, uint64_t num_points, int sh_degree,
                         int antialiased, int from_coord, int version, uint8_t *h_stream,
                         size_t capacity, int device);
 int spz_amd_decode_host(const uint8_t *h_stream, size_t size, int to_coord,
                         const spz_amd_cloud_out *h_cloud, int device);
+int spz_amd_decode_host_ex(const uint8_t *h_stream, size_t size, uint64_t max_points, int to_coord,
+                           const spz_amd_cloud_out *h_cloud, int device);
 int spz_amd_convert_coordinates_host(float *h_positions, float *h_rotations, float *h_sh,
                                      uint64_t num_points, int sh_degree, int from_coord,
                                      int to_coord, int device);
 /* Host form of spz_amd_decode_gather_device: the packed stream and the index list are in host memory,
  * the `count` decoded points land in host arrays.  The header is read from the stream with the checks
- * of spz_amd_peek_header_ex(max_points). */
+ * of spz_amd_peek_header_ex(max_points).  Unlike the device form, which clamps, an index >= num_points
+ * is rejected here with SPZ_AMD_ERR_INVALID_ARG before anything is copied. */
 int spz_amd_decode_gather_host(const uint8_t *h_stream, size_t size, uint64_t max_points,
                                const uint32_t *h_indices, uint64_t count, int to_coord,
                                const spz_amd_cloud_out *h_cloud, int device);

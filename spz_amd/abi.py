@@ -38,7 +38,7 @@ EXPORTS = (
     "spz_amd_decode_shard_device", "spz_amd_decode_gather_device", "spz_amd_decode_gather_host",
     "spz_amd_convert_coordinates_device",
     "spz_amd_encode_host",
-    "spz_amd_decode_host", "spz_amd_convert_coordinates_host", "spz_amd_get_tables",
+    "spz_amd_decode_host", "spz_amd_decode_host_ex", "spz_amd_convert_coordinates_host", "spz_amd_get_tables",
     "spz_amd_ply_default_columns", "spz_amd_ply_rows_to_cloud_device", "spz_amd_cloud_to_ply_rows_device",
     "spz_amd_ply_rows_to_cloud_host", "spz_amd_cloud_to_ply_rows_host",
     "spz_amd_median_scale_sum_device", "spz_amd_median_scale_sum_host",
@@ -140,6 +140,8 @@ def bind(L):
     L.spz_amd_encode_host.argtypes = [C.POINTER(CloudPtrs), u64, i32, i32, i32, i32, vp, sz, i32]
     L.spz_amd_decode_host.restype = i32
     L.spz_amd_decode_host.argtypes = [vp, sz, i32, C.POINTER(CloudPtrs), i32]
+    L.spz_amd_decode_host_ex.restype = i32
+    L.spz_amd_decode_host_ex.argtypes = [vp, sz, u64, i32, C.POINTER(CloudPtrs), i32]
     L.spz_amd_convert_coordinates_host.restype = i32
     L.spz_amd_convert_coordinates_host.argtypes = [vp, vp, vp, u64, i32, i32, i32, i32]
     L.spz_amd_get_tables.restype = i32

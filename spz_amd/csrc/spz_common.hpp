@@ -78,23 +78,29 @@ inline int current_device(int *device) {
 }
 
 
-// Device scratch for the *_host entry points.  Small requests are served from one cached
-// allocation per device (grow-only up to kWorkspaceKeep, guarded by a per-device mutex that is held
-// for the duration of the host call), so that the many tiny save/load calls of a typical session do
-// not pay seven hipMalloc/hipFree pairs each; larger requests get a temporary allocation.
-constexpr size_t kWorkspaceKeep = size_t(256) << 20;
-int workspace_acquire(int device, size_t bytes, void **base, bool *temporary);  // locks `device`
-void workspace_release(int device, void *base, bool temporary);                 // unlocks
-void workspace_free_all();                                                      // drops the cached allocations
+// Device scratch for the *_host entry points: ONE grow-only allocation per device, kept between calls
+// (a 10 M-point SH3 save needs 3 GB of it; allocating and freeing that per call cost more than the
+// copies), guarded by a per-device mutex that is held for the duration of the host call and released by
+// spz_amd_release_device_memory().  With it live the two copy streams and the events of the chunked
+// H2D / kernel / D2H pipeline (spz_abi.hip).
+constexpr int kPipeChunksMax = 64;
+struct HostPipe {
+  hipStream_t up = nullptr, down = nullptr;   // uploads + kernels / downloads
+  hipEvent_t *events = nullptr;
+  int n_events = 0;
+};
+int workspace_acquire(int device, size_t bytes, void **base, HostPipe **pipe);  // locks `device`
+void workspace_release(int device);                                              // unlocks
+void workspace_free_all();                                                       // drops the cached allocations
 
 class Workspace {
  public:
   ~Workspace() {
-    if (open_) workspace_release(device_, base_, temporary_);
+    if (open_) workspace_release(device_);
   }
   // Reserves `bytes` (already a sum of aligned() sizes) on the CURRENT device `device`.
   int open(int device, size_t bytes) {
-    int rc = workspace_acquire(device, bytes, &base_, &temporary_);
+    int rc = workspace_acquire(device, bytes, &base_, &pipe_);
     if (rc != SPZ_AMD_OK) return rc;
     device_ = device;
     open_ = true;
@@ -106,12 +112,14 @@ class Workspace {
     used_ += aligned(bytes);
     return p;
   }
+  HostPipe *pipe() const { return pipe_; }
 
  private:
   void *base_ = nullptr;
+  HostPipe *pipe_ = nullptr;
   size_t used_ = 0;
   int device_ = 0;
-  bool temporary_ = false, open_ = false;
+  bool open_ = false;
 };
 
 struct DeviceGuard {

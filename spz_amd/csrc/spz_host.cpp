@@ -23,6 +23,7 @@
 
 #include "spz_amd.h"
 #include "spz_deflate.hpp"
+#include "spz_host_util.hpp"
 #include "spz_inflate.hpp"
 
 namespace spz {
@@ -314,7 +315,7 @@ bool decodeOnePoint(const PackedGaussian &g, uint32_t version, int32_t fractiona
   uint8_t stream[16 + 9 + 1 + 3 + 3 + 4 + 45];
   const size_t size = onePointStream(g, version, fractionalBits, stream);
   spz_amd_cloud_out out = {r->position, r->scale, r->rotation, r->alpha, r->color, r->sh};
-  return !deviceFailed(spz_amd_decode_host(stream, size, to, &out, deviceIndex()), "PackedGaussian::unpack");
+  return !deviceFailed(spz_amd_decode_host_ex(stream, size, 0, to, &out, deviceIndex()), "PackedGaussian::unpack");
 }
 
 }  // namespace
@@ -480,7 +481,9 @@ size_t parseGzipHeader(const uint8_t *p, size_t n, GzipIndex *idx) {
       ++pos;
     }
   }
-  if (flg & 2) pos += 2;  // FHCRC
+  // FHCRC: zlib checks the header CRC16 and rejects a member whose CRC16 is wrong; the fast readers start
+  // behind the header and would not.  The reference writer never sets it, so such members go to zlib.
+  if (flg & 2) return 0;
   return pos + 8 <= n ? pos : 0;
 }
 
@@ -501,7 +504,8 @@ bool inflateIndexed(const uint8_t *p, size_t n, size_t headerLen, const GzipInde
   for (size_t i = 0; i < nb; ++i) off[i + 1] = off[i] + idx.pieceBytes[i];
   if (off[nb] + 8 != n) return false;  // exactly one member, nothing after it
   if (idx.totalBytes > (n - headerLen) * 1032 + 1024) return false;  // beyond deflate's maximum expansion
-  out->resize(idx.totalBytes);
+  out->clear();
+  detail::resizeUninitialized(out, idx.totalBytes);  // every piece is checked to fill its range exactly
   std::vector<uLong> crcs(nb);
   std::atomic<size_t> next{0};
   std::atomic<bool> failed{false};
@@ -573,7 +577,8 @@ bool inflateWholeBuffer(const uint8_t *p, size_t n, std::vector<uint8_t> *out) {
   if (isize == 0 || isize > n * 1032 + 1024) return false;
   void *d = lib.alloc();
   if (!d) return false;
-  out->resize(isize);
+  out->clear();
+  detail::resizeUninitialized(out, isize);  // accepted only when libdeflate wrote all of it (got == isize)
   size_t got = 0;
   const int rc = lib.gunzip(d, p, n, out->data(), out->size(), &got);
   lib.release(d);
@@ -751,6 +756,18 @@ PackedGaussians deserializePackedGaussians(std::istream &in) {
 }
 
 // ---- pack / unpack -------------------------------------------------------------------------------
+namespace {
+// Sizes the six arrays of a cloud that a device copy is about to fill completely.
+void sizeCloudArrays(GaussianCloud *r, size_t n, size_t shDim, detail::Prefault *prefault) {
+  std::vector<float> *arrays[6] = {&r->positions, &r->scales, &r->rotations, &r->alphas, &r->colors, &r->sh};
+  const size_t counts[6] = {n * 3, n * 3, n * 4, n, n * 3, n * shDim * 3};
+  for (int i = 0; i < 6; ++i) {
+    detail::resizeUninitialized(arrays[i], counts[i]);
+    prefault->add(arrays[i]->data(), counts[i] * sizeof(float));
+  }
+}
+}  // namespace
+
 bool packToStream(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream) {
   g_last_status = SPZ_AMD_OK;
   if (!checkSizes(g)) {
@@ -764,7 +781,11 @@ bool packToStream(const GaussianCloud &g, const PackOptions &o, std::vector<uint
   }
   spz_amd_layout lay;
   if (spz_amd_stream_layout(static_cast<uint64_t>(g.numPoints), g.shDegree, 3, &lay) != SPZ_AMD_OK) return false;
-  stream->resize(lay.total_bytes);
+  // every byte of the stream is written by the device copy: no zero fill, pages mapped in the background
+  stream->clear();
+  detail::resizeUninitialized(stream, lay.total_bytes);
+  detail::Prefault prefault;
+  prefault.add(stream->data(), stream->size());
   spz_amd_cloud_in in = {g.positions.data(), g.scales.data(), g.rotations.data(),
                          g.alphas.data(),    g.colors.data(), g.sh.empty() ? nullptr : g.sh.data()};
   const int rc = spz_amd_encode_host(&in, static_cast<uint64_t>(g.numPoints), g.shDegree, g.antialiased ? 1 : 0,
@@ -781,15 +802,12 @@ GaussianCloud unpackFromStream(const uint8_t *stream, size_t size, const UnpackO
   r.shDegree = hdr.sh_degree;
   r.antialiased = (hdr.flags & 1) != 0;
   const size_t n = hdr.num_points;
-  r.positions.resize(n * 3);
-  r.scales.resize(n * 3);
-  r.rotations.resize(n * 4);
-  r.alphas.resize(n);
-  r.colors.resize(n * 3);
-  r.sh.resize(n * dimForDegree(hdr.sh_degree) * 3);
+  detail::Prefault prefault;
+  sizeCloudArrays(&r, n, static_cast<size_t>(dimForDegree(hdr.sh_degree)), &prefault);
   spz_amd_cloud_out out = {r.positions.data(), r.scales.data(), r.rotations.data(),
                            r.alphas.data(),    r.colors.data(), r.sh.empty() ? nullptr : r.sh.data()};
   const int rc = spz_amd_decode_host(stream, size, static_cast<int>(o.to), &out, deviceIndex());
+  prefault.join();
   if (deviceFailed(rc, "decode")) return {};
   return r;
 }
@@ -818,6 +836,8 @@ GaussianCloud unpackGaussians(const PackedGaussians &packed, const UnpackOptions
   h.flags = packed.antialiased ? 1 : 0;
   std::vector<uint8_t> stream(16);
   spz_amd_write_header(&h, stream.data());
+  stream.reserve(16 + packed.positions.size() + packed.alphas.size() + packed.colors.size() + packed.scales.size() +
+                 packed.rotations.size() + packed.sh.size());
   for (const auto *v : {&packed.positions, &packed.alphas, &packed.colors, &packed.scales, &packed.rotations,
                         &packed.sh}) {
     stream.insert(stream.end(), v->begin(), v->end());
@@ -833,16 +853,15 @@ GaussianCloud unpackGaussians(const PackedGaussians &packed, const UnpackOptions
   r.shDegree = packed.shDegree;
   r.antialiased = packed.antialiased;
   const size_t n = static_cast<size_t>(packed.numPoints);
-  r.positions.resize(n * 3);
-  r.scales.resize(n * 3);
-  r.rotations.resize(n * 4);
-  r.alphas.resize(n);
-  r.colors.resize(n * 3);
-  r.sh.resize(n * shDim * 3);
   if (n == 0) return r;
+  detail::Prefault prefault;
+  sizeCloudArrays(&r, n, static_cast<size_t>(shDim), &prefault);
   spz_amd_cloud_out out = {r.positions.data(), r.scales.data(), r.rotations.data(),
                            r.alphas.data(),    r.colors.data(), r.sh.empty() ? nullptr : r.sh.data()};
-  const int rc = spz_amd_decode_host(stream.data(), stream.size(), static_cast<int>(o.to), &out, deviceIndex());
+  // no point limit here: the reference's 10 M cap lives in deserializePackedGaussians (load-spz.cc:549,561),
+  // unpackGaussians (:467-531) has none
+  const int rc = spz_amd_decode_host_ex(stream.data(), stream.size(), 0, static_cast<int>(o.to), &out, deviceIndex());
+  prefault.join();
   if (deviceFailed(rc, "decode")) return {};
   return r;
 }

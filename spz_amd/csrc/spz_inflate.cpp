@@ -15,6 +15,7 @@
 //   5. CRC-32 (parallel, crc32_combine) and ISIZE must match the gzip trailer.
 // Any irregularity returns false and the caller's serial reader decides.
 #include "spz_inflate.hpp"
+#include "spz_host_util.hpp"
 
 #include <zlib.h>
 
@@ -507,7 +508,8 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
   std::vector<uint64_t> offset(n + 1, 0);
   for (size_t j = 0; j < n; ++j) offset[j + 1] = offset[j] + length[j];
   if ((offset[n] & 0xffffffffull) != isize) return false;  // ISIZE is the length modulo 2^32
-  out->resize(static_cast<size_t>(offset[n]));
+  out->clear();
+  detail::resizeUninitialized(out, static_cast<size_t>(offset[n]));  // pass 2 writes every byte; the CRC-32 decides
   std::vector<std::vector<uint8_t>> ctx(n);  // ctx[j] = the W bytes before chunk j + 1's first byte
   for (size_t j = 0; j + 1 < n; ++j) {
     ctx[j].assign(W, 0);

@@ -79,14 +79,17 @@ namespace spz_amd_detail {
 #endif
 // 1: quaternion divisions without the IEEE expansion's operand scaling inside the exponent window where
 // that is exact (spz_kernels.hip, "Correctly rounded divisions ..."); 0: the plain `/` everywhere.
-// 1: the tiles of the sections are dealt out in a repeating pattern (each section gets slots in proportion
-// to its tile count) instead of section after section, so that at any moment the resident blocks are the
-// launch's average mix of arithmetic-heavy (rotations) and traffic-heavy (sh) tiles.
+// Interleaved grid: the tiles of the sections are dealt out in a repeating pattern (each section gets slots in
+// proportion to its tile count) instead of section after section, so that at any moment the resident
+// blocks are the launch's average mix of arithmetic-heavy (rotations) and traffic-heavy (sh) tiles.
+// 0: never, 1: always, 2: by the measured policy (profiles/r02_tune_a_*.jsonl, 10 M points): encode gains
+// without sh (+6 %: the rotation tiles no longer run as one arithmetic-bound phase) and loses with sh3
+// (-4 %); decode gains with sh (+7 % sh3, +16 % sh1) and loses without (-13 %: five equal streams at once).
 #ifndef SPZ_ENC_INTERLEAVE
-#define SPZ_ENC_INTERLEAVE 0
+#define SPZ_ENC_INTERLEAVE 2
 #endif
 #ifndef SPZ_DEC_INTERLEAVE
-#define SPZ_DEC_INTERLEAVE 0
+#define SPZ_DEC_INTERLEAVE 2
 #endif
 #ifndef SPZ_QUAT_FAST
 #define SPZ_QUAT_FAST 1

@@ -23,12 +23,32 @@ static_assert(sizeof(SelectState) <= SPZ_AMD_MEDIAN_WORKSPACE_BYTES, "workspace 
 
 // (s0 + s1) + s2 in f32, left to right like the reference's expression, as an unsigned key whose
 // integer order is the float order (-0.0 sorts directly below +0.0; the volume is the same for both).
-__device__ __forceinline__ uint32_t scale_sum_key(const float *__restrict__ s, uint64_t i) {
-  const float *p = s + 3 * i;
-  float sum = (p[0] + p[1]) + p[2];
+__device__ __forceinline__ uint32_t scale_sum_key(float s0, float s1, float s2) {
+  float sum = (s0 + s1) + s2;
   const uint32_t u = __float_as_uint(sum);
   return u ^ ((u >> 31) ? 0xffffffffu : 0x80000000u);
 }
+
+// h[bin] += 1 for every lane with `valid`, without the same-address serialisation of 64 LDS atomics: real
+// scale sums put most of a wave into two or three bins of the first pass (sign + exponent bits).  Up to four
+// rounds of "take the first pending lane's bin, count the lanes that share it with one ballot, one lane adds
+// the count"; lanes still pending after that are spread over many bins and add for themselves.
+__device__ __forceinline__ void wave_histogram_add(uint32_t *h, uint32_t bin, bool valid) {
+  unsigned long long todo = __ballot(valid);
+#pragma unroll 1
+  for (int round = 0; round < 4 && todo != 0ull; ++round) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const uint32_t b = (uint32_t)__shfl((int)bin, leader, 64);
+    const bool mine = valid && bin == b;
+    const unsigned long long same = __ballot(mine);
+    if ((int)(threadIdx.x & 63u) == leader) atomicAdd(&h[b], (uint32_t)__popcll(same));
+    valid = valid && !mine;
+    todo &= ~same;
+  }
+  if (valid) atomicAdd(&h[bin], 1u);
+}
+
+constexpr int kSelectPointsPerThread = 4;  // 12 floats = three 16-byte loads per lane, 3 KiB contiguous per wave
 
 __global__ __launch_bounds__(256) void spz_select_hist_kernel(const float *__restrict__ scales, uint64_t n,
                                                               SelectState *__restrict__ st, int pass) {
@@ -37,9 +57,26 @@ __global__ __launch_bounds__(256) void spz_select_hist_kernel(const float *__res
   __syncthreads();
   const uint32_t prefix = st->prefix, mask = st->mask;
   const int shift = 24 - 8 * pass;
-  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
-    const uint32_t key = scale_sum_key(scales, i);
-    if ((key & mask) == prefix) atomicAdd(&h[(key >> shift) & 255u], 1u);
+  const uint64_t stride = (uint64_t)gridDim.x * 256 * kSelectPointsPerThread;
+  const uint64_t n_round = (n + stride - 1) / stride * stride;  // every lane of a wave makes the same number of trips
+  for (uint64_t i = ((uint64_t)blockIdx.x * 256 + threadIdx.x) * kSelectPointsPerThread; i < n_round; i += stride) {
+    float v[3 * kSelectPointsPerThread];
+    if (i + kSelectPointsPerThread <= n) {
+      const F32x4 *q = reinterpret_cast<const F32x4 *>(scales + 3 * i);
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const F32x4 t = q[r];
+        v[4 * r + 0] = t.x; v[4 * r + 1] = t.y; v[4 * r + 2] = t.z; v[4 * r + 3] = t.w;
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < 3 * kSelectPointsPerThread; ++r) v[r] = (3 * i + r < 3 * n) ? scales[3 * i + r] : 0.0f;
+    }
+#pragma unroll
+    for (int r = 0; r < kSelectPointsPerThread; ++r) {
+      const uint32_t key = scale_sum_key(v[3 * r], v[3 * r + 1], v[3 * r + 2]);
+      wave_histogram_add(h, (key >> shift) & 255u, i + r < n && (key & mask) == prefix);
+    }
   }
   __syncthreads();
   if (h[threadIdx.x]) atomicAdd(&st->hist[pass][threadIdx.x], h[threadIdx.x]);
@@ -99,8 +136,10 @@ int spz_amd_median_scale_sum_device(const float *d_scales, uint64_t num_points, 
   SelectState *st = static_cast<SelectState *>(d_workspace);
   SPZ_HIP_TRY(hipMemsetAsync(st, 0, sizeof(SelectState), s));
   const uint32_t k = (uint32_t)(num_points / 2);  // rank size/2 of the sorted sums (splat-types.h:182)
-  unsigned long long blocks = (num_points + 255) / 256;
-  if (blocks > 8192) blocks = 8192;  // grid-stride beyond 2 M points: 32 blocks per CU
+  // 1024 points per block and trip; at most 4 blocks per CU, so that the per-block flush into the 256 global
+  // bins stays at ~1000 adds per bin
+  unsigned long long blocks = (num_points + 256 * kSelectPointsPerThread - 1) / (256 * kSelectPointsPerThread);
+  if (blocks > 1024) blocks = 1024;
   for (int pass = 0; pass < 4; ++pass) {
     hipLaunchKernelGGL(spz_select_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d_scales, num_points, st, pass);
     hipLaunchKernelGGL(spz_select_pick_kernel, dim3(1), dim3(64), 0, s, st, pass, k, d_median);

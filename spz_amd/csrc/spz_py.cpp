@@ -313,6 +313,12 @@ PYBIND11_MODULE(spz, m) {
     return g;
   }, py::arg("data"), py::arg("indices"), py::arg("options") = spz::UnpackOptions(), py::arg("gzipped") = true,
      "unpackIndices(loadSpzPacked(data), indices, options): one gather launch.");
+  m.def("_unpack_from_stream", [](const py::bytes &data, const spz::UnpackOptions &o) {
+    const std::string in = data;
+    spz::GaussianCloud g = spz::unpackFromStream(reinterpret_cast<const uint8_t *>(in.data()), in.size(), o);
+    if (g.numPoints == 0) raiseIfDeviceUnusable();
+    return g;
+  }, py::arg("data"), py::arg("options") = spz::UnpackOptions(), "Cloud of a raw (pre-gzip) stream: loadSpz without the gunzip step.");
   m.def("_pack_to_stream", [](const spz::GaussianCloud &g, const spz::PackOptions &o) -> py::object {
     std::vector<uint8_t> out;
     if (!spz::packToStream(g, o, &out)) {

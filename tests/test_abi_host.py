@@ -146,6 +146,26 @@ def test_compute_entry_points_fail_loudly_without_a_gpu(lib):
     assert lib.spz_amd_device_count() == 0
 
 
+def test_ten_million_point_cap_sits_where_the_reference_has_it(lib):
+    """The 10 M limit belongs to deserializePackedGaussians (load-spz.cc:549,561): spz_amd_decode_host (the
+    loadSpz route) applies it, spz_amd_decode_host_ex(max_points=0) (the unpackGaussians route, :467-531,
+    which has no limit) does not.  Status codes only: a size-consistent 11 M-point SH0 header."""
+    import torch
+    from spz_amd import abi
+    n = 11_000_000
+    size = abi.stream_layout(n, 0, 3).total_bytes
+    stream = np.zeros(size, np.uint8)             # untouched pages: costs nothing until read
+    stream[:16] = np.frombuffer(abi.write_header(3, n, 0), np.uint8)
+    out = [np.zeros(1, np.float32) for _ in range(5)]
+    p = abi.CloudPtrs(*[a.ctypes.data for a in out], None)
+    assert lib.spz_amd_decode_host(stream.ctypes.data, size, 0, C.byref(p), 0) == abi.ERR_TOO_MANY_POINTS
+    assert lib.spz_amd_decode_host_ex(stream.ctypes.data, size, 10_999_999, 0, C.byref(p), 0) == abi.ERR_TOO_MANY_POINTS
+    if not torch.cuda.is_available():
+        # past the header checks and the argument checks; the device is what is missing
+        assert lib.spz_amd_decode_host_ex(stream.ctypes.data, size, 0, 0, C.byref(p), 0) == abi.ERR_NO_DEVICE
+        assert lib.spz_amd_decode_host_ex(stream.ctypes.data, size - 1, 0, 0, C.byref(p), 0) == abi.ERR_SHORT_STREAM
+
+
 def test_python_module_raises_without_a_gpu():
     import torch
     import spz_amd.spz as spz
@@ -224,6 +244,9 @@ def test_argument_validation_happens_before_any_device_work(lib):
     assert gat(cnt=0) == abi.OK
     assert gat(ind=None) == abi.ERR_INVALID_ARG
     assert gat(cloud=no_sh) == abi.ERR_INVALID_ARG
+    # an index past the end is an argument error of the host form (the device form clamps, as documented)
+    bad_idx = np.array([0, n], np.uint32)
+    assert gat(ind=bad_idx.ctypes.data) == abi.ERR_INVALID_ARG
     # median selection: arguments first
     one = np.zeros(3, np.float32)
     res = np.zeros(1, np.float32)

@@ -250,10 +250,10 @@ def test_fast_divisions_exhaustive(dev):
     2^32 hashed operand pairs, and the whole encoders / the v3 decoder fast-vs-general (2^31 hashed
     quaternions, all 2^32 rotation words)."""
     top = 0x7f800000 + 1
-    for mode, name in ((0, "x / sqrt1_2"), (1, "x / 511"), (2, "sqrt")):
+    for mode, name, exps in ((0, "x / sqrt1_2", 226), (1, "x / 511", 226), (2, "sqrt", 162)):
         bad, first, seen = _selftest(mode, 0, top)
         assert bad == 0, f"{name}: {bad} floats differ, first bit pattern {first:#010x}"
-        assert seen > (200 << 23), f"{name}: only {seen} inputs were inside the window"
+        assert seen >= (exps << 23), f"{name}: only {seen} inputs were inside the window"
     for mode, name, count in ((3, "x / norm", 1 << 32), (4, "smallest-three encoder", 1 << 31),
                               (5, "first-three encoder", 1 << 30), (6, "smallest-three decoder", 1 << 35)):
         bad, first, seen = _selftest(mode, 0, count)
@@ -382,6 +382,58 @@ def test_host_pointer_entry_points(dev, oracle):
     rc, w = oracle.unpack(want, 7)
     for k in FIELDS:
         assert_bits_equal(u[k], w[k], f"decode_host {k}")
+
+
+def test_host_pipeline_of_several_chunks(dev, oracle):
+    """A host-pointer call big enough to run as a pipeline of point-range chunks (upload k+1 | kernel k |
+    download k-1 on two streams and two host threads): 1.3 M + 7 SH3 Gaussians = 4 chunks of 96 MB, the last
+    one ragged.  Bytes and floats equal the oracle's over the whole cloud; the C++ layer on top (fresh,
+    not zero-filled vectors; pages mapped in the background) returns the same; a 16 M-point SH0 stream
+    decodes through the unpackGaussians route although it is past the reference reader's 10 M cap."""
+    import spz_amd.spz as spz
+    from spz_amd import abi
+    from spz_amd.synth import make_cloud_numpy
+    L = abi.load_library()
+    n, deg = 1_300_007, 3
+    c = make_cloud_numpy(n, deg, 62)
+    lay = abi.stream_layout(n, deg, 3)
+    out = np.full(lay.total_bytes, 0xa5, np.uint8)
+    p = abi.CloudPtrs(*[c[k].ctypes.data for k in FIELDS])
+    abi.check(L.spz_amd_encode_host(C.byref(p), n, deg, 1, 6, 3, out.ctypes.data, out.size, 0), "encode_host")
+    want = oracle.pack(c, n, deg, True, 6)
+    assert_bytes_equal(out, want, "encode_host, 4 chunks")
+    u = {k: np.full_like(c[k], np.nan) for k in FIELDS}
+    q = abi.CloudPtrs(*[u[k].ctypes.data for k in FIELDS])
+    abi.check(L.spz_amd_decode_host(out.ctypes.data, out.size, 7, C.byref(q), 0), "decode_host")
+    rc, w = oracle.unpack(want, 7)
+    for k in FIELDS:
+        assert_bits_equal(u[k], w[k], f"decode_host, 4 chunks: {k}")
+    g = spz.GaussianCloud()
+    g.sh_degree = deg
+    g.antialiased = True
+    for k in FIELDS:
+        setattr(g, k, c[k])
+    o = spz.PackOptions()
+    o.from_coord = spz.RDF
+    raw = spz._pack_to_stream(g, o)
+    assert_bytes_equal(np.frombuffer(raw, np.uint8), want, "packToStream, 4 chunks")
+    uo = spz.UnpackOptions()
+    uo.to_coord = spz.LUF
+    back = spz._unpack_from_stream(raw, uo)
+    assert back.num_points == n and back.sh_degree == deg and back.antialiased
+    for k in FIELDS:
+        assert_bits_equal(np.asarray(getattr(back, k)), w[k], f"unpackFromStream, 4 chunks: {k}")
+    # no point limit on the unpackGaussians route (load-spz.cc:467-531); the loadSpz route keeps the reader's cap
+    m = 16_000_000
+    big = np.zeros(abi.stream_layout(m, 0, 3).total_bytes, np.uint8)
+    big[:16] = np.frombuffer(abi.write_header(3, m, 0), np.uint8)
+    big[16 + 16 * m:16 + 20 * m].view(np.uint32)[:] = 0xc0000000       # identity rotations
+    u0 = {k: np.empty(m * f, np.float32) for k, f in (("positions", 3), ("scales", 3), ("rotations", 4), ("alphas", 1), ("colors", 3))}
+    q0 = abi.CloudPtrs(*[u0[k].ctypes.data for k in ("positions", "scales", "rotations", "alphas", "colors")], None)
+    assert L.spz_amd_decode_host(big.ctypes.data, big.size, 0, C.byref(q0), 0) == abi.ERR_TOO_MANY_POINTS
+    abi.check(L.spz_amd_decode_host_ex(big.ctypes.data, big.size, 0, 0, C.byref(q0), 0), "decode_host_ex")
+    assert np.array_equal(u0["rotations"].reshape(-1, 4)[[0, m // 2, m - 1]], np.float32([[0, 0, 0, 1]] * 3))
+    assert np.all(u0["scales"][[0, 3 * m - 1]] == -10.0) and np.all(np.isneginf(u0["alphas"][[0, m - 1]]))
 
 
 def test_error_codes_on_device_entry_points(dev):

@@ -136,12 +136,20 @@ def test_gunzip_readers_agree_with_zlib(reference):
     hdr += b"scene.bin\0" + b"a comment\0"
     hdr += (zlib.crc32(bytes(hdr)) & 0xffff).to_bytes(2, "little")
     cases["fname_fcomment_fhcrc"] = bytes(hdr) + body
+    bad_hcrc = bytearray(cases["fname_fcomment_fhcrc"]); bad_hcrc[len(hdr) - 1] ^= 0x5a   # zlib rejects a wrong header CRC16
+    hdr2 = bytearray(one[:10]); hdr2[3] = 0x02
+    hdr2 += (zlib.crc32(bytes(hdr2)) & 0xffff).to_bytes(2, "little")
+    cases["fhcrc_only"] = bytes(hdr2) + body
     # damaged index: a piece size off by one, an impossible block size, a wrong total
     for name, at, val in (("index_piece", 16 + 20, 1), ("index_block", 16 + 4, 0x40), ("index_total", 16 + 8, 3)):
         b = bytearray(par); b[at] ^= val
         cases[name] = bytes(b)
     for name, b in list(cases.items()):
         assert zlib_verdict(b) == raw, name
+    cases["fhcrc_wrong"] = bytes(bad_hcrc)
+    assert zlib_verdict(cases["fhcrc_wrong"]) is None
+    b = bytearray(cases["fhcrc_only"]); b[10] ^= 1
+    cases["fhcrc_only_wrong"] = bytes(b)
     mid = bytearray(par); mid[len(mid) // 2] ^= 0x10
     cases["corrupt_indexed"] = bytes(mid)
     mid = bytearray(one); mid[len(mid) // 2] ^= 0x10

@@ -100,7 +100,10 @@ def main():
         json.dump(summary, f, indent=1)
     if "spz_decode_kernel" in traffic and "hbm_bytes_per_launch" in traffic["spz_decode_kernel"]:
         with open(os.path.join(out_dir, "pmc_traffic.json"), "w") as f:
+            sys.path.insert(0, ROOT)
+            from bench import kernel_source_sha256
             json.dump({"tag": a.tag, "points": a.points, "sh_degree": a.sh_degree,
+                       "kernel_source_sha256": kernel_source_sha256(),
                        "decode_hbm_bytes_per_launch": traffic["spz_decode_kernel"]["hbm_bytes_per_launch"],
                        "encode_hbm_bytes_per_launch": traffic.get("spz_encode_kernel", {}).get("hbm_bytes_per_launch"),
                        "source": f"profiles/{a.tag}_summary.json"}, f, indent=1)

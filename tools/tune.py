@@ -27,19 +27,19 @@ def D(block=256, unroll=4, wc=0, ntl=0, nts=0):
 # Round-2 experiments (the round-1 geometry / non-temporal / reverse-order tables are in git history and
 # profiles/r01_tune_*.jsonl).  Every variant is the shipped configuration plus the listed macros.
 VARIANTS = {
-    "quat_ieee": {"enc": "plain IEEE divisions in the quaternion code", "dec": "same", "defs": {"SPZ_QUAT_FAST": 0}},
-    "quat_fast": {"enc": "shipped (fast exact divisions)", "dec": "same", "defs": {"SPZ_QUAT_FAST": 1}},
-    "il_enc": {"enc": "sections interleaved", "dec": "shipped", "defs": {"SPZ_ENC_INTERLEAVE": 1}},
+    "quat_ieee": {"enc": "plain IEEE divisions, no interleave", "dec": "same",
+                  "defs": {"SPZ_QUAT_FAST": 0, "SPZ_ENC_INTERLEAVE": 0, "SPZ_DEC_INTERLEAVE": 0}},
+    "quat_fast": {"enc": "fast exact divisions, no interleave", "dec": "same",
+                  "defs": {"SPZ_ENC_INTERLEAVE": 0, "SPZ_DEC_INTERLEAVE": 0}},
+    "il_enc": {"enc": "sections interleaved", "dec": "sequential", "defs": {"SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 0}},
+    "il_dec": {"enc": "sequential", "dec": "sections interleaved", "defs": {"SPZ_ENC_INTERLEAVE": 0, "SPZ_DEC_INTERLEAVE": 1}},
     "il_both": {"enc": "sections interleaved", "dec": "sections interleaved",
                 "defs": {"SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 1}},
-    "il_ieee": {"enc": "sections interleaved, IEEE divisions", "dec": "interleaved, IEEE",
-                "defs": {"SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 1, "SPZ_QUAT_FAST": 0}},
-    "u2": {"enc": "256 x 2 units", "dec": "256 x 2 units", "defs": {"SPZ_ENC_UNROLL": 2, "SPZ_DEC_UNROLL": 2}},
-    "u1": {"enc": "256 x 1 unit", "dec": "256 x 1 unit", "defs": {"SPZ_ENC_UNROLL": 1, "SPZ_DEC_UNROLL": 1}},
-    "u8": {"enc": "256 x 8 units", "dec": "256 x 8 units", "defs": {"SPZ_ENC_UNROLL": 8, "SPZ_DEC_UNROLL": 8}},
-    "u2_il": {"enc": "256 x 2, interleaved", "dec": "256 x 2, interleaved",
-              "defs": {"SPZ_ENC_UNROLL": 2, "SPZ_DEC_UNROLL": 2, "SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 1}},
-    "quat_fast_b": {"enc": "shipped, second copy (noise floor)", "dec": "same", "defs": {"SPZ_QUAT_FAST": 1}},
+    "policy": {"enc": "shipped: interleave by policy", "dec": "same", "defs": {}},
+    "u8_policy": {"enc": "256 x 8 units, policy", "dec": "256 x 8 units, policy", "defs": {"SPZ_ENC_UNROLL": 8, "SPZ_DEC_UNROLL": 8}},
+    "u8_il_dec": {"enc": "256 x 8, sequential", "dec": "256 x 8, interleaved",
+                  "defs": {"SPZ_ENC_UNROLL": 8, "SPZ_DEC_UNROLL": 8, "SPZ_ENC_INTERLEAVE": 0, "SPZ_DEC_INTERLEAVE": 1}},
+    "policy_b": {"enc": "shipped, second copy (noise floor)", "dec": "same", "defs": {}},
 }
 
 
@@ -56,7 +56,7 @@ def build(names):
         subprocess.run(cmd, check=True)
 
 
-def run(points, rounds, names, deg=3, version=3):
+def run(points, rounds, names, deg=3, version=3, batch=1):
     import statistics
 
     import torch
@@ -111,10 +111,18 @@ def run(points, rounds, names, deg=3, version=3):
         for name, L in libs.items():
             e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
             enc(L); dec(L)   # untimed: puts the caches in this pair's own steady state
-            e[0].record(); enc(L); e[1].record(); dec(L); e[2].record()
+            # batch > 1 (short kernels): `batch` launches back to back per timed region, so that the figure is the
+            # device's rate and not the host's launch latency in front of a single 20 us kernel
+            e[0].record()
+            for _b in range(batch):
+                enc(L)
+            e[1].record()
+            for _b in range(batch):
+                dec(L)
+            e[2].record()
             torch.cuda.synchronize()
-            times[name]["enc"].append(e[0].elapsed_time(e[1]))
-            times[name]["dec"].append(e[1].elapsed_time(e[2]))
+            times[name]["enc"].append(e[0].elapsed_time(e[1]) / batch)
+            times[name]["dec"].append(e[1].elapsed_time(e[2]) / batch)
             scrub.fill_(1)
             c = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
             c[0].record(); dec(L); c[1].record()
@@ -124,7 +132,7 @@ def run(points, rounds, names, deg=3, version=3):
     gb = points * bpp / 1e9
     rows = []
     for name in libs:
-        r = {"variant": name, "points": points, "sh_degree": deg, "version": version,
+        r = {"variant": name, "points": points, "sh_degree": deg, "version": version, "launches_per_timed_region": batch,
              "enc_cfg": VARIANTS[name]["enc"], "dec_cfg": VARIANTS[name]["dec"]}
         for k in ("enc", "dec", "dec_cold"):
             med, mn = statistics.median(times[name][k]), min(times[name][k])
@@ -146,10 +154,11 @@ if __name__ == "__main__":
     ap.add_argument("--rounds", type=int, default=15)
     ap.add_argument("--deg", type=int, default=3)
     ap.add_argument("--version", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=1)
     ap.add_argument("--variants", default=",".join(VARIANTS))
     a = ap.parse_args()
     names = [v for v in a.variants.split(",") if v]
     if a.mode == "build":
         build(names)
     else:
-        run(a.points, a.rounds, names, a.deg, a.version)
+        run(a.points, a.rounds, names, a.deg, a.version, a.batch)
