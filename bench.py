@@ -46,6 +46,11 @@ def parse():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl = RCCL over xGMI (the measured configuration); gloo = rehearsal of the N>1 code path "
                          "on a box with fewer GPUs than ranks (host-staged exchange, ranks may share a GPU)")
+    ap.add_argument("--route", default="auto", choices=["auto", "rccl", "torch", "ipc"],
+                    help="N>1 exchange: rccl = spz_amd_gatherv_rccl (native: one ncclGroupStart/End, small sections sent "
+                         "while sh is still encoding); torch = torch.distributed batch_isend_irecv; ipc = peers encode "
+                         "straight into the root's stream over an IPC mapping.  auto = rccl on the nccl backend "
+                         "(falls back to torch if the communicator cannot be made), torch on gloo")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-points", type=int, default=0, help="0 = the whole per-GPU workload")
     ap.add_argument("--traffic-file", default=os.path.join(ROOT, "profiles", "pmc_traffic.json"))
@@ -230,7 +235,10 @@ def main():
     streams = [torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     stream = streams[0]
     global_streams = [None] * nbuf
-    if use_coll and rank == 0:
+    route = None
+    if use_coll:
+        route = args.route if args.route != "auto" else ("rccl" if args.backend == "nccl" else "torch")
+    if use_coll and rank == 0 and route != "ipc":
         for b in range(nbuf):
             global_streams[b] = torch.empty(plan.layout.total_bytes, dtype=torch.uint8, device=dev)
             shard.write_global_header(global_streams[b], plan)
@@ -238,12 +246,57 @@ def main():
     K, W = args.steps, args.warmup
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(4)] for _ in range(K)]
 
-    if use_coll and rank == 0:
+    # ---- the exchange route ----------------------------------------------------------------------------
+    route_note = None
+    gx, comm_stream, ipcs = None, None, None
+    if use_coll:
+        if route == "rccl":
+            err = None
+            try:
+                gx = shard.RcclGather(plan, rank)
+            except (RuntimeError, OSError) as e:   # no RCCL / communicator refused (e.g. ranks sharing a GPU)
+                err = str(e)
+            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 0:
+                if gx is not None:
+                    gx.close()
+                gx, route = None, "torch"
+                route_note = f"native RCCL route unavailable ({err or 'another rank failed'}): fell back to torch.distributed"
+            else:
+                comm_stream = torch.cuda.Stream(device=dev)
+        if route == "ipc":
+            ipcs = [shard.IpcGlobalStream(plan, rank) for _ in range(nbuf)]
+            if rank == 0:
+                for b in range(nbuf):
+                    shard.write_global_header(ipcs[b].raw.tensor(dev), plan)
+                    global_streams[b] = ipcs[b].raw.tensor(dev)
+    ghdr = D.make_header(plan.num_points, deg, ver) if use_coll else None
+    ev_small = [torch.cuda.Event() for _ in range(nbuf)]
+    ev_sh = [torch.cuda.Event() for _ in range(nbuf)]
+    done_ev = [None] * nbuf
+
+    if route == "ipc":
+        # every rank encodes its shard straight into the root's stream (the kernel's stores ARE the exchange) and
+        # decodes its fragments from there; a peer's decode therefore reads them back over xGMI
+        views = [ipcs[b].raw.tensor(dev) for b in range(nbuf)]
+        run_encode = lambda b: D.encode_shard(cloud, plan.first[rank], n, plan.num_points, deg, ipcs[b].raw,
+                                              from_coord=frm, version=ver, write_header=(rank == 0))
+        run_decode = lambda b: D.decode_shard(views[b], ghdr, plan.first[rank], n, to, out=out)
+    elif use_coll and rank == 0:
         # the root encodes straight into (and decodes straight from) its slot of the global stream
-        ghdr = D.make_header(plan.num_points, deg, ver)
         run_encode = lambda b: D.encode_shard(cloud, plan.first[0], n, plan.num_points, deg, global_streams[b],
                                               from_coord=frm, version=ver, write_header=True)
         run_decode = lambda b: D.decode_shard(global_streams[b], ghdr, plan.first[0], n, to, out=out)
+    elif route == "rccl":
+        def run_encode(b):
+            # the five small sections first (20 B/point): their fragments travel while the sh section (45 B/point) encodes
+            D.encode_shard(cloud, 0, n, n, deg, streams[b], from_coord=frm, version=ver, write_header=True,
+                           section_mask=abi.SMALL_SECTIONS)
+            ev_small[b].record()
+            D.encode_shard(cloud, 0, n, n, deg, streams[b], from_coord=frm, version=ver, section_mask=abi.SH_SECTION)
+            ev_sh[b].record()
+        run_decode = lambda b: D.decode(streams[b], hdr, to, out=out)
     else:
         run_encode = lambda b: D.encode(cloud, n, deg, False, frm, ver, out=streams[b])
         run_decode = lambda b: D.decode(streams[b], hdr, to, out=out)
@@ -255,6 +308,24 @@ def main():
         for w in pending[b]:
             w.wait()       # RCCL: the current stream waits for the gatherv that last used buffer b
         pending[b] = []
+        if done_ev[b] is not None:
+            torch.cuda.current_stream().wait_event(done_ev[b])
+            done_ev[b] = None
+
+    def exchange(b):
+        if route == "torch":
+            pending[b] = shard.gather_stream(None if rank == 0 else streams[b], plan, rank, global_streams[b],
+                                             async_op=True)
+        elif route == "rccl":
+            local = None if rank == 0 else streams[b]
+            if rank != 0:
+                comm_stream.wait_event(ev_small[b])
+            gx.gather(local, global_streams[b], abi.SMALL_SECTIONS, stream=comm_stream)
+            if rank != 0:
+                comm_stream.wait_event(ev_sh[b])
+            gx.gather(local, global_streams[b], abi.SH_SECTION, stream=comm_stream)
+            done_ev[b] = torch.cuda.Event()
+            done_ev[b].record(comm_stream)
 
     def step(k, timed):
         b = counter[0] % nbuf
@@ -265,8 +336,7 @@ def main():
         run_encode(b)
         if e: e[1].record()
         if use_coll:
-            pending[b] = shard.gather_stream(None if rank == 0 else streams[b], plan, rank, global_streams[b],
-                                             async_op=True)
+            exchange(b)
         if e: e[2].record()
         run_decode(b)
         if e: e[3].record()
@@ -291,6 +361,9 @@ def main():
         last = step(0, False)     # one more untimed step whose buffers are then checked
         fence()
         global_stream = global_streams[last]
+        if route == "ipc" and rank != 0:   # what this rank's bytes must be: its shard encoded once more, locally
+            D.encode(cloud, n, deg, False, frm, ver, out=streams[last])
+            torch.cuda.synchronize()
         src_buf = global_stream if rank == 0 else streams[last]
         mine = torch.stack([src_buf[(g if rank == 0 else l):(g if rank == 0 else l) + nb].sum(dtype=torch.int64)
                             for g, l, nb in plan.fragments(rank)])
@@ -416,9 +489,13 @@ def main():
                             f"+ decode to={args.to_coord} with the coordinate flips fused, inputs resident in HBM",
                 "points_per_gpu": n, "sh_degree": deg, "version": ver,
                 "parallelism": ("single GPU" if world == 1 else
-                                f"point-range shards x{world}" + (", one grouped RCCL gatherv of the byte stream to "
-                                                                   "rank 0 per step, double-buffered: it overlaps the kernels of the next steps"
-                                                                   if use_coll else ", no collective") +
+                                f"point-range shards x{world}" + ({
+                                    "rccl": ", gatherv of the byte stream to rank 0 by spz_amd_gatherv_rccl (one ncclGroupStart/End "
+                                            "per section group, the small sections sent while sh encodes), double-buffered",
+                                    "torch": ", one grouped gatherv of the byte stream to rank 0 per step "
+                                             "(torch.distributed batch_isend_irecv), double-buffered",
+                                    "ipc": ", peers encode straight into rank 0's stream over an IPC mapping (no second pass)",
+                                }[route] if use_coll else ", no collective") +
                                 ("" if args.backend == "nccl" else " [REHEARSAL: gloo backend, host-staged, not a measurement]")),
             },
             "roofline": {
@@ -438,6 +515,7 @@ def main():
             "decode_gaussians_per_s_per_gpu": n / (dec_ms * 1e-3),
             "reencode_fixed_point": fixed_point,
             "gather_verified": gather_verified,
+            "exchange_route": route, "exchange_route_note": route_note,
             "shards_only": shards_only,
             "config4_fused_vs_two_pass": two_pass,
         }
@@ -465,7 +543,22 @@ def main():
                                                gpu_decoded_bit_sums_fn)
         print(json.dumps(res), flush=True)
     if distributed:
+        torch.cuda.synchronize()
         dist.barrier()
+        if gx is not None:
+            gx.close()
+        if ipcs is not None:
+            if rank == 0:
+                global_streams[:] = [None] * nbuf
+            views = None
+            dist.barrier()               # no peer may still have the root's buffer in use
+            for i in ipcs:
+                if rank != 0:
+                    i.close()
+            dist.barrier()
+            for i in ipcs:
+                if rank == 0:
+                    i.close()
         dist.destroy_process_group()
 
 

@@ -49,7 +49,8 @@ enum {
   SPZ_AMD_ERR_CAPACITY = -7,        /* output buffer too small */
   SPZ_AMD_ERR_NO_DEVICE = -8,       /* no usable HIP device / runtime */
   SPZ_AMD_ERR_HIP = -9,             /* a HIP call failed (see spz_amd_last_hip_error) */
-  SPZ_AMD_ERR_UNSUPPORTED = -10     /* e.g. encode of version 1 */
+  SPZ_AMD_ERR_UNSUPPORTED = -10,    /* e.g. encode of version 1; RCCL not loadable */
+  SPZ_AMD_ERR_COMM = -11            /* an RCCL call failed (see spz_amd_last_rccl_error) */
 };
 
 /* CoordinateSystem values, splat-types.h:24-34. */
@@ -148,6 +149,51 @@ int spz_amd_encode_shard_device(const spz_amd_cloud_in *d_cloud, uint64_t first,
 int spz_amd_decode_shard_device(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr,
                                 uint64_t first, uint64_t count, int to_coord,
                                 const spz_amd_cloud_out *d_cloud, void *hip_stream);
+
+/* Same as spz_amd_encode_shard_device for a subset of the sections: bit s of section_mask selects section s
+ * (SPZ_AMD_SEC_*).  Lets a multi-GPU caller encode the five small sections (20 B/point), hand their
+ * fragments to the exchange, and encode the sh section (up to 45 B/point) while they travel. */
+int spz_amd_encode_shard_sections_device(const spz_amd_cloud_in *d_cloud, uint64_t first, uint64_t count,
+                                         uint64_t num_points_total, int sh_degree, int antialiased,
+                                         int from_coord, int version, int write_header, unsigned section_mask,
+                                         uint8_t *d_stream, size_t capacity, void *hip_stream);
+
+/* ---- the exchange step of the multi-GPU path: the stream of R point-range shards lands on one
+ *      device.  spz_amd_shard_fragments gives the six byte ranges of a shard: where they sit in the full
+ *      stream (global_offset) and in a stream that holds the shard alone (local_offset).
+ *
+ *      RCCL route: spz_amd_gatherv_rccl issues ONE ncclGroupStart/End with the six ncclSend of every
+ *      non-root rank matched by ncclRecv on the root straight at the final offsets (RCCL has no gatherv).
+ *      comm is an ncclComm_t the caller owns (spz_amd_rccl_comm_init wraps ncclCommInitRank for callers that
+ *      have none; the 128-byte id comes from spz_amd_rccl_unique_id on one rank and travels by any means).
+ *      first[r], count[r]: the contiguous point ranges in rank order.  d_local_stream: this rank's own
+ *      stream (header + its fragments); the root passes NULL when it encoded straight into
+ *      d_global_stream (spz_amd_encode_shard_device).  Enqueued on hip_stream, no synchronisation.
+ *      RCCL is looked up at run time (dlopen): SPZ_AMD_ERR_UNSUPPORTED when it cannot be found.
+ *
+ *      IPC route: the root allocates the stream with spz_amd_ipc_alloc and passes the 64-byte handle to its
+ *      peers (same node); a peer maps it with spz_amd_ipc_open and hands the mapped pointer to
+ *      spz_amd_encode_shard_device as d_stream: the encode kernel's stores write the fragments into the
+ *      root's memory over xGMI, no second pass.  The root may read after the peer's stream has completed. -- */
+typedef struct {
+  uint64_t global_offset[SPZ_AMD_NUM_SECTIONS], local_offset[SPZ_AMD_NUM_SECTIONS], bytes[SPZ_AMD_NUM_SECTIONS];
+} spz_amd_fragments;
+int spz_amd_shard_fragments(uint64_t first, uint64_t count, uint64_t num_points_total, int sh_degree, int version,
+                            spz_amd_fragments *out);
+#define SPZ_AMD_RCCL_UNIQUE_ID_BYTES 128
+int spz_amd_rccl_available(void);
+int spz_amd_last_rccl_error(void); /* ncclResult_t of the last failing RCCL call on this thread */
+int spz_amd_rccl_unique_id(uint8_t id[SPZ_AMD_RCCL_UNIQUE_ID_BYTES]);
+int spz_amd_rccl_comm_init(const uint8_t id[SPZ_AMD_RCCL_UNIQUE_ID_BYTES], int world, int rank, void **comm);
+int spz_amd_rccl_comm_destroy(void *comm);
+int spz_amd_gatherv_rccl(void *comm, int rank, int world, int root, const uint64_t *first, const uint64_t *count,
+                         int sh_degree, int version, const uint8_t *d_local_stream, uint8_t *d_global_stream,
+                         unsigned section_mask, void *hip_stream);
+#define SPZ_AMD_IPC_HANDLE_BYTES 64
+int spz_amd_ipc_alloc(size_t bytes, void **d_ptr, uint8_t handle[SPZ_AMD_IPC_HANDLE_BYTES]);
+int spz_amd_ipc_free(void *d_ptr);
+int spz_amd_ipc_open(const uint8_t handle[SPZ_AMD_IPC_HANDLE_BYTES], void **d_ptr);
+int spz_amd_ipc_close(void *d_ptr);
 
 /* ---- random access: decode only the points d_indices[0..count) out of a stream that
  *      stays packed in device memory — the bulk form of PackedGaussians::unpack(i, converter)

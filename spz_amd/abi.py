@@ -22,6 +22,7 @@ ERR_CAPACITY = -7
 ERR_NO_DEVICE = -8
 ERR_HIP = -9
 ERR_UNSUPPORTED = -10
+ERR_COMM = -11
 
 UNSPECIFIED, LDB, RDB, LUB, RUB, LDF, RDF, LUF, RUF = range(9)
 NUM_SECTIONS = 6
@@ -43,7 +44,17 @@ EXPORTS = (
     "spz_amd_ply_rows_to_cloud_host", "spz_amd_cloud_to_ply_rows_host",
     "spz_amd_median_scale_sum_device", "spz_amd_median_scale_sum_host",
     "spz_amd_selftest_device",
+    "spz_amd_encode_shard_sections_device", "spz_amd_shard_fragments",
+    "spz_amd_rccl_available", "spz_amd_last_rccl_error", "spz_amd_rccl_unique_id", "spz_amd_rccl_comm_init",
+    "spz_amd_rccl_comm_destroy", "spz_amd_gatherv_rccl",
+    "spz_amd_ipc_alloc", "spz_amd_ipc_free", "spz_amd_ipc_open", "spz_amd_ipc_close",
 )
+
+RCCL_UNIQUE_ID_BYTES = 128
+IPC_HANDLE_BYTES = 64
+ALL_SECTIONS = 0x3f
+SMALL_SECTIONS = 0x1f      # positions, alphas, colors, scales, rotations (20 B/point for v3)
+SH_SECTION = 0x20
 
 
 class Header(C.Structure):
@@ -69,6 +80,12 @@ class PlyColumns(C.Structure):
     """spz_amd_ply_columns: column map of a .ply vertex row."""
     _fields_ = [("stride", C.c_int32), ("sh_dim", C.c_int32), ("position", C.c_int32 * 3), ("scale", C.c_int32 * 3),
                 ("rotation", C.c_int32 * 4), ("alpha", C.c_int32), ("color", C.c_int32 * 3), ("sh", C.c_int32 * 45)]
+
+
+class Fragments(C.Structure):
+    """spz_amd_fragments: the six byte ranges of a point-range shard."""
+    _fields_ = [("global_offset", C.c_uint64 * NUM_SECTIONS), ("local_offset", C.c_uint64 * NUM_SECTIONS),
+                ("bytes", C.c_uint64 * NUM_SECTIONS)]
 
 
 class SpzAmdError(RuntimeError):
@@ -156,6 +173,29 @@ def bind(L):
     L.spz_amd_ply_rows_to_cloud_host.argtypes = [vp, u64, C.POINTER(PlyColumns), i32, C.POINTER(CloudPtrs), i32]
     L.spz_amd_cloud_to_ply_rows_host.restype = i32
     L.spz_amd_cloud_to_ply_rows_host.argtypes = [C.POINTER(CloudPtrs), u64, i32, i32, vp, i32]
+    u32 = C.c_uint
+    L.spz_amd_encode_shard_sections_device.restype = i32
+    L.spz_amd_encode_shard_sections_device.argtypes = [C.POINTER(CloudPtrs), u64, u64, u64, i32, i32, i32, i32, i32, u32, vp, sz, vp]
+    L.spz_amd_shard_fragments.restype = i32
+    L.spz_amd_shard_fragments.argtypes = [u64, u64, u64, i32, i32, C.POINTER(Fragments)]
+    L.spz_amd_rccl_available.restype = i32
+    L.spz_amd_last_rccl_error.restype = i32
+    L.spz_amd_rccl_unique_id.restype = i32
+    L.spz_amd_rccl_unique_id.argtypes = [vp]
+    L.spz_amd_rccl_comm_init.restype = i32
+    L.spz_amd_rccl_comm_init.argtypes = [vp, i32, i32, C.POINTER(vp)]
+    L.spz_amd_rccl_comm_destroy.restype = i32
+    L.spz_amd_rccl_comm_destroy.argtypes = [vp]
+    L.spz_amd_gatherv_rccl.restype = i32
+    L.spz_amd_gatherv_rccl.argtypes = [vp, i32, i32, i32, C.POINTER(u64), C.POINTER(u64), i32, i32, vp, vp, u32, vp]
+    L.spz_amd_ipc_alloc.restype = i32
+    L.spz_amd_ipc_alloc.argtypes = [sz, C.POINTER(vp), vp]
+    L.spz_amd_ipc_free.restype = i32
+    L.spz_amd_ipc_free.argtypes = [vp]
+    L.spz_amd_ipc_open.restype = i32
+    L.spz_amd_ipc_open.argtypes = [vp, C.POINTER(vp)]
+    L.spz_amd_ipc_close.restype = i32
+    L.spz_amd_ipc_close.argtypes = [vp]
     L.spz_amd_selftest_device.restype = i32
     L.spz_amd_selftest_device.argtypes = [i32, u64, u64, C.POINTER(u64 * 3), vp]
     return L

@@ -317,7 +317,7 @@ int layout_impl(uint64_t n, int sh_degree, int version, spz_amd_layout *out) {
 
 int encode_impl(const spz_amd_cloud_in *cl, uint64_t first, uint64_t count, uint64_t n_total, int sh_degree,
                 int antialiased, int from_coord, int version, int write_header, uint8_t *d_stream,
-                size_t capacity, void *hip_stream) {
+                size_t capacity, void *hip_stream, unsigned section_mask = 0x3fu) {
   if (cl == nullptr || d_stream == nullptr || !valid_coord(from_coord)) return SPZ_AMD_ERR_INVALID_ARG;
   if (version == 1) return SPZ_AMD_ERR_UNSUPPORTED;
   spz_amd_layout lay;
@@ -345,14 +345,17 @@ int encode_impl(const spz_amd_cloud_in *cl, uint64_t first, uint64_t count, uint
   p.pos_scale = 0.0f;
   auto frag = [&](int s) { return d_stream + lay.offset[s] + first * lay.bytes_per_point[s]; };
   auto fl = [](const float *q) { return const_cast<float *>(q); };
+  auto want = [&](int s) { return ((section_mask >> s) & 1u) != 0u; };
   // Largest sections first so the tail of the grid is made of the small ones.
-  add_section(&p, EncGeom::kTileUnits, KIND_SH, frag(SPZ_AMD_SEC_SH), fl(cl->sh), count * (uint64_t)sd * 3u);
-  add_section(&p, EncGeom::kTileUnits, KIND_POS24, frag(SPZ_AMD_SEC_POSITIONS), fl(cl->positions), count * 3u);
-  add_section(&p, EncGeom::kTileUnits, version >= 3 ? KIND_ROT_S3 : KIND_ROT_F3, frag(SPZ_AMD_SEC_ROTATIONS), fl(cl->rotations),
-              count * 4u);
-  add_section(&p, EncGeom::kTileUnits, KIND_SCALE, frag(SPZ_AMD_SEC_SCALES), fl(cl->scales), count * 3u);
-  add_section(&p, EncGeom::kTileUnits, KIND_COLOR, frag(SPZ_AMD_SEC_COLORS), fl(cl->colors), count * 3u);
-  add_section(&p, EncGeom::kTileUnits, KIND_ALPHA, frag(SPZ_AMD_SEC_ALPHAS), fl(cl->alphas), count);
+  if (want(SPZ_AMD_SEC_SH)) add_section(&p, EncGeom::kTileUnits, KIND_SH, frag(SPZ_AMD_SEC_SH), fl(cl->sh), count * (uint64_t)sd * 3u);
+  if (want(SPZ_AMD_SEC_POSITIONS)) add_section(&p, EncGeom::kTileUnits, KIND_POS24, frag(SPZ_AMD_SEC_POSITIONS), fl(cl->positions), count * 3u);
+  if (want(SPZ_AMD_SEC_ROTATIONS)) {
+    add_section(&p, EncGeom::kTileUnits, version >= 3 ? KIND_ROT_S3 : KIND_ROT_F3, frag(SPZ_AMD_SEC_ROTATIONS), fl(cl->rotations),
+                count * 4u);
+  }
+  if (want(SPZ_AMD_SEC_SCALES)) add_section(&p, EncGeom::kTileUnits, KIND_SCALE, frag(SPZ_AMD_SEC_SCALES), fl(cl->scales), count * 3u);
+  if (want(SPZ_AMD_SEC_COLORS)) add_section(&p, EncGeom::kTileUnits, KIND_COLOR, frag(SPZ_AMD_SEC_COLORS), fl(cl->colors), count * 3u);
+  if (want(SPZ_AMD_SEC_ALPHAS)) add_section(&p, EncGeom::kTileUnits, KIND_ALPHA, frag(SPZ_AMD_SEC_ALPHAS), fl(cl->alphas), count);
   if (write_header) {
     p.header_dst = d_stream;
     p.header_words[0] = kMagic;
@@ -550,6 +553,7 @@ const char *spz_amd_status_string(int status) {
     case SPZ_AMD_ERR_NO_DEVICE: return "no usable HIP device";
     case SPZ_AMD_ERR_HIP: return "HIP runtime error";
     case SPZ_AMD_ERR_UNSUPPORTED: return "unsupported operation";
+    case SPZ_AMD_ERR_COMM: return "RCCL error";
     default: return "unknown status";
   }
 }
@@ -677,6 +681,15 @@ int spz_amd_encode_shard_device(const spz_amd_cloud_in *d_cloud, uint64_t first,
                                 void *hip_stream) {
   return encode_impl(d_cloud, first, count, num_points_total, sh_degree, antialiased, from_coord, version,
                      write_header, d_stream, capacity, hip_stream);
+}
+
+int spz_amd_encode_shard_sections_device(const spz_amd_cloud_in *d_cloud, uint64_t first, uint64_t count,
+                                         uint64_t num_points_total, int sh_degree, int antialiased, int from_coord,
+                                         int version, int write_header, unsigned section_mask, uint8_t *d_stream,
+                                         size_t capacity, void *hip_stream) {
+  if ((section_mask & ~0x3fu) != 0u) return SPZ_AMD_ERR_INVALID_ARG;
+  return encode_impl(d_cloud, first, count, num_points_total, sh_degree, antialiased, from_coord, version,
+                     write_header, d_stream, capacity, hip_stream, section_mask);
 }
 
 int spz_amd_decode_device(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr, int to_coord,

@@ -55,9 +55,15 @@ inline int prefaultThreads() {
   return n;
 }
 
-// Maps the pages of freshly allocated buffers (MADV_POPULATE_WRITE: as if written, contents untouched, so it
-// may run while a device-to-host copy is already landing in them) from a few threads; joins in the
-// destructor.  Where the kernel lacks the advice nothing is done and the pages fault on first use.
+// Maps the pages of freshly allocated buffers from a few threads; joins in the destructor.
+//  * MADV_HUGEPAGE first: with transparent huge pages in "madvise" mode (this image, the GPU boxes) the range
+//    is then backed by 2 MiB pages — 1 200 faults instead of 576 000 for the 2.36 GB of a 10 M-point cloud.
+//    Measured on the GPU box's host: 4 KiB pages map at 16-23 GB/s whatever the thread count (and a device
+//    copy into untouched pages runs at 13 GB/s against 56 GB/s into mapped ones), which made the first
+//    touch of the outputs cost more than the PCIe transfer.
+//  * MADV_POPULATE_WRITE then maps them "as if written", contents untouched, so it may run while a
+//    device-to-host copy is already landing in them.  Where the kernel lacks the advice nothing is done and
+//    the pages fault on first use.
 class Prefault {
  public:
   Prefault() = default;
@@ -65,15 +71,16 @@ class Prefault {
   Prefault &operator=(const Prefault &) = delete;
   ~Prefault() { join(); }
   void add(void *p, size_t bytes) {
-#ifdef MADV_POPULATE_WRITE
+#if defined(MADV_POPULATE_WRITE) && defined(MADV_HUGEPAGE)
     const int threads = prefaultThreads();
     if (threads <= 0 || bytes < (size_t(32) << 20)) return;
-    const size_t page = static_cast<size_t>(sysconf(_SC_PAGESIZE));
-    const uintptr_t lo = (reinterpret_cast<uintptr_t>(p) + page - 1) & ~(page - 1);
-    const uintptr_t hi = (reinterpret_cast<uintptr_t>(p) + bytes) & ~(page - 1);
+    const size_t huge = size_t(2) << 20;
+    const uintptr_t lo = (reinterpret_cast<uintptr_t>(p) + huge - 1) & ~(huge - 1);
+    const uintptr_t hi = (reinterpret_cast<uintptr_t>(p) + bytes) & ~(huge - 1);
     if (hi <= lo) return;
-    const size_t pieces = std::min<size_t>(static_cast<size_t>(threads), (hi - lo) / (size_t(8) << 20) + 1);
-    const size_t per = (((hi - lo) / pieces) + page - 1) & ~(page - 1);
+    (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
+    const size_t pieces = std::min<size_t>(static_cast<size_t>(threads), (hi - lo) / (size_t(16) << 20) + 1);
+    const size_t per = (((hi - lo) / pieces) + huge - 1) & ~(huge - 1);
     for (uintptr_t a = lo; a < hi; a += per) {
       const size_t len = std::min<size_t>(per, hi - a);
       pool_.emplace_back([a, len]() { (void)madvise(reinterpret_cast<void *>(a), len, MADV_POPULATE_WRITE); });

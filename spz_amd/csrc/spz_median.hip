@@ -48,7 +48,7 @@ __device__ __forceinline__ void wave_histogram_add(uint32_t *h, uint32_t bin, bo
   if (valid) atomicAdd(&h[bin], 1u);
 }
 
-constexpr int kSelectPointsPerThread = 4;  // 12 floats = three 16-byte loads per lane, 3 KiB contiguous per wave
+constexpr int kSelectPointsPerThread = 8;  // 24 floats = six 16-byte loads in flight per lane, 6 KiB contiguous per wave
 
 __global__ __launch_bounds__(256) void spz_select_hist_kernel(const float *__restrict__ scales, uint64_t n,
                                                               SelectState *__restrict__ st, int pass) {
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void spz_select_hist_kernel(const float *__res
     if (i + kSelectPointsPerThread <= n) {
       const F32x4 *q = reinterpret_cast<const F32x4 *>(scales + 3 * i);
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
+      for (int r = 0; r < 3 * kSelectPointsPerThread / 4; ++r) {
         const F32x4 t = q[r];
         v[4 * r + 0] = t.x; v[4 * r + 1] = t.y; v[4 * r + 2] = t.z; v[4 * r + 3] = t.w;
       }
@@ -136,10 +136,13 @@ int spz_amd_median_scale_sum_device(const float *d_scales, uint64_t num_points, 
   SelectState *st = static_cast<SelectState *>(d_workspace);
   SPZ_HIP_TRY(hipMemsetAsync(st, 0, sizeof(SelectState), s));
   const uint32_t k = (uint32_t)(num_points / 2);  // rank size/2 of the sorted sums (splat-types.h:182)
-  // 1024 points per block and trip; at most 4 blocks per CU, so that the per-block flush into the 256 global
-  // bins stays at ~1000 adds per bin
+  // 2048 points per block and trip; at most 8 blocks per CU (the per-block flush into the 256 global bins stays
+  // at ~2000 adds per bin), every block the same number of trips
   unsigned long long blocks = (num_points + 256 * kSelectPointsPerThread - 1) / (256 * kSelectPointsPerThread);
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 2048) {
+    const unsigned long long trips = (blocks + 2047) / 2048;
+    blocks = (blocks + trips - 1) / trips;
+  }
   for (int pass = 0; pass < 4; ++pass) {
     hipLaunchKernelGGL(spz_select_hist_kernel, dim3((unsigned)blocks), dim3(256), 0, s, d_scales, num_points, st, pass);
     hipLaunchKernelGGL(spz_select_pick_kernel, dim3(1), dim3(64), 0, s, st, pass, k, d_median);

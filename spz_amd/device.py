@@ -54,6 +54,21 @@ def peek_header(stream_t, max_points=abi.REFERENCE_MAX_POINTS, stream=None):
     return rc, (h if rc == abi.OK else None)
 
 
+class RawStream:
+    """A device byte buffer known by address only (spz_amd_ipc_alloc / spz_amd_ipc_open).  `tensor()` gives a
+    uint8 view of it for checks (through __cuda_array_interface__; the buffer must outlive the view)."""
+
+    def __init__(self, ptr, nbytes):
+        self.ptr, self.nbytes = int(ptr), int(nbytes)
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2, "strides": None}
+
+    def tensor(self, device):
+        return torch.as_tensor(self, device=device)
+
+
 def encode(cloud, num_points, sh_degree, antialiased=False, from_coord=0, version=3, out=None, stream=None):
     """packGaussians + serializePackedGaussians on the GPU -> uint8 CUDA tensor holding the raw
     (pre-gzip) stream.  Asynchronous on `stream` (default: torch's current stream)."""
@@ -86,15 +101,19 @@ def decode(stream_t, header, to_coord=0, out=None, stream=None):
 
 
 def encode_shard(cloud, first, count, num_points_total, sh_degree, out, antialiased=False, from_coord=0, version=3,
-                 write_header=False, stream=None):
-    """Encode points [first, first+count) (cloud holds only those) into the FULL stream `out`."""
+                 write_header=False, stream=None, section_mask=abi.ALL_SECTIONS):
+    """Encode points [first, first+count) (cloud holds only those) into the FULL stream `out`: a uint8 CUDA
+    tensor, or a RawStream (pointer + size: e.g. another process's buffer mapped over IPC).  section_mask
+    restricts the launch to some of the six sections (abi.SMALL_SECTIONS / abi.SH_SECTION)."""
     L = abi.load_library()
-    p = _ptrs(cloud, sh_degree, count, out.device)
-    with torch.cuda.device(out.device):
-        rc = L.spz_amd_encode_shard_device(C.byref(p), first, count, num_points_total, sh_degree,
-                                           int(bool(antialiased)), from_coord, version, int(bool(write_header)),
-                                           out.data_ptr(), out.numel(), _stream_handle(stream))
-    abi.check(rc, "spz_amd_encode_shard_device")
+    device = cloud["positions"].device
+    p = _ptrs(cloud, sh_degree, count, device)
+    ptr, size = (out.ptr, out.nbytes) if isinstance(out, RawStream) else (out.data_ptr(), out.numel())
+    with torch.cuda.device(device):
+        rc = L.spz_amd_encode_shard_sections_device(C.byref(p), first, count, num_points_total, sh_degree,
+                                                    int(bool(antialiased)), from_coord, version, int(bool(write_header)),
+                                                    int(section_mask), ptr, size, _stream_handle(stream))
+    abi.check(rc, "spz_amd_encode_shard_sections_device")
     return out
 
 

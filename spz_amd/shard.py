@@ -162,6 +162,79 @@ def scatter_stream(global_stream, plan, rank, local_stream, src=0, group=None, a
     return []
 
 
+class RcclGather:
+    """The RCCL route through the C ABI (spz_amd_gatherv_rccl): one ncclGroupStart/End of send/recv pairs that
+    land every fragment at its final offset on the root.  The communicator is this class's own
+    (ncclCommInitRank on a unique id that rank `dst` creates and torch.distributed — any backend — hands round);
+    one rank per GPU, as RCCL requires."""
+
+    def __init__(self, plan, rank, dst=0, group=None):
+        import ctypes as C
+        self.plan, self.rank, self.dst = plan, rank, dst
+        self.L = abi.load_library()
+        if not self.L.spz_amd_rccl_available():
+            raise RuntimeError("librccl.so.1 cannot be loaded")
+        ident = [None]
+        if rank == dst:
+            buf = (C.c_uint8 * abi.RCCL_UNIQUE_ID_BYTES)()
+            abi.check(self.L.spz_amd_rccl_unique_id(buf), "spz_amd_rccl_unique_id")
+            ident = [bytes(buf)]
+        dist.broadcast_object_list(ident, src=dst, group=group)
+        self.comm = C.c_void_p()
+        buf = (C.c_uint8 * abi.RCCL_UNIQUE_ID_BYTES).from_buffer_copy(ident[0])
+        abi.check(self.L.spz_amd_rccl_comm_init(buf, plan.world_size, rank, C.byref(self.comm)), "spz_amd_rccl_comm_init")
+        self.first = (C.c_uint64 * plan.world_size)(*plan.first)
+        self.count = (C.c_uint64 * plan.world_size)(*plan.count)
+
+    def gather(self, local_stream, global_stream, section_mask=abi.ALL_SECTIONS, stream=None):
+        """Enqueue on `stream` (torch.cuda.Stream; None = current).  local_stream: this rank's own stream tensor
+        (None on a root that encoded straight into global_stream); global_stream: root only."""
+        s = (stream or torch.cuda.current_stream()).cuda_stream
+        lp = local_stream.data_ptr() if local_stream is not None else None
+        gp = None
+        if global_stream is not None:
+            gp = global_stream.ptr if hasattr(global_stream, "ptr") else global_stream.data_ptr()
+        rc = self.L.spz_amd_gatherv_rccl(self.comm, self.rank, self.plan.world_size, self.dst, self.first, self.count,
+                                         self.plan.sh_degree, self.plan.version, lp, gp, int(section_mask), s)
+        if rc == abi.ERR_COMM:
+            raise abi.SpzAmdError(rc, f"spz_amd_gatherv_rccl (ncclResult {self.L.spz_amd_last_rccl_error()})")
+        abi.check(rc, "spz_amd_gatherv_rccl")
+
+    def close(self):
+        if self.comm:
+            self.L.spz_amd_rccl_comm_destroy(self.comm)
+            self.comm = None
+
+
+class IpcGlobalStream:
+    """The IPC route: rank `dst` allocates the global stream and exports it; every other rank of the node maps
+    it and encodes its shard straight into it (device.encode_shard(..., out=self.raw)), so the encode
+    kernel's stores are the exchange.  `raw` is a device.RawStream on every rank."""
+
+    def __init__(self, plan, rank, dst=0, group=None):
+        import ctypes as C
+        from .device import RawStream
+        self.L = abi.load_library()
+        self.owner = rank == dst
+        nbytes = plan.layout.total_bytes
+        ptr = C.c_void_p()
+        handle = [None]
+        if self.owner:
+            buf = (C.c_uint8 * abi.IPC_HANDLE_BYTES)()
+            abi.check(self.L.spz_amd_ipc_alloc(nbytes, C.byref(ptr), buf), "spz_amd_ipc_alloc")
+            handle = [bytes(buf)]
+        dist.broadcast_object_list(handle, src=dst, group=group)
+        if not self.owner:
+            buf = (C.c_uint8 * abi.IPC_HANDLE_BYTES).from_buffer_copy(handle[0])
+            abi.check(self.L.spz_amd_ipc_open(buf, C.byref(ptr)), "spz_amd_ipc_open")
+        self.raw = RawStream(ptr.value, nbytes)
+
+    def close(self):
+        if self.raw is not None:
+            (self.L.spz_amd_ipc_free if self.owner else self.L.spz_amd_ipc_close)(self.raw.ptr)
+            self.raw = None
+
+
 def write_global_header(global_stream, plan, antialiased=False):
     hdr = abi.write_header(plan.version, plan.num_points, plan.sh_degree, 12, antialiased)
     global_stream[:16].copy_(torch.frombuffer(bytearray(hdr), dtype=torch.uint8))

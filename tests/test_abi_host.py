@@ -166,6 +166,25 @@ def test_ten_million_point_cap_sits_where_the_reference_has_it(lib):
         assert lib.spz_amd_decode_host_ex(stream.ctypes.data, size - 1, 0, 0, C.byref(p), 0) == abi.ERR_SHORT_STREAM
 
 
+def test_shard_fragments_match_the_python_plan(lib):
+    """spz_amd_shard_fragments (the table spz_amd_gatherv_rccl walks) against spz_amd.shard.ShardPlan.fragments
+    (what the torch route and the gloo tests use)."""
+    from spz_amd import abi, shard
+    for n, deg, ver, world in ((1000, 3, 3, 3), (80_000_000, 3, 3, 8), (17, 0, 2, 4), (5, 1, 3, 8)):
+        plan = shard.plan_even(n, deg, world, ver)
+        for r in range(world):
+            f = abi.Fragments()
+            assert lib.spz_amd_shard_fragments(plan.first[r], plan.count[r], n, deg, ver, C.byref(f)) == abi.OK
+            assert [(f.global_offset[s], f.local_offset[s], f.bytes[s]) for s in range(6)] == plan.fragments(r)
+    f = abi.Fragments()
+    assert lib.spz_amd_shard_fragments(5, 6, 10, 0, 3, C.byref(f)) == abi.ERR_INVALID_ARG
+    assert lib.spz_amd_shard_fragments(0, 1, 1, 4, 3, C.byref(f)) == abi.ERR_INVALID_ARG
+    # the exchange entry points validate before they touch RCCL or the device
+    assert lib.spz_amd_gatherv_rccl(None, 0, 1, 0, None, None, 0, 3, None, None, 0x3f, None) == abi.ERR_INVALID_ARG
+    assert lib.spz_amd_ipc_open(None, None) == abi.ERR_INVALID_ARG
+    assert lib.spz_amd_encode_shard_sections_device(None, 0, 0, 0, 0, 0, 0, 3, 0, 0x40, None, 0, None) == abi.ERR_INVALID_ARG
+
+
 def test_python_module_raises_without_a_gpu():
     import torch
     import spz_amd.spz as spz

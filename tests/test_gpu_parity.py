@@ -940,3 +940,109 @@ def test_bench_multi_rank_path_rehearsal_on_one_gpu(dev):
     assert res["shards_only"]["value"] > res["value"] > 0
     assert res["shards_only"]["gatherv_bytes_into_root_per_step"] == 300000 * 65
     assert "cpu_baseline" not in res        # rank 0 at N=1 only
+    assert res["exchange_route"] == "torch"
+
+
+def test_ipc_route_with_two_processes_on_one_gpu(dev):
+    """The IPC route of the exchange: rank 0 allocates the global stream with spz_amd_ipc_alloc, the
+    other PROCESS maps it (hipIpcOpenMemHandle) and its encode kernel stores its fragments straight into rank 0's
+    memory; rank 0 then checks every fragment against the byte sums the owner computed from a local encode
+    (`gather_verified`).  Two ranks of bench.py sharing this GPU; no second pass over the bytes anywhere."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29643", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+           "--points", "300000", "--backend", "gloo", "--route", "ipc"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["exchange_route"] == "ipc" and res["gather_verified"] is True
+    assert res["n_gpus"] == 2 and res["value"] > 0
+
+
+def test_ipc_mapped_stream_equals_the_single_encode(dev, oracle):
+    """Same route at the C ABI, bytes compared in full: this process owns the stream (spz_amd_ipc_alloc) and encodes
+    shard 0 with the header; a child process opens the handle and encodes shard 1 of the same seeded cloud into
+    the mapping; the result equals the oracle's stream of the whole cloud."""
+    import os
+    import subprocess
+    import sys
+    import torch
+    from conftest import ROOT
+    from spz_amd import abi, device as D
+    from spz_amd.synth import make_cloud_numpy, floats_per_point
+    L = abi.load_library()
+    n, deg, cut = 200_003, 3, 120_016
+    c = make_cloud_numpy(n, deg, 77)
+    total = abi.stream_layout(n, deg, 3).total_bytes
+    ptr = C.c_void_p()
+    handle = (C.c_uint8 * abi.IPC_HANDLE_BYTES)()
+    abi.check(L.spz_amd_ipc_alloc(total, C.byref(ptr), handle), "spz_amd_ipc_alloc")
+    try:
+        raw = D.RawStream(ptr.value, total)
+        view = raw.tensor(dev)
+        view.zero_()
+        torch.cuda.synchronize()
+        child = ("import sys, ctypes as C, torch\n"
+                 "from spz_amd import abi, device as D\n"
+                 "from spz_amd.synth import make_cloud_numpy, floats_per_point, FIELDS\n"
+                 "n, deg, cut, total = (int(x) for x in sys.argv[2:6])\n"
+                 "L = abi.load_library(); dev = torch.device('cuda:0')\n"
+                 "h = (C.c_uint8 * abi.IPC_HANDLE_BYTES).from_buffer_copy(bytes.fromhex(sys.argv[1]))\n"
+                 "p = C.c_void_p(); abi.check(L.spz_amd_ipc_open(h, C.byref(p)), 'open')\n"
+                 "c = make_cloud_numpy(n, deg, 77)\n"
+                 "sub = {k: torch.from_numpy(c[k][cut * floats_per_point(k, deg):]).to(dev) for k in FIELDS}\n"
+                 "D.encode_shard(sub, cut, n - cut, n, deg, D.RawStream(p.value, total), antialiased=True, from_coord=6)\n"
+                 "torch.cuda.synchronize(); abi.check(L.spz_amd_ipc_close(p), 'close')\n")
+        sub0 = {k: torch.from_numpy(c[k][:cut * floats_per_point(k, deg)]).to(dev) for k in FIELDS}
+        D.encode_shard(sub0, 0, cut, n, deg, raw, antialiased=True, from_coord=6, write_header=True)
+        torch.cuda.synchronize()
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", PYTHONPATH=ROOT)
+        r = subprocess.run([sys.executable, "-c", child, bytes(handle).hex(), str(n), str(deg), str(cut), str(total)],
+                           capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        torch.cuda.synchronize()
+        assert_bytes_equal(view.cpu().numpy(), oracle.pack(c, n, deg, True, 6), "two processes, one stream")
+        del view
+    finally:
+        abi.check(L.spz_amd_ipc_free(ptr), "spz_amd_ipc_free")
+
+
+def test_rccl_gatherv_native_on_one_gpu(dev, oracle):
+    """spz_amd_gatherv_rccl through a real RCCL communicator (world size 1, which is what one GPU allows: RCCL
+    refuses two ranks on a device): the rank's own stream travels by ncclSend/ncclRecv to itself inside the same
+    ncclGroupStart/End construction the multi-GPU path uses, in two calls (small sections, then sh), and lands
+    at the global offsets.  The N > 1 exchange itself stays unmeasured on hardware."""
+    import torch
+    from spz_amd import abi, device as D
+    from spz_amd.synth import make_cloud_numpy
+    L = abi.load_library()
+    assert L.spz_amd_rccl_available() == 1, "librccl.so.1 not loadable"
+    ident = (C.c_uint8 * abi.RCCL_UNIQUE_ID_BYTES)()
+    abi.check(L.spz_amd_rccl_unique_id(ident), "unique id")
+    comm = C.c_void_p()
+    abi.check(L.spz_amd_rccl_comm_init(ident, 1, 0, C.byref(comm)), "comm init")
+    try:
+        n, deg = 100_003, 3
+        c = make_cloud_numpy(n, deg, 78)
+        local = D.encode(D.to_device(c, dev), n, deg, True, 6)
+        glob = torch.zeros_like(local)
+        first, count = (C.c_uint64 * 1)(0), (C.c_uint64 * 1)(n)
+        s = torch.cuda.current_stream().cuda_stream
+        for mask in (abi.SMALL_SECTIONS, abi.SH_SECTION):
+            rc = L.spz_amd_gatherv_rccl(comm, 0, 1, 0, first, count, deg, 3, local.data_ptr(), glob.data_ptr(), mask, s)
+            assert rc == 0, (rc, L.spz_amd_last_rccl_error())
+        torch.cuda.synchronize()
+        want = oracle.pack(c, n, deg, True, 6)
+        assert_bytes_equal(glob.cpu().numpy()[16:], want[16:], "fragments after the self-exchange")
+        assert not glob[:16].any(), "the gatherv moves fragments only; the header is the root's to write"
+        # argument checks: ranges must be contiguous in rank order, the root needs a destination
+        bad_first = (C.c_uint64 * 1)(5)
+        assert L.spz_amd_gatherv_rccl(comm, 0, 1, 0, bad_first, count, deg, 3, local.data_ptr(), glob.data_ptr(), 0x3f, s) == abi.ERR_INVALID_ARG
+        assert L.spz_amd_gatherv_rccl(comm, 0, 1, 0, first, count, deg, 3, local.data_ptr(), None, 0x3f, s) == abi.ERR_INVALID_ARG
+    finally:
+        abi.check(L.spz_amd_rccl_comm_destroy(comm), "comm destroy")

@@ -31,7 +31,7 @@ def main():
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     manifest, rows = [], []
 
-    def timed(case, kernels, alg_bytes, fn, note=""):
+    def timed(case, kernels, alg_bytes, fn, note="", per_kernel_alg=None):
         """kernels: list of (name substring, dispatches per call) in dispatch order."""
         fn()
         torch.cuda.synchronize()
@@ -43,7 +43,8 @@ def main():
         e[1].record()
         torch.cuda.synchronize()
         ms = e[0].elapsed_time(e[1]) / a.launches
-        manifest.append({"case": case, "kernels": kernels, "calls": a.launches, "algorithmic_bytes": alg_bytes, "note": note})
+        manifest.append({"case": case, "kernels": kernels, "calls": a.launches, "algorithmic_bytes": alg_bytes, "note": note,
+                         "per_kernel_algorithmic": per_kernel_alg})
         r = {"case": case, "ms_per_call_events": round(ms, 4), "algorithmic_GB": round(alg_bytes / 1e9, 4),
              "GBps": round(alg_bytes / ms / 1e6, 1), "frac_of_8TBps": round(alg_bytes / ms / 1e6 / 8000, 3)}
         rows.append(r)
@@ -60,10 +61,13 @@ def main():
         pout = abi.CloudPtrs(*[out[k].data_ptr() for k in FIELDS])
         hdr = abi.Header(ver, n, deg, 12, 0, 0)
         alg = n * (bpp[deg] - (1 if ver == 2 else 0))
-        timed(f"encode {tag}", [("spz_encode_kernel", 1)], alg,
-              lambda: abi.check(L.spz_amd_encode_device(C.byref(pin), n, deg, 0, 6, ver, stream.data_ptr(), stream.numel(), s), "enc"))
-        timed(f"decode {tag}", [("spz_decode_kernel", 1)], alg,
-              lambda: abi.check(L.spz_amd_decode_device(stream.data_ptr(), stream.numel(), C.byref(hdr), 6, C.byref(pout), s), "dec"))
+        def pair():
+            abi.check(L.spz_amd_encode_device(C.byref(pin), n, deg, 0, 6, ver, stream.data_ptr(), stream.numel(), s), "enc")
+            abi.check(L.spz_amd_decode_device(stream.data_ptr(), stream.numel(), C.byref(hdr), 6, C.byref(pout), s), "dec")
+        # encode and decode alternate, as in bench.py's step: what one kernel leaves in the write-back caches is
+        # paid by the next, so each is timed in the pair's own steady state (profiles/r01_tune_h_*)
+        timed(f"{tag}", [("spz_encode_kernel", 1), ("spz_decode_kernel", 1)], 2 * alg, pair,
+              per_kernel_alg={"spz_encode_kernel": alg, "spz_decode_kernel": alg})
         if deg == 3:
             d = 45
             timed("convertCoordinates 10M sh3 (standalone flip pass)", [("spz_flip_kernel", 1)], n * (3 + 4 + d) * 8,
@@ -84,8 +88,10 @@ def main():
             idx = torch.randint(0, n, (n,), device=dev, dtype=torch.int32)
             timed("gather decode, 10M random indices of a 10M sh3 stream", [("spz_decode_gather_kernel", 1)], n * 301 + n * 4,
                   lambda: D.decode_gather(stream, hdr, idx, 0, out=out),
-                  note="algorithmic = 65 B read + 236 B written + 4 B index per point; the attribute-major format puts a point's "
-                       "65 bytes into six sections, so a random point costs ~7 sectors of 64 B: ~6.9x the useful read bytes")
+                  note="algorithmic = 65 B read + 236 B written + 4 B index per point.  The attribute-major format puts a point's "
+                       "65 bytes into six sections, so a random point touches ~7 sectors of 64 B (448 B): inherent to the format. "
+                       "The x2 correction of FETCH_SIZE is calibrated for streaming reads only; for these scattered sector reads "
+                       "the true read traffic lies between FETCH_SIZE x1 and x2")
             del idx
             # medianVolume's selection: 4 histogram passes + 4 one-wave picks
             ws = torch.empty(abi.MEDIAN_WORKSPACE_BYTES, dtype=torch.uint8, device=dev)

@@ -136,6 +136,35 @@ int main(int argc, char **argv) {
     printf("{\"what\": \"populate_write\", \"GB\": %.2f, \"threads\": %d, \"s\": %.4f, \"GBps\": %.1f}\n", big / 1e9, threads, t, big / 1e9 / t);
     munmap(p, big);
   }
+#ifndef MADV_HUGEPAGE
+#define MADV_HUGEPAGE 14
+#endif
+  for (int threads : {1, 4, 16, 32}) {   // the same with transparent huge pages asked for (THP mode "madvise")
+    void *p = fresh(big + (size_t(2) << 20));
+    char *q = (char *)(((uintptr_t)p + (size_t(2) << 20) - 1) & ~((uintptr_t)(size_t(2) << 20) - 1));
+    const size_t len = big & ~((size_t(2) << 20) - 1);
+    const int adv = madvise(q, len, MADV_HUGEPAGE);
+    const double t = populate(q, len, threads);
+    printf("{\"what\": \"populate_write_hugepage\", \"madvise_rc\": %d, \"GB\": %.2f, \"threads\": %d, \"s\": %.4f, \"GBps\": %.1f}\n", adv, len / 1e9, threads, t, len / 1e9 / t);
+    if (threads == 16) {
+      t0 = now();
+      CK(hipMemcpy(q, d_big, len, hipMemcpyDeviceToHost));
+      const double t2 = now() - t0;
+      printf("{\"what\": \"d2h_into_populated_hugepages\", \"GB\": %.2f, \"s\": %.4f, \"GBps\": %.1f}\n", len / 1e9, t2, len / 1e9 / t2);
+    }
+    munmap(p, big + (size_t(2) << 20));
+  }
+  {
+    void *p = fresh(big + (size_t(2) << 20));   // DMA into untouched pages of a huge-page-advised range
+    char *q = (char *)(((uintptr_t)p + (size_t(2) << 20) - 1) & ~((uintptr_t)(size_t(2) << 20) - 1));
+    const size_t len = big & ~((size_t(2) << 20) - 1);
+    (void)madvise(q, len, MADV_HUGEPAGE);
+    t0 = now();
+    CK(hipMemcpy(q, d_big, len, hipMemcpyDeviceToHost));
+    const double t = now() - t0;
+    printf("{\"what\": \"d2h_into_untouched_hugepage_range\", \"GB\": %.2f, \"s\": %.4f, \"GBps\": %.1f}\n", len / 1e9, t, len / 1e9 / t);
+    munmap(p, big + (size_t(2) << 20));
+  }
   {
     void *p = fresh(big);   // DMA straight into untouched pageable memory
     t0 = now();
