@@ -76,7 +76,12 @@ clean:
 	rm -rf $(LIBDIR) $(ROOT)build $(ROOT)spz_amd/spz*.so $(ROOT)spz_amd/bin
 	$(MAKE) -C $(ROOT)oracle clean
 
-.PHONY: fuzz all device host python cli oracle asm clean
+.PHONY: fuzz gzip-campaign all device host python cli oracle asm clean
+
+# The byte-identity of the multi-threaded gzip writer against zlib 1.2.11 on ~9 300 randomized inputs (host
+# only, about twenty minutes on 8 cores); the result line goes to profiles/.
+gzip-campaign: host python
+	$(PYTHON) $(ROOT)tools/gzip_campaign.py --inputs 9300 | tee $(ROOT)profiles/gzip_campaign.json
 
 # Host-side robustness: the gzip readers and the .ply header parser under AddressSanitizer + UBSan
 # (CPU only; the GPU pool has no sanitizer support).  Mutated inputs; must finish without a report.

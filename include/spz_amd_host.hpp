@@ -174,6 +174,9 @@ GaussianCloud unpackIndices(const PackedGaussians &packed, const std::vector<uin
 // Raw (pre-gzip) stream <-> cloud, i.e. saveSpz / loadSpz without the zlib step.
 bool packToStream(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream);
 GaussianCloud unpackFromStream(const uint8_t *stream, size_t size, const UnpackOptions &o);
+// CPUs this process may use (online count, affinity mask, cgroup quota): what the thread-count defaults of the
+// gzip writer / readers derive from.
+unsigned effectiveCpuCount();
 // Status (spz_amd.h codes) of the last device call made by this thread; 0 = ok.
 int lastDeviceStatus();
 void setLastDeviceStatus(int status);

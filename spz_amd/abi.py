@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "lib", "libspz_amd.so")
+# SPZ_AMD_LIB: another build of the library (tools/tune.py variants under a profiler); default: the in-tree build
+LIB_PATH = os.environ.get("SPZ_AMD_LIB") or os.path.join(HERE, "lib", "libspz_amd.so")
 
 OK = 0
 ERR_INVALID_ARG = -1

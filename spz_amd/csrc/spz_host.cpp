@@ -7,6 +7,7 @@
 #include "spz_amd_host.hpp"
 
 #include <dlfcn.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
@@ -149,6 +150,7 @@ bool readFile(const std::string &filename, std::vector<uint8_t> *data, bool log)
 
 }  // namespace
 
+unsigned effectiveCpuCount() { return detail::effectiveCpuCount(); }
 int lastDeviceStatus() { return g_last_status; }
 void setLastDeviceStatus(int status) { g_last_status = status; }
 
@@ -365,8 +367,49 @@ namespace {
 int exactGzipThreads() {
   const char *e = std::getenv("SPZ_AMD_GZIP_EXACT_THREADS");
   if (e) return std::max(0, std::atoi(e));
-  return static_cast<int>(std::min<unsigned>(std::thread::hardware_concurrency(), 32u));
+  return static_cast<int>(std::min<unsigned>(detail::effectiveCpuCount(), 32u));
 }
+}  // namespace
+
+namespace {
+
+// Physical memory the machine has free right now (0 if unknown).
+size_t availablePhysicalBytes() {
+  const long pages = sysconf(_SC_AVPHYS_PAGES), page = sysconf(_SC_PAGESIZE);
+  return (pages > 0 && page > 0) ? static_cast<size_t>(pages) * static_cast<size_t>(page) : 0;
+}
+
+// SPZ_AMD_GZIP_VERIFY: 0 (default) = the writer's own 256 KiB prefix check against zlib; 1 = additionally inflate
+// the finished member and compare every byte with the input before returning it (a valid member of the right
+// content: ~0.1 s per 100 MB); 2 = additionally run zlib itself over the whole input and compare the two members
+// byte for byte (the identity claim itself, at zlib's price).  A failed check discards the parallel result and
+// returns zlib's.
+int gzipVerifyLevel() {
+  const char *e = std::getenv("SPZ_AMD_GZIP_VERIFY");
+  return e ? std::max(0, std::atoi(e)) : 0;
+}
+
+bool compressGzippedZlib(const uint8_t *data, size_t size, std::vector<uint8_t> *out);
+
+bool verifiedExact(const uint8_t *data, size_t size, const std::vector<uint8_t> &member, int level) {
+  if (level >= 1) {
+    std::vector<uint8_t> back;
+    if (!decompressGzipped(member.data(), member.size(), &back) || back.size() != size ||
+        std::memcmp(back.data(), data, size) != 0) {
+      logLine("[SPZ ERROR] spz_amd: the parallel gzip writer's member does not inflate to its input; using zlib");
+      return false;
+    }
+  }
+  if (level >= 2) {
+    std::vector<uint8_t> z;
+    if (!compressGzippedZlib(data, size, &z) || z != member) {
+      logLine("[SPZ ERROR] spz_amd: the parallel gzip writer's bytes differ from zlib's; using zlib");
+      return false;
+    }
+  }
+  return true;
+}
+
 }  // namespace
 
 bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out) {
@@ -378,8 +421,20 @@ bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out
     // parse jobs of 1 MiB; smaller ones (down to 128 KiB) when that is what it takes to give every thread two
     const int windows = static_cast<int>(std::min<size_t>(32, std::max<size_t>(4, size / (size_t(threads > 0 ? threads : 1) * 2 * 32768))));
     const size_t verify = std::min<size_t>(size_t(256) << 10, std::max<size_t>(size_t(64) << 10, size / 16));
-    if (threads > 1 && exactgz::compress(data, size, threads, windows, out, verify)) return true;
+    // The writer keeps every job's symbols until assembly: about 3 bytes per input byte plus the output, where
+    // zlib needs under 1 MB.  A host that does not have that to spare gets zlib's pace instead of the OOM killer.
+    const size_t avail = availablePhysicalBytes();
+    const bool fits = avail == 0 || size / 2 * 9 < avail;   // 4.5 x the input
+    if (threads > 1 && fits && exactgz::compress(data, size, threads, windows, out, verify)) {
+      const int level = gzipVerifyLevel();
+      if (level == 0 || verifiedExact(data, size, *out, level)) return true;
+    }
   }
+  return compressGzippedZlib(data, size, out);
+}
+
+namespace {
+bool compressGzippedZlib(const uint8_t *data, size_t size, std::vector<uint8_t> *out) {
   z_stream stream = {};
   // Same parameters as load-spz.cc:190: default level, gzip wrapper, memLevel 9.
   if (deflateInit2(&stream, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 9, Z_DEFAULT_STRATEGY) != Z_OK) {
@@ -415,6 +470,7 @@ bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out
   deflateEnd(&stream);
   return success;
 }
+}  // namespace
 
 // ---- opt-in parallel gzip ---------------------------------------------------------
 // zlib is ~87 % of an end-to-end saveSpz.  This is pigz's "independent blocks"
@@ -489,7 +545,7 @@ size_t parseGzipHeader(const uint8_t *p, size_t n, GzipIndex *idx) {
 
 int gunzipThreads(size_t pieces) {
   const char *e = std::getenv("SPZ_AMD_GUNZIP_THREADS");
-  size_t t = e ? static_cast<size_t>(std::max(1, std::atoi(e))) : std::min<size_t>(std::thread::hardware_concurrency(), 32);
+  size_t t = e ? static_cast<size_t>(std::max(1, std::atoi(e))) : std::min<size_t>(detail::effectiveCpuCount(), 32);
   return static_cast<int>(std::max<size_t>(1, std::min(t, pieces)));
 }
 
@@ -786,6 +842,7 @@ bool packToStream(const GaussianCloud &g, const PackOptions &o, std::vector<uint
   detail::resizeUninitialized(stream, lay.total_bytes);
   detail::Prefault prefault;
   prefault.add(stream->data(), stream->size());
+  prefault.start();
   spz_amd_cloud_in in = {g.positions.data(), g.scales.data(), g.rotations.data(),
                          g.alphas.data(),    g.colors.data(), g.sh.empty() ? nullptr : g.sh.data()};
   const int rc = spz_amd_encode_host(&in, static_cast<uint64_t>(g.numPoints), g.shDegree, g.antialiased ? 1 : 0,
@@ -804,6 +861,7 @@ GaussianCloud unpackFromStream(const uint8_t *stream, size_t size, const UnpackO
   const size_t n = hdr.num_points;
   detail::Prefault prefault;
   sizeCloudArrays(&r, n, static_cast<size_t>(dimForDegree(hdr.sh_degree)), &prefault);
+  prefault.start();
   spz_amd_cloud_out out = {r.positions.data(), r.scales.data(), r.rotations.data(),
                            r.alphas.data(),    r.colors.data(), r.sh.empty() ? nullptr : r.sh.data()};
   const int rc = spz_amd_decode_host(stream, size, static_cast<int>(o.to), &out, deviceIndex());
@@ -856,6 +914,7 @@ GaussianCloud unpackGaussians(const PackedGaussians &packed, const UnpackOptions
   if (n == 0) return r;
   detail::Prefault prefault;
   sizeCloudArrays(&r, n, static_cast<size_t>(shDim), &prefault);
+  prefault.start();
   spz_amd_cloud_out out = {r.positions.data(), r.scales.data(), r.rotations.data(),
                            r.alphas.data(),    r.colors.data(), r.sh.empty() ? nullptr : r.sh.data()};
   // no point limit here: the reference's 10 M cap lives in deserializePackedGaussians (load-spz.cc:549,561),

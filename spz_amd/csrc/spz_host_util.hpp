@@ -7,12 +7,15 @@
 // Prefault maps the fresh pages from several threads while the first transfer is under way.
 #pragma once
 
+#include <sched.h>
 #include <sys/mman.h>
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstddef>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <thread>
@@ -46,11 +49,42 @@ void resizeUninitialized(std::vector<T> *v, size_t n) {
   v->resize(n);
 }
 
+// CPUs this process may actually use: the smaller of the online count, the scheduler affinity mask and the
+// cgroup CPU quota (a container on a 256-thread host is often allowed 16: worker pools sized by
+// hardware_concurrency() there only add contention, which is what "no scaling from 32 to 128 threads" was).
+inline unsigned effectiveCpuCount() {
+  static const unsigned n = []() {
+    unsigned c = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) c = std::min<unsigned>(c, std::max(1, CPU_COUNT(&set)));
+    auto quota = [](const char *path, bool v2) -> double {
+      FILE *f = std::fopen(path, "r");
+      if (!f) return 0.0;
+      char a[64] = "", b[64] = "";
+      const int got = std::fscanf(f, "%63s %63s", a, b);
+      std::fclose(f);
+      if (v2) return (got == 2 && std::strcmp(a, "max") != 0 && std::atof(b) > 0) ? std::atof(a) / std::atof(b) : 0.0;
+      return got >= 1 ? std::atof(a) : 0.0;
+    };
+    double q = quota("/sys/fs/cgroup/cpu.max", true);                       // cgroup v2: "<quota> <period>" or "max <period>"
+    if (q <= 0.0) {
+      const double us = quota("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", false);  // cgroup v1
+      const double period = quota("/sys/fs/cgroup/cpu/cpu.cfs_period_us", false);
+      if (us > 0.0 && period > 0.0) q = us / period;
+    }
+    if (q > 0.0) c = std::min<unsigned>(c, std::max(1u, static_cast<unsigned>(q + 0.999)));
+    return c;
+  }();
+  return n;
+}
+
 inline int prefaultThreads() {
   static const int n = []() {
     const char *e = std::getenv("SPZ_AMD_PREFAULT_THREADS");
     if (e) return std::max(0, std::atoi(e));
-    return static_cast<int>(std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency() / 2)));
+    // measured on the GPU box's host (tools/pcie_probe.hip, 2.36 GB): 1 thread 28 GB/s, 4 threads 110 GB/s,
+    // 16 and 32 threads 35 GB/s (they contend in the page allocator)
+    return static_cast<int>(std::min<unsigned>(4u, effectiveCpuCount()));
   }();
   return n;
 }
@@ -58,12 +92,15 @@ inline int prefaultThreads() {
 // Maps the pages of freshly allocated buffers from a few threads; joins in the destructor.
 //  * MADV_HUGEPAGE first: with transparent huge pages in "madvise" mode (this image, the GPU boxes) the range
 //    is then backed by 2 MiB pages — 1 200 faults instead of 576 000 for the 2.36 GB of a 10 M-point cloud.
-//    Measured on the GPU box's host: 4 KiB pages map at 16-23 GB/s whatever the thread count (and a device
-//    copy into untouched pages runs at 13 GB/s against 56 GB/s into mapped ones), which made the first
-//    touch of the outputs cost more than the PCIe transfer.
+//    Measured on the GPU box's host: 4 KiB pages map at 16-23 GB/s whatever the thread count and a device
+//    copy into untouched pages runs at 13-16 GB/s against 56 GB/s into mapped ones, which made the first
+//    touch of the outputs cost more than the PCIe transfer; huge pages map at 110 GB/s.
 //  * MADV_POPULATE_WRITE then maps them "as if written", contents untouched, so it may run while a
 //    device-to-host copy is already landing in them.  Where the kernel lacks the advice nothing is done and
 //    the pages fault on first use.
+//  * Order: the buffers are cut into 32 MiB segments that are mapped in the order of their relative position,
+//    i.e. all buffers advance front to back together — the order in which the chunks of the device pipeline
+//    arrive — so the mapping runs ahead of the copies after a head start of one chunk.
 class Prefault {
  public:
   Prefault() = default;
@@ -72,23 +109,36 @@ class Prefault {
   ~Prefault() { join(); }
   void add(void *p, size_t bytes) {
 #if defined(MADV_POPULATE_WRITE) && defined(MADV_HUGEPAGE)
-    const int threads = prefaultThreads();
-    if (threads <= 0 || bytes < (size_t(32) << 20)) return;
+    if (prefaultThreads() <= 0 || bytes < (size_t(32) << 20)) return;
     const size_t huge = size_t(2) << 20;
     const uintptr_t lo = (reinterpret_cast<uintptr_t>(p) + huge - 1) & ~(huge - 1);
     const uintptr_t hi = (reinterpret_cast<uintptr_t>(p) + bytes) & ~(huge - 1);
     if (hi <= lo) return;
     (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
-    const size_t pieces = std::min<size_t>(static_cast<size_t>(threads), (hi - lo) / (size_t(16) << 20) + 1);
-    const size_t per = (((hi - lo) / pieces) + huge - 1) & ~(huge - 1);
-    for (uintptr_t a = lo; a < hi; a += per) {
-      const size_t len = std::min<size_t>(per, hi - a);
-      pool_.emplace_back([a, len]() { (void)madvise(reinterpret_cast<void *>(a), len, MADV_POPULATE_WRITE); });
+    const size_t seg = size_t(32) << 20;
+    for (uintptr_t a = lo; a < hi; a += seg) {
+      segs_.push_back({a, std::min<size_t>(seg, hi - a), static_cast<double>(a - lo) / static_cast<double>(hi - lo)});
     }
 #else
     (void)p;
     (void)bytes;
 #endif
+  }
+  void start() {
+    if (segs_.empty()) return;
+    std::sort(segs_.begin(), segs_.end(), [](const Seg &x, const Seg &y) { return x.where < y.where; });
+    const int threads = std::min<int>(prefaultThreads(), static_cast<int>(segs_.size()));
+    for (int t = 0; t < threads; ++t) {
+      pool_.emplace_back([this]() {
+        for (;;) {
+          const size_t i = next_.fetch_add(1);
+          if (i >= segs_.size()) return;
+#ifdef MADV_POPULATE_WRITE
+          (void)madvise(reinterpret_cast<void *>(segs_[i].addr), segs_[i].len, MADV_POPULATE_WRITE);
+#endif
+        }
+      });
+    }
   }
   void join() {
     for (auto &t : pool_) t.join();
@@ -96,7 +146,14 @@ class Prefault {
   }
 
  private:
+  struct Seg {
+    uintptr_t addr;
+    size_t len;
+    double where;  // relative position inside its buffer
+  };
+  std::vector<Seg> segs_;
   std::vector<std::thread> pool_;
+  std::atomic<size_t> next_{0};
 };
 
 }  // namespace detail

@@ -246,6 +246,8 @@ PYBIND11_MODULE(spz, m) {
     return py::bytes(reinterpret_cast<const char *>(out.data()), out.size());
   }, py::arg("data"), py::arg("threads") = 8, py::arg("windows_per_chunk") = 32, py::arg("verify_prefix") = 0,
      "The multi-threaded writer with zlib's exact bytes (None when it declines the input).");
+  m.def("_effective_cpu_count", []() { return spz::effectiveCpuCount(); },
+        "CPUs the worker pools of the container stage size themselves by (online, affinity mask, cgroup quota).");
   m.def("_parallel_inflate_count", []() { return spz::pinflate::successCount(); },
         "Members inflated by the parallel single-stream reader so far in this process.");
   m.def("_decompress_gzipped", [](const py::bytes &data) -> py::object {

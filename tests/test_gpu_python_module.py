@@ -472,6 +472,14 @@ def test_whole_file_of_a_large_cloud_equals_the_reference_file(spz, reference):
     o.from_coord = spz.RDF
     want = reference.save_spz(c, n, deg, True, 6).tobytes()
     assert spz._save_spz_bytes(g, o) == want
+    # the same with the writer's opt-in checks switched on: SPZ_AMD_GZIP_VERIFY=1 inflates the finished member
+    # and compares it with the stream, =2 also runs zlib over the whole stream and compares the two members
+    for level in ("1", "2"):
+        os.environ["SPZ_AMD_GZIP_VERIFY"] = level
+        try:
+            assert spz._save_spz_bytes(g, o) == want, f"SPZ_AMD_GZIP_VERIFY={level}"
+        finally:
+            del os.environ["SPZ_AMD_GZIP_VERIFY"]
     u = spz.UnpackOptions()
     u.to_coord = spz.LUF
     back = spz._load_spz_bytes(want, u)

@@ -20,6 +20,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--launches", type=int, default=6)
+    ap.add_argument("--cases", default="", help="comma-separated substrings: run only the cases whose name contains one")
     ap.add_argument("--manifest", default=os.path.join(ROOT, "gpurun_out", "all_kernels_manifest.json"))
     a = ap.parse_args()
     import torch
@@ -31,8 +32,12 @@ def main():
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     manifest, rows = [], []
 
+    only = [c for c in a.cases.split(",") if c]
+
     def timed(case, kernels, alg_bytes, fn, note="", per_kernel_alg=None):
         """kernels: list of (name substring, dispatches per call) in dispatch order."""
+        if only and not any(c in case for c in only):
+            return
         fn()
         torch.cuda.synchronize()
         manifest.append({"case": case + " (warm-up)", "kernels": kernels, "calls": 1, "algorithmic_bytes": alg_bytes, "skip": True})
@@ -50,6 +55,23 @@ def main():
         rows.append(r)
         print(json.dumps(r), flush=True)
 
+    # what this box's memory system does on the guide's reference shape (a device-to-device copy of 1 GiB): boxes of
+    # the pool differ by more than 10 % on the same binary, so every row is to be read next to this figure
+    src = torch.empty(1 << 30, dtype=torch.uint8, device=dev).fill_(7)
+    dst = torch.empty_like(src)
+    dst.copy_(src)
+    torch.cuda.synchronize()
+    e = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    e[0].record()
+    for _ in range(10):
+        dst.copy_(src)
+    e[1].record()
+    torch.cuda.synchronize()
+    box = {"case": "box reference: torch device-to-device copy of 1 GiB (read + write)", "ms_per_call_events": round(e[0].elapsed_time(e[1]) / 10, 4),
+           "GBps": round(2 * (1 << 30) / (e[0].elapsed_time(e[1]) / 10) / 1e6, 1)}
+    print(json.dumps(box), flush=True)
+    rows.append(box)
+    del src, dst
     bpp = {0: 76, 1: 121, 2: 196, 3: 301}
     for n, deg, ver, tag in ((10_000_000, 3, 3, "10M sh3 v3"), (10_000_000, 0, 3, "10M sh0 v3"), (10_000_000, 1, 3, "10M sh1 v3"),
                              (1_000_000, 0, 2, "cfg2 1M sh0 v2")):
@@ -100,6 +122,8 @@ def main():
                   n * 48, lambda: abi.check(L.spz_amd_median_scale_sum_device(cloud["scales"].data_ptr(), n, ws.data_ptr(),
                                                                               med.data_ptr(), s), "median"),
                   note="algorithmic = 4 passes x 12 B per point")
+            if only and not any(c in "medianVolume" for c in only):
+                continue
             want = (cloud["scales"].view(-1, 3)[:, 0] + cloud["scales"].view(-1, 3)[:, 1] + cloud["scales"].view(-1, 3)[:, 2]).sort().values[n // 2]
             assert float(med[0]) == float(want), (float(med[0]), float(want))
             # the same on a distribution that puts every sum into ONE first-pass bin (sums in [-6, -4))

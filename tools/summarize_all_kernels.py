@@ -67,6 +67,22 @@ def main():
         if cc:
             rows = sorted((r for r in cc if short(r["Kernel_Name"]) and r["Counter_Name"] == counter), key=lambda r: int(r["Dispatch_Id"]))
             traffic[counter] = split([(short(r["Kernel_Name"]), float(r["Counter_Value"]) * 1024.0) for r in rows], manifest)
+    sq = {}
+    cc = load(tag, "sq", "counter_collection")
+    if cc:
+        for counter in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY"):
+            rows = sorted((r for r in cc if short(r["Kernel_Name"]) and r["Counter_Name"] == counter), key=lambda r: int(r["Dispatch_Id"]))
+            sq[counter] = split([(short(r["Kernel_Name"]), float(r["Counter_Value"])) for r in rows], manifest)
+
+    def sq_fields(i, name=None):
+        if len(sq) < 4:
+            return {}
+        tot = {c: sum((call[1][name] if name else call[0]) for call in sq[c][i]) for c in sq}
+        if tot["SQ_WAVES"] <= 0:
+            return {}
+        return {"valu_insts_per_wave": round(tot["SQ_INSTS_VALU"] / tot["SQ_WAVES"], 1),
+                "wait_fraction_of_wave_cycles": round(tot["SQ_WAIT_ANY"] / max(1.0, tot["SQ_WAVE_CYCLES"]), 3)}
+
     for i, case in enumerate(manifest["cases"]):
         if case.get("skip"):
             continue
@@ -86,6 +102,7 @@ def main():
                     row["hbm_read_bytes_per_call"] = round(rd)
                     row["hbm_write_bytes_per_call"] = round(wr)
                     row["traffic_over_algorithmic"] = round((rd + wr) / alg, 3)
+                row.update(sq_fields(i, name))
                 res["rows"].append(row)
             continue
         row = {"case": case["case"], "kernels": sorted({k for k, _ in case["kernels"]}), "algorithmic_bytes_per_call": case["algorithmic_bytes"]}
@@ -109,13 +126,18 @@ def main():
             row["hbm_read_bytes_per_call"] = round(rd)
             row["hbm_write_bytes_per_call"] = round(wr)
             row["traffic_over_algorithmic"] = round((rd + wr) / case["algorithmic_bytes"], 3)
+        row.update(sq_fields(i))
         res["rows"].append(row)
     res["event_rows_of_the_stats_run"] = manifest.get("event_rows")
     out = os.path.join(ROOT, "profiles", f"{tag}_all_kernels.json")
     with open(out, "w") as f:
         json.dump(res, f, indent=1)
+    box = [r for r in (manifest.get("event_rows") or []) if r["case"].startswith("box reference")]
+    if box:
+        res["box_reference"] = box[0]
+        print(f"box reference copy: {box[0]['GBps']} GB/s")
     for r in res["rows"]:
-        print(f"{r['case'][:58]:58s} {r.get('kernel_us_avg', 0):9.1f} us  {r.get('frac_of_8TBps', 0):5.3f}  traffic/alg {r.get('traffic_over_algorithmic', '-')}")
+        print(f"{r['case'][:58]:58s} {r.get('kernel_us_avg', 0):9.1f} us  {r.get('frac_of_8TBps', 0):5.3f}  traffic/alg {r.get('traffic_over_algorithmic', '-')}  valu/wave {r.get('valu_insts_per_wave', '-')}")
 
 
 if __name__ == "__main__":
