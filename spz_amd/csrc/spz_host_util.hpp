@@ -89,18 +89,28 @@ inline int prefaultThreads() {
   return n;
 }
 
+// The outputs are mapped BEFORE the device call starts (default).  Mapping them beside it (SPZ_AMD_PREFAULT_CONCURRENT=1)
+// looked better on paper and measured worse: the copies' own pinning of source and destination pages and the
+// populate threads contend in the kernel's mm (10 M SH3 unpack: 79 ms mapped first, 119 ms side by side).
+inline bool prefaultJoinFirst() {
+  static const bool v = []() {
+    const char *e = std::getenv("SPZ_AMD_PREFAULT_CONCURRENT");
+    return !(e && std::atoi(e) != 0);
+  }();
+  return v;
+}
+
 // Maps the pages of freshly allocated buffers from a few threads; joins in the destructor.
 //  * MADV_HUGEPAGE first: with transparent huge pages in "madvise" mode (this image, the GPU boxes) the range
 //    is then backed by 2 MiB pages — 1 200 faults instead of 576 000 for the 2.36 GB of a 10 M-point cloud.
 //    Measured on the GPU box's host: 4 KiB pages map at 16-23 GB/s whatever the thread count and a device
 //    copy into untouched pages runs at 13-16 GB/s against 56 GB/s into mapped ones, which made the first
 //    touch of the outputs cost more than the PCIe transfer; huge pages map at 110 GB/s.
-//  * MADV_POPULATE_WRITE then maps them "as if written", contents untouched, so it may run while a
-//    device-to-host copy is already landing in them.  Where the kernel lacks the advice nothing is done and
-//    the pages fault on first use.
-//  * Order: the buffers are cut into 32 MiB segments that are mapped in the order of their relative position,
-//    i.e. all buffers advance front to back together — the order in which the chunks of the device pipeline
-//    arrive — so the mapping runs ahead of the copies after a head start of one chunk.
+//  * MADV_POPULATE_WRITE then maps them "as if written", contents untouched (so it could also run while a
+//    device-to-host copy is landing in them).  Where the kernel lacks the advice nothing is done and the
+//    pages fault on first use.
+//  * The buffers are cut into 32 MiB segments, taken by the threads in the order of their relative position
+//    (all buffers advance front to back together: the order in which the chunks of the device pipeline arrive).
 class Prefault {
  public:
   Prefault() = default;
@@ -139,6 +149,7 @@ class Prefault {
         }
       });
     }
+    if (prefaultJoinFirst()) join();
   }
   void join() {
     for (auto &t : pool_) t.join();

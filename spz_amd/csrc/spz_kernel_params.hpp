@@ -82,14 +82,23 @@ namespace spz_amd_detail {
 // Interleaved grid: the tiles of the sections are dealt out in a repeating pattern (each section gets slots in
 // proportion to its tile count) instead of section after section, so that at any moment the resident
 // blocks are the launch's average mix of arithmetic-heavy (rotations) and traffic-heavy (sh) tiles.
-// 0: never, 1: always, 2: by the measured policy (profiles/r02_tune_a_*.jsonl, 10 M points): encode gains
-// without sh (+6 %: the rotation tiles no longer run as one arithmetic-bound phase) and loses with sh3
-// (-4 %); decode gains with sh (+7 % sh3, +16 % sh1) and loses without (-13 %: five equal streams at once).
+// 0: never, 1: always, 2: by the measured policy (profiles/r02_tune_*.jsonl, 10 M points, five boxes): encode
+// gains without sh (+4...6 %: the rotation tiles no longer run as one arithmetic-bound phase) and loses with sh3
+// (-4 %); decode gains with sh of degree 1 and 2 (+11...16 %), loses without sh (up to -13 %: five equal
+// streams at once) and at degree 3 depends on the box (+7 %, +9 %, -6 %, -7 %), so it stays sequential there.
 #ifndef SPZ_ENC_INTERLEAVE
 #define SPZ_ENC_INTERLEAVE 2
 #endif
 #ifndef SPZ_DEC_INTERLEAVE
 #define SPZ_DEC_INTERLEAVE 2
+#endif
+// Tuning switches of the interleaved grid: runs of SPZ_IL_GROUP consecutive tiles (a power of two) per pattern slot;
+// SPZ_IL_ONLY_ROT = 1 interleaves only the rotation tiles into the largest section, the rest stays sequential.
+#ifndef SPZ_IL_GROUP
+#define SPZ_IL_GROUP 1
+#endif
+#ifndef SPZ_IL_ONLY_ROT
+#define SPZ_IL_ONLY_ROT 0
 #endif
 #ifndef SPZ_QUAT_FAST
 #define SPZ_QUAT_FAST 1

@@ -628,9 +628,10 @@ struct TileRef { uint32_t si, tl; };
 __device__ __forceinline__ TileRef locate_tile(const KParams &p, uint32_t tile) {
   TileRef t;
   if (tile < p.il_tiles) {
-    const uint32_t rep = tile / kIlPeriod, k = tile - rep * kIlPeriod;
+    const uint32_t group = tile / (uint32_t)SPZ_IL_GROUP, within = tile % (uint32_t)SPZ_IL_GROUP;
+    const uint32_t rep = group / kIlPeriod, k = group - rep * kIlPeriod;
     t.si = p.il_sec[k];
-    t.tl = rep * p.il_count[t.si] + p.il_rank[k];
+    t.tl = (rep * p.il_count[t.si] + p.il_rank[k]) * (uint32_t)SPZ_IL_GROUP + within;
   } else {
     t.si = find_section(p, tile);
     t.tl = tile - p.sec[t.si].tile_begin + p.sec[t.si].tile_skip;

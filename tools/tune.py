@@ -40,6 +40,12 @@ VARIANTS = {
     "u8_il_dec": {"enc": "256 x 8, sequential", "dec": "256 x 8, interleaved",
                   "defs": {"SPZ_ENC_UNROLL": 8, "SPZ_DEC_UNROLL": 8, "SPZ_ENC_INTERLEAVE": 0, "SPZ_DEC_INTERLEAVE": 1}},
     "policy_b": {"enc": "shipped, second copy (noise floor)", "dec": "same", "defs": {}},
+    "il_g8": {"enc": "interleaved, runs of 8 tiles", "dec": "same", "defs": {"SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 1, "SPZ_IL_GROUP": 8}},
+    "il_g32": {"enc": "interleaved, runs of 32 tiles", "dec": "same", "defs": {"SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 1, "SPZ_IL_GROUP": 32}},
+    "il_rot": {"enc": "only the rotation tiles interleaved into the largest section", "dec": "same",
+               "defs": {"SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 1, "SPZ_IL_ONLY_ROT": 1}},
+    "il_rot_g8": {"enc": "rotation tiles only, runs of 8", "dec": "same",
+                  "defs": {"SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 1, "SPZ_IL_ONLY_ROT": 1, "SPZ_IL_GROUP": 8}},
 }
 
 
