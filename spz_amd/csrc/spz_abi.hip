@@ -446,9 +446,9 @@ int decode_impl(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr,
     p.plain_tiles = (uint32_t)plain;
   }
 #endif
-  // policy: with sh of degree 1 or 2 (every box measured gains, 11-16 %); not without sh (loses up to 13 %) and not at
-  // degree 3, where the boxes of the pool split (+7 % and +9 % on two, -6 % and -7 % on two others)
-  if (!SPZ_DEC_REVERSE && (SPZ_DEC_INTERLEAVE == 1 || (SPZ_DEC_INTERLEAVE == 2 && sd > 0 && sd < 15))) interleave_sections(&p);
+  // policy: with an sh section (every box measured gains at degrees 1 and 2; at degree 3 with runs of 8 tiles, see
+  // SPZ_IL_GROUP); not without sh (loses up to 13 %)
+  if (!SPZ_DEC_REVERSE && (SPZ_DEC_INTERLEAVE == 1 || (SPZ_DEC_INTERLEAVE == 2 && sd > 0))) interleave_sections(&p);
   uint32_t grid = 1;
   rc = grid_for(device, p.total_tiles, &grid);
   if (rc != SPZ_AMD_OK) return rc;

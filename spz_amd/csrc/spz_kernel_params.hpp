@@ -82,20 +82,24 @@ namespace spz_amd_detail {
 // Interleaved grid: the tiles of the sections are dealt out in a repeating pattern (each section gets slots in
 // proportion to its tile count) instead of section after section, so that at any moment the resident
 // blocks are the launch's average mix of arithmetic-heavy (rotations) and traffic-heavy (sh) tiles.
-// 0: never, 1: always, 2: by the measured policy (profiles/r02_tune_*.jsonl, 10 M points, five boxes): encode
-// gains without sh (+4...6 %: the rotation tiles no longer run as one arithmetic-bound phase) and loses with sh3
-// (-4 %); decode gains with sh of degree 1 and 2 (+11...16 %), loses without sh (up to -13 %: five equal
-// streams at once) and at degree 3 depends on the box (+7 %, +9 %, -6 %, -7 %), so it stays sequential there.
+// 0: never, 1: always, 2: by the measured policy (profiles/r02_tune_*.jsonl, 10 M points, six boxes): encode
+// gains without sh (+4...6 %: the rotation tiles no longer run as one arithmetic-bound phase) and loses with sh
+// (-3...5 %); decode gains with sh (+8...16 %; degree 3: see SPZ_IL_GROUP) and loses without (up to -13 %: five
+// equal streams at once).
 #ifndef SPZ_ENC_INTERLEAVE
 #define SPZ_ENC_INTERLEAVE 2
 #endif
 #ifndef SPZ_DEC_INTERLEAVE
 #define SPZ_DEC_INTERLEAVE 2
 #endif
-// Tuning switches of the interleaved grid: runs of SPZ_IL_GROUP consecutive tiles (a power of two) per pattern slot;
+// The interleaved grid deals RUNS of SPZ_IL_GROUP consecutive tiles (a power of two) per pattern slot.  8 = one tile
+// per XCD (the dispatcher deals consecutive blocks round-robin over the eight XCDs), so inside a run the eight
+// XCDs write one contiguous 128 KiB window exactly as in the sequential order.  With single tiles (1) the gain of
+// the sh3 decode depended on the box (+7 %, +9 %, +12 % on three, -5 %, -6 %, -7 % on three others); with runs
+// of 8 it was +12 % on a box of the first kind and -0.5 % on one of the second (profiles/r02_tune_f_*, r02_tune_g_*).
 // SPZ_IL_ONLY_ROT = 1 interleaves only the rotation tiles into the largest section, the rest stays sequential.
 #ifndef SPZ_IL_GROUP
-#define SPZ_IL_GROUP 1
+#define SPZ_IL_GROUP 8
 #endif
 #ifndef SPZ_IL_ONLY_ROT
 #define SPZ_IL_ONLY_ROT 0

@@ -8,8 +8,8 @@ mkdir -p $O
 cd $R
 { rocm-smi --showmemorypartition --showcomputepartition --showclocks --showpower --showmaxpower --showperflevel 2>&1 | grep -v "^=" | head -40; rocminfo 2>/dev/null | grep -E "Marketing Name|Compute Unit|Max Clock|Memory Properties|Size:" | head -20; } > $O/box_info_$TAG.txt 2>&1
 grep -E "partition|sclk|mclk|fclk|Power|Marketing" $O/box_info_$TAG.txt | head -20
-V=quat_fast,il_both,il_g8,il_g32,il_rot,il_rot_g8,policy
-for deg in 3 1 0; do
+V=seq,il_g1,il_g4,il_g8,il_g16,il_g64,policy
+for deg in 3 2 1 0; do
 timeout -k 10 200 python tools/tune.py run --deg $deg --rounds 11 --variants $V > $O/tune_${TAG}_sh$deg.jsonl 2>&1 || { echo "tune sh$deg failed"; tail -n 5 $O/tune_${TAG}_sh$deg.jsonl; exit 3; }
 done
 TAGX=$TAG python - <<'PY'

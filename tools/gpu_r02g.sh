@@ -12,11 +12,11 @@ tail -n 6 $O/pytest_gpu_$TAG.log
 if [ $rc -ne 0 ]; then echo "pytest rc=$rc: stopping"; exit $rc; fi
 timeout -k 10 200 ./spz_amd/bin/host_bench 10000000 3 4 1 > $O/host_bench_$TAG.json 2>&1 || { echo "host_bench failed"; tail -n 5 $O/host_bench_$TAG.json; exit 3; }
 cat $O/host_bench_$TAG.json
-V=quat_fast,il_both,il_g8,il_rot_g8,policy,policy_b
+V=seq,il_g1,il_g8,policy,policy_b
 for deg in 3 2; do
 timeout -k 10 200 python tools/tune.py run --deg $deg --rounds 11 --variants $V > $O/tune_${TAG}_sh$deg.jsonl 2>&1 || { echo "tune sh$deg failed"; tail -n 5 $O/tune_${TAG}_sh$deg.jsonl; exit 3; }
 done
-timeout -k 10 200 python tools/tune.py run --deg 0 --version 2 --points 1000000 --rounds 30 --batch 20 --variants quat_fast,policy,policy_b > $O/tune_${TAG}_cfg2.jsonl 2>&1 || { echo "tune cfg2 failed"; exit 3; }
+timeout -k 10 200 python tools/tune.py run --deg 0 --version 2 --points 1000000 --rounds 30 --batch 20 --variants quat_ieee,seq,policy,policy_b > $O/tune_${TAG}_cfg2.jsonl 2>&1 || { echo "tune cfg2 failed"; exit 3; }
 TAGX=$TAG python - <<'PY'
 import json,glob,os
 tag=os.environ.get("TAGX")

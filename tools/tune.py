@@ -26,26 +26,21 @@ def D(block=256, unroll=4, wc=0, ntl=0, nts=0):
 
 # Round-2 experiments (the round-1 geometry / non-temporal / reverse-order tables are in git history and
 # profiles/r01_tune_*.jsonl).  Every variant is the shipped configuration plus the listed macros.
+_IL = {"SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 1}
 VARIANTS = {
-    "quat_ieee": {"enc": "plain IEEE divisions, no interleave", "dec": "same",
+    "quat_ieee": {"enc": "plain IEEE divisions, sequential grid", "dec": "same",
                   "defs": {"SPZ_QUAT_FAST": 0, "SPZ_ENC_INTERLEAVE": 0, "SPZ_DEC_INTERLEAVE": 0}},
-    "quat_fast": {"enc": "fast exact divisions, no interleave", "dec": "same",
-                  "defs": {"SPZ_ENC_INTERLEAVE": 0, "SPZ_DEC_INTERLEAVE": 0}},
-    "il_enc": {"enc": "sections interleaved", "dec": "sequential", "defs": {"SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 0}},
-    "il_dec": {"enc": "sequential", "dec": "sections interleaved", "defs": {"SPZ_ENC_INTERLEAVE": 0, "SPZ_DEC_INTERLEAVE": 1}},
-    "il_both": {"enc": "sections interleaved", "dec": "sections interleaved",
-                "defs": {"SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 1}},
-    "policy": {"enc": "shipped: interleave by policy", "dec": "same", "defs": {}},
-    "u8_policy": {"enc": "256 x 8 units, policy", "dec": "256 x 8 units, policy", "defs": {"SPZ_ENC_UNROLL": 8, "SPZ_DEC_UNROLL": 8}},
-    "u8_il_dec": {"enc": "256 x 8, sequential", "dec": "256 x 8, interleaved",
-                  "defs": {"SPZ_ENC_UNROLL": 8, "SPZ_DEC_UNROLL": 8, "SPZ_ENC_INTERLEAVE": 0, "SPZ_DEC_INTERLEAVE": 1}},
+    "seq": {"enc": "sequential grid (sections one after another)", "dec": "same",
+            "defs": {"SPZ_ENC_INTERLEAVE": 0, "SPZ_DEC_INTERLEAVE": 0}},
+    "il_g1": {"enc": "interleaved, single tiles", "dec": "same", "defs": dict(_IL, SPZ_IL_GROUP=1)},
+    "il_g4": {"enc": "interleaved, runs of 4 tiles", "dec": "same", "defs": dict(_IL, SPZ_IL_GROUP=4)},
+    "il_g8": {"enc": "interleaved, runs of 8 tiles", "dec": "same", "defs": dict(_IL, SPZ_IL_GROUP=8)},
+    "il_g16": {"enc": "interleaved, runs of 16 tiles", "dec": "same", "defs": dict(_IL, SPZ_IL_GROUP=16)},
+    "il_g64": {"enc": "interleaved, runs of 64 tiles", "dec": "same", "defs": dict(_IL, SPZ_IL_GROUP=64)},
+    "il_rot_g8": {"enc": "rotation tiles only, runs of 8", "dec": "same", "defs": dict(_IL, SPZ_IL_ONLY_ROT=1, SPZ_IL_GROUP=8)},
+    "policy": {"enc": "shipped: interleave by policy, runs of 8", "dec": "same", "defs": {}},
     "policy_b": {"enc": "shipped, second copy (noise floor)", "dec": "same", "defs": {}},
-    "il_g8": {"enc": "interleaved, runs of 8 tiles", "dec": "same", "defs": {"SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 1, "SPZ_IL_GROUP": 8}},
-    "il_g32": {"enc": "interleaved, runs of 32 tiles", "dec": "same", "defs": {"SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 1, "SPZ_IL_GROUP": 32}},
-    "il_rot": {"enc": "only the rotation tiles interleaved into the largest section", "dec": "same",
-               "defs": {"SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 1, "SPZ_IL_ONLY_ROT": 1}},
-    "il_rot_g8": {"enc": "rotation tiles only, runs of 8", "dec": "same",
-                  "defs": {"SPZ_ENC_INTERLEAVE": 1, "SPZ_DEC_INTERLEAVE": 1, "SPZ_IL_ONLY_ROT": 1, "SPZ_IL_GROUP": 8}},
+    "u8_policy": {"enc": "256 x 8 units, policy", "dec": "256 x 8 units, policy", "defs": {"SPZ_ENC_UNROLL": 8, "SPZ_DEC_UNROLL": 8}},
 }
 
 
