@@ -8,7 +8,7 @@ from conftest import ROOT
 
 
 def test_committed_bench_line_has_the_contract_fields():
-    with open(os.path.join(ROOT, "profiles", "r01_bench.json")) as f:
+    with open(os.path.join(ROOT, "profiles", "r02_bench.json")) as f:
         r = json.load(f)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
@@ -19,8 +19,13 @@ def test_committed_bench_line_has_the_contract_fields():
     n = r["config"]["points_per_gpu"]
     assert abs(r["value"] - n / (r["ms_per_step"] * 1e-3)) < 1e-6 * r["value"]
     rf = r["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source"):
         assert k in rf, k
+    # the traffic figure is never presented as measured by the bench run itself, and only repeated for the kernels
+    # it was measured on
+    src = rf["traffic_source"]
+    assert src["measured_in_this_run"] is False and "kernel_source_sha256" in src
+    assert (rf["traffic"] is not None) == bool(src.get("matches_this_workload") and src.get("matches_current_kernel_sources"))
     assert rf["bound"] == "hbm" and rf["unit"] == "GB/s" and rf["peak"] == 8000.0
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-9
     assert abs(rf["achieved"] - rf["algorithmic_bytes_per_launch"] / (rf["avg_launch_ms"] * 1e-3) / 1e9) < 1e-6 * rf["achieved"]

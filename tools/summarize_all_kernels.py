@@ -28,7 +28,7 @@ def load(tag, kind, suffix):
     pats = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_all_{kind}_{tag}", "**", f"*_{suffix}.csv"), recursive=True)
     if not pats:
         return None
-    with open(pats[0]) as f:
+    with open(max(pats, key=os.path.getmtime)) as f:   # a tag that was run twice: the newest files
         return list(csv.DictReader(f))
 
 

@@ -19,7 +19,7 @@ csv.field_size_limit(1 << 30)
 
 def find(tag, kind, suffix):
     pats = glob.glob(os.path.join(ROOT, "gpurun_out", f"prof_{kind}_{tag}", "**", f"*_{suffix}.csv"), recursive=True)
-    return pats[0] if pats else None
+    return max(pats, key=os.path.getmtime) if pats else None   # a tag that was run twice: the newest files
 
 
 def short(name):
