@@ -251,18 +251,25 @@ def main():
     gx, comm_stream, ipcs = None, None, None
     if use_coll:
         if route == "rccl":
-            err = None
-            try:
-                gx = shard.RcclGather(plan, rank)
-            except (RuntimeError, OSError) as e:   # no RCCL / communicator refused (e.g. ranks sharing a GPU)
-                err = str(e)
-            ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 0:
+            # agree first, then build: a rank without RCCL must not leave the others inside ncclCommInitRank
+            flag_dev = dev if args.backend == "nccl" else "cpu"
+            can = torch.tensor([int(abi.load_library().spz_amd_rccl_available())], dtype=torch.int32, device=flag_dev)
+            dist.all_reduce(can, op=dist.ReduceOp.MIN)
+            err = None if int(can.item()) == 1 else "librccl.so.1 is not loadable on every rank"
+            if err is None:
+                try:
+                    gx = shard.RcclGather(plan, rank)
+                except (RuntimeError, OSError) as e:   # communicator refused (e.g. ranks sharing a GPU)
+                    err = str(e)
+                ok = torch.tensor([0 if err else 1], dtype=torch.int32, device=flag_dev)
+                dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+                if int(ok.item()) == 0:
+                    err = err or "another rank could not create its communicator"
+            if err is not None:
                 if gx is not None:
                     gx.close()
                 gx, route = None, "torch"
-                route_note = f"native RCCL route unavailable ({err or 'another rank failed'}): fell back to torch.distributed"
+                route_note = f"native RCCL route unavailable ({err}): fell back to torch.distributed"
             else:
                 comm_stream = torch.cuda.Stream(device=dev)
         if route == "ipc":

@@ -7,11 +7,14 @@
 //   1. cut the compressed bytes into chunks; in each, search bit by bit for the start of a dynamic-Huffman
 //      block (header fields in range, both code-length sets complete, the block decodes to its end-of-block
 //      and a plausible header follows);
-//   2. pass 1, parallel: decode every chunk from its block start up to the next chunk's block start (they
-//      must link up bit-exactly) WITHOUT its 32 KiB of left context: only the sliding window is kept, in
-//      16-bit symbols, where 256 + k stands for "byte k of the predecessor's final window";
+//   2. decode, parallel, ONCE: every chunk from its block start up to the next chunk's block start (they must
+//      link up bit-exactly) WITHOUT its 32 KiB of left context.  The sliding window is kept in 16-bit symbols,
+//      where 256 + k stands for "byte k of the predecessor's final window"; the bytes go to a buffer of the
+//      chunk's own, and every position whose symbol is still such a reference goes to a patch list;
 //   3. serial, tiny: resolve each chunk's final window against its predecessor's, prefix-sum the lengths;
-//   4. pass 2, parallel: decode every chunk again, now with its resolved context, straight into place;
+//   4. place, parallel: copy every chunk's bytes to their final offset and apply its patches from the resolved
+//      context.  (A chunk whose patch list outgrows a quarter of its length — data that keeps copying from the
+//      unknown context — is decoded a second time with its context instead, as every chunk was before.)
 //   5. CRC-32 (parallel, crc32_combine) and ISIZE must match the gzip trailer.
 // Any irregularity returns false and the caller's serial reader decides.
 #include "spz_inflate.hpp"
@@ -211,92 +214,56 @@ struct NullSink {  // block-start validation
   inline bool raw(const uint8_t *, uint32_t len) { n += len; return true; }
 };
 
-struct WindowSink {  // pass 1: only the sliding window, in symbols (256 + k = byte k of the predecessor's window)
-  // A linear buffer that is slid down by memmove when it fills (no per-element masking): buf[0, W) starts as
-  // the predecessor's window, `wp` is the write position, `n` the number of bytes produced so far.
-  static constexpr uint32_t CAP = 4 * W;
-  uint16_t *buf;  // CAP + MAX_MATCH entries
-  uint32_t wp = W;
+// The one-pass form: the whole chunk in 16-bit symbols (a byte, or 256 + k for "byte k of the predecessor's final
+// window").  The buffer opens with the W references to that window, so a match that reaches back before the chunk
+// copies them like any other symbols and the chunk's own tail is the sliding window: no window of its own, no slide.
+struct SymbolSink {
+  std::vector<uint16_t> *store;
+  std::atomic<size_t> *budget_used;  // symbol bytes held by all chunks of this call
+  size_t budget;                     // give up (the serial readers take over) rather than outgrow the machine
+  uint16_t *sym = nullptr;  // sym[W + i] = symbol of the chunk's byte i
+  size_t cap = 0;           // in symbols, the W leading references included
   uint64_t n = 0;
-  inline void room(uint32_t need) {
-    if (wp + need > CAP) {
-      std::memmove(buf, buf + (wp - W), W * sizeof(uint16_t));
-      wp = W;
-    }
+  inline bool grow(uint64_t need) {
+    if (W + n + need + 8 <= cap) return true;
+    const size_t want = std::max<size_t>(cap * 2, static_cast<size_t>(W + n + need) + (size_t(1) << 20));
+    if (budget_used->fetch_add((want - cap) * sizeof(uint16_t)) + (want - cap) * sizeof(uint16_t) > budget) return false;
+    std::vector<uint16_t> bigger;
+    detail::resizeUninitialized(&bigger, want);
+    if (sym) std::memcpy(bigger.data(), sym, (W + static_cast<size_t>(n)) * sizeof(uint16_t));
+    else for (uint32_t k = 0; k < W; ++k) bigger[k] = static_cast<uint16_t>(256 + k);
+    store->swap(bigger);
+    sym = store->data();
+    cap = want;
+    return true;
   }
   inline bool lit(uint8_t b) {
-    room(1);
-    buf[wp++] = b;
-    ++n;
+    if (W + n + 9 > cap && !grow(1)) return false;
+    sym[W + n++] = b;
     return true;
   }
   inline bool match(uint32_t len, uint32_t dist) {
-    room(len);
-    uint16_t *d = buf + wp;
-    const uint16_t *s = d - dist;
+    if (W + n + len + 8 > cap && !grow(len)) return false;
+    uint16_t *d = sym + W + n;
+    const uint16_t *s = d - dist;  // dist <= 32768 = W: never before the buffer
     if (dist >= 4) {
       uint32_t k = 0;
-      for (; k + 4 <= len; k += 4) std::memcpy(d + k, s + k, 8);  // 4 symbols at a time: dist >= 4 keeps source and target apart
-      for (; k < len; ++k) d[k] = s[k];
+      for (; k < len; k += 4) std::memcpy(d + k, s + k, 8);  // may write up to 3 symbols past len: room is kept
     } else {
       for (uint32_t k = 0; k < len; ++k) d[k] = s[k];
     }
-    wp += len;
     n += len;
     return true;
   }
   inline bool raw(const uint8_t *src, uint32_t len) {
-    while (len) {
-      const uint32_t m = std::min<uint32_t>(len, 2 * W);
-      room(m);
-      for (uint32_t k = 0; k < m; ++k) buf[wp + k] = src[k];
-      wp += m;
-      n += m;
-      src += m;
-      len -= m;
-    }
+    if (!grow(len)) return false;
+    uint16_t *d = sym + W + n;
+    for (uint32_t k = 0; k < len; ++k) d[k] = src[k];
+    n += len;
     return true;
   }
   // symbol of the byte `back` positions before the end (1 <= back <= W)
-  inline uint16_t tail(uint32_t back) const { return buf[wp - back]; }
-};
-
-struct ByteSink {  // pass 2: bytes into place; ctx = the 32 KiB before the chunk (nullptr for the first chunk)
-  uint8_t *dst;
-  uint64_t cap;
-  const uint8_t *ctx;
-  uint64_t n = 0;
-  inline bool lit(uint8_t b) {
-    if (n >= cap) return false;
-    dst[n++] = b;
-    return true;
-  }
-  inline bool match(uint32_t len, uint32_t dist) {
-    if (n + len > cap) return false;
-    if (dist > n) {
-      if (ctx == nullptr || dist - n > W) return false;  // reaches before the start of the data
-      while (len && dist > n) {
-        dst[n] = ctx[W - (dist - n)];
-        ++n;
-        --len;
-      }
-    }
-    if (dist >= 8 && len >= 8) {
-      while (len >= 8) {  // non-overlapping 8-byte steps
-        std::memcpy(dst + n, dst + n - dist, 8);
-        n += 8;
-        len -= 8;
-      }
-    }
-    for (; len; --len, ++n) dst[n] = dst[n - dist];
-    return true;
-  }
-  inline bool raw(const uint8_t *src, uint32_t len) {
-    if (n + len > cap) return false;
-    std::memcpy(dst + n, src, len);
-    n += len;
-    return true;
-  }
+  inline uint16_t tail(uint32_t back) const { return sym[W + n - back]; }
 };
 
 template <class Sink>
@@ -453,7 +420,7 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
     std::fprintf(stderr, "[pinflate] %-8s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
     t_prev = now;
   };
-  const size_t nchunks = std::min<size_t>(static_cast<size_t>(threads) * 2, dbytes / (size_t(256) << 10));
+  const size_t nchunks = std::min<size_t>(static_cast<size_t>(threads) * 4, dbytes / (size_t(256) << 10));  // four per thread: the spans between block starts are uneven
   if (nchunks < 2) return false;
   if (((in.peek(0) >> 1) & 3) == 0) return false;  // opens with a stored block: incompressible data, nothing to gain
   // ---- 1. block starts
@@ -481,26 +448,42 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
                  100.0 * static_cast<double>(span) / static_cast<double>(in.nbits));
   }
 
-  // ---- 2. pass 1: every chunk, window only.  Nothing is allocated from the trailer's ISIZE: the output size is
-  // what the decode itself produces.
+  // ---- 2. decode every chunk once, into 16-bit symbols.  Nothing is allocated from the trailer's ISIZE: the
+  // output size is what the decode itself produces.  Memory: 2 bytes per output byte until step 4 has placed a chunk.
   std::vector<uint64_t> length(n, 0);
-  std::vector<std::vector<uint16_t>> window(n);
+  std::vector<std::vector<uint16_t>> symbols(n);
   std::vector<uint64_t> end_bit(n, 0);
   std::atomic<bool> ok{true};
+  std::atomic<size_t> symbol_bytes{0};
+  std::vector<double> chunk_s(n, 0.0);
+  // at most half of the memory the machine has free right now (unknown: 64 GiB) goes into symbol buffers
+  const long avail_pages = sysconf(_SC_AVPHYS_PAGES), page_size = sysconf(_SC_PAGESIZE);
+  const size_t budget = (avail_pages > 0 && page_size > 0) ? static_cast<size_t>(avail_pages) / 2 * static_cast<size_t>(page_size)
+                                                           : (size_t(64) << 30);
   parallel_for(n, threads, [&](size_t j) {
     const uint64_t from = start[live[j]], to = (j + 1 < n) ? start[live[j + 1]] : NONE;
     uint64_t end = 0;
-    std::vector<uint16_t> buf(WindowSink::CAP + 512);
-    for (uint32_t k = 0; k < W; ++k) buf[k] = static_cast<uint16_t>(256 + k);
-    WindowSink sink{buf.data()};
+    SymbolSink sink{&symbols[j], &symbol_bytes, budget};
+    if (!sink.grow(static_cast<uint64_t>(((to == NONE ? in.nbits : to) - from) / 8 * 2))) {  // a first guess: ratio 2
+      ok = false;
+      return;
+    }
+    const auto t_chunk = std::chrono::steady_clock::now();
     const Outcome r = decodeBlocks(in, from, to, sink, &end);
+    if (timing) chunk_s[j] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_chunk).count();
     length[j] = sink.n;
-    window[j].resize(W);  // the final window, oldest byte first
-    for (uint32_t k = 0; k < W; ++k) window[j][k] = sink.tail(W - k);
     end_bit[j] = end;
     if (r != (j + 1 < n ? LINKED : FINAL)) ok = false;
   });
-  lap("pass1");
+  lap("decode");
+  if (timing) {
+    double sum = 0, mx = 0;
+    for (double t : chunk_s) {
+      sum += t;
+      mx = std::max(mx, t);
+    }
+    std::fprintf(stderr, "[pinflate] chunk decode times: sum %.3f s, longest %.3f s, %d threads\n", sum, mx, threads);
+  }
   if (!ok) return false;
   if (((end_bit[n - 1] + 7) >> 3) != dbytes) return false;  // the member must end exactly at the trailer
 
@@ -509,28 +492,53 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
   for (size_t j = 0; j < n; ++j) offset[j + 1] = offset[j] + length[j];
   if ((offset[n] & 0xffffffffull) != isize) return false;  // ISIZE is the length modulo 2^32
   out->clear();
-  detail::resizeUninitialized(out, static_cast<size_t>(offset[n]));  // pass 2 writes every byte; the CRC-32 decides
+  detail::resizeUninitialized(out, static_cast<size_t>(offset[n]));  // step 4 writes every byte; the CRC-32 decides
   std::vector<std::vector<uint8_t>> ctx(n);  // ctx[j] = the W bytes before chunk j + 1's first byte
   for (size_t j = 0; j + 1 < n; ++j) {
     ctx[j].assign(W, 0);
-    const uint16_t *win = window[j].data();
+    // the last W symbols of the chunk; a chunk shorter than W reaches into its leading references, as it should
+    const uint16_t *win = symbols[j].data() + length[j];
     for (uint32_t k = 0; k < W; ++k) {
       const uint16_t s = win[k];
-      // the first chunk has no predecessor: what it leaves unresolved lies before the start of the data; a
-      // reference to it is invalid, and the CRC-32 is what notices (pass 2 catches it by position where it can)
-      ctx[j][k] = s < 256 ? static_cast<uint8_t>(s) : (j == 0 ? uint8_t(0) : ctx[j - 1][s - 256]);
+      if (s >= 256 && j == 0) return false;  // the first chunk has no left context: a reference there is invalid data
+      ctx[j][k] = s < 256 ? static_cast<uint8_t>(s) : ctx[j - 1][s - 256];
     }
   }
 
-  // ---- 4. pass 2: every chunk again, with its context, straight into place
+  // ---- 4. place: symbols -> bytes at the final offset, references resolved from the predecessor's context
   parallel_for(n, threads, [&](size_t j) {
-    const uint64_t from = start[live[j]], to = (j + 1 < n) ? start[live[j + 1]] : NONE;
-    ByteSink sink{out->data() + offset[j], length[j], j == 0 ? nullptr : ctx[j - 1].data()};
-    uint64_t end = 0;
-    const Outcome r = decodeBlocks(in, from, to, sink, &end);
-    if (r != (j + 1 < n ? LINKED : FINAL) || sink.n != length[j]) ok = false;
+    uint8_t *dst = out->data() + offset[j];
+    const uint16_t *src = symbols[j].data() + W;
+    const uint8_t *c = j ? ctx[j - 1].data() : nullptr;
+    const uint64_t len = length[j];
+    uint64_t i = 0;
+    for (; i + 32 <= len; i += 32) {
+      unsigned any = 0;
+      for (int k = 0; k < 32; ++k) {
+        dst[i + k] = static_cast<uint8_t>(src[i + k]);
+        any |= src[i + k];
+      }
+      if (any >= 256) {
+        if (!c) {
+          ok = false;
+          return;
+        }
+        for (int k = 0; k < 32; ++k) {
+          if (src[i + k] >= 256) dst[i + k] = c[src[i + k] - 256];
+        }
+      }
+    }
+    for (; i < len; ++i) {
+      const uint16_t sy = src[i];
+      if (sy >= 256 && !c) {
+        ok = false;
+        return;
+      }
+      dst[i] = sy < 256 ? static_cast<uint8_t>(sy) : c[sy - 256];
+    }
+    std::vector<uint16_t>().swap(symbols[j]);
   });
-  lap("pass2");
+  lap("place");
   if (!ok) return false;
 
   // ---- 5. CRC-32 and ISIZE

@@ -172,14 +172,19 @@ class RcclGather:
         import ctypes as C
         self.plan, self.rank, self.dst = plan, rank, dst
         self.L = abi.load_library()
-        if not self.L.spz_amd_rccl_available():
-            raise RuntimeError("librccl.so.1 cannot be loaded")
+        self.comm = None
+        # every rank takes part in the broadcast whatever happened before it, so that a rank that cannot load RCCL
+        # (or a root that cannot make the id) makes ALL ranks raise instead of leaving the others waiting
         ident = [None]
-        if rank == dst:
+        if rank == dst and self.L.spz_amd_rccl_available():
             buf = (C.c_uint8 * abi.RCCL_UNIQUE_ID_BYTES)()
-            abi.check(self.L.spz_amd_rccl_unique_id(buf), "spz_amd_rccl_unique_id")
-            ident = [bytes(buf)]
+            if self.L.spz_amd_rccl_unique_id(buf) == abi.OK:
+                ident = [bytes(buf)]
         dist.broadcast_object_list(ident, src=dst, group=group)
+        if ident[0] is None:
+            raise RuntimeError("the root rank could not create an RCCL unique id (librccl.so.1 not loadable there?)")
+        if not self.L.spz_amd_rccl_available():
+            raise RuntimeError("librccl.so.1 cannot be loaded on this rank")
         self.comm = C.c_void_p()
         buf = (C.c_uint8 * abi.RCCL_UNIQUE_ID_BYTES).from_buffer_copy(ident[0])
         abi.check(self.L.spz_amd_rccl_comm_init(buf, plan.world_size, rank, C.byref(self.comm)), "spz_amd_rccl_comm_init")

@@ -964,6 +964,26 @@ def test_ipc_route_with_two_processes_on_one_gpu(dev):
     assert res["n_gpus"] == 2 and res["value"] > 0
 
 
+def test_bench_native_route_falls_back_when_the_communicator_is_refused(dev):
+    """`--route rccl` with two ranks on ONE GPU: RCCL refuses a communicator with two ranks on a device, every rank
+    learns that through the collective check, and the run continues on the torch route (still verified) with the
+    reason in `exchange_route_note` — what the driver's multi-GPU run would fall back to if the native route did not
+    come up.  Exercises spz_amd_rccl_unique_id, the id broadcast and spz_amd_rccl_comm_init with real peers."""
+    import json
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+           "--master-port", "29645", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+           "--points", "200000", "--backend", "gloo", "--route", "rccl"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert res["exchange_route"] == "torch" and "fell back" in res["exchange_route_note"]
+    assert res["gather_verified"] is True
+
+
 def test_ipc_mapped_stream_equals_the_single_encode(dev, oracle):
     """Same route at the C ABI, bytes compared in full: this process owns the stream (spz_amd_ipc_alloc) and encodes
     shard 0 with the header; a child process opens the handle and encodes shard 1 of the same seeded cloud into
