@@ -78,6 +78,20 @@ inline unsigned effectiveCpuCount() {
   return n;
 }
 
+// Asks for transparent huge pages behind a freshly allocated buffer that is about to be written once (a no-op where
+// THP is off or "always"): its first-touch faults then come 2 MiB at a time.
+inline void adviseHugePages(void *p, size_t bytes) {
+#ifdef MADV_HUGEPAGE
+  const size_t huge = size_t(2) << 20;
+  const uintptr_t lo = (reinterpret_cast<uintptr_t>(p) + huge - 1) & ~(huge - 1);
+  const uintptr_t hi = (reinterpret_cast<uintptr_t>(p) + bytes) & ~(huge - 1);
+  if (hi > lo) (void)madvise(reinterpret_cast<void *>(lo), hi - lo, MADV_HUGEPAGE);
+#else
+  (void)p;
+  (void)bytes;
+#endif
+}
+
 inline int prefaultThreads() {
   static const int n = []() {
     const char *e = std::getenv("SPZ_AMD_PREFAULT_THREADS");
@@ -134,7 +148,8 @@ class Prefault {
     (void)bytes;
 #endif
   }
-  void start() {
+  // wait = false: the caller joins itself at the point where the pages are needed (joinHook)
+  void start(bool wait = true) {
     if (segs_.empty()) return;
     std::sort(segs_.begin(), segs_.end(), [](const Seg &x, const Seg &y) { return x.where < y.where; });
     const int threads = std::min<int>(prefaultThreads(), static_cast<int>(segs_.size()));
@@ -149,8 +164,10 @@ class Prefault {
         }
       });
     }
-    if (prefaultJoinFirst()) join();
+    if (wait && prefaultJoinFirst()) join();
   }
+  // for C callbacks: joins the Prefault passed as the argument
+  static void joinHook(void *self) { static_cast<Prefault *>(self)->join(); }
   void join() {
     for (auto &t : pool_) t.join();
     pool_.clear();
