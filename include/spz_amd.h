@@ -224,12 +224,6 @@ int spz_amd_decode_host(const uint8_t *h_stream, size_t size, int to_coord,
                         const spz_amd_cloud_out *h_cloud, int device);
 int spz_amd_decode_host_ex(const uint8_t *h_stream, size_t size, uint64_t max_points, int to_coord,
                            const spz_amd_cloud_out *h_cloud, int device);
-/* The same with a hook that is called exactly once — before the first byte is written to h_cloud, on whatever
- * thread does that, or before the call returns if nothing is written — so that a caller can finish preparing its
- * output buffers (e.g. mapping freshly allocated pages) while the stream is already being uploaded. */
-int spz_amd_decode_host_hook(const uint8_t *h_stream, size_t size, uint64_t max_points, int to_coord,
-                             const spz_amd_cloud_out *h_cloud, int device, void (*before_first_download)(void *),
-                             void *hook_arg);
 int spz_amd_convert_coordinates_host(float *h_positions, float *h_rotations, float *h_sh,
                                      uint64_t num_points, int sh_degree, int from_coord,
                                      int to_coord, int device);

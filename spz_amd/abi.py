@@ -40,7 +40,7 @@ EXPORTS = (
     "spz_amd_decode_shard_device", "spz_amd_decode_gather_device", "spz_amd_decode_gather_host",
     "spz_amd_convert_coordinates_device",
     "spz_amd_encode_host",
-    "spz_amd_decode_host", "spz_amd_decode_host_ex", "spz_amd_decode_host_hook", "spz_amd_convert_coordinates_host", "spz_amd_get_tables",
+    "spz_amd_decode_host", "spz_amd_decode_host_ex", "spz_amd_convert_coordinates_host", "spz_amd_get_tables",
     "spz_amd_ply_default_columns", "spz_amd_ply_rows_to_cloud_device", "spz_amd_cloud_to_ply_rows_device",
     "spz_amd_ply_rows_to_cloud_host", "spz_amd_cloud_to_ply_rows_host",
     "spz_amd_median_scale_sum_device", "spz_amd_median_scale_sum_host",

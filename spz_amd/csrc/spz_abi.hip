@@ -479,15 +479,13 @@ int plan_chunks(uint64_t n, size_t float_bytes_per_point, uint64_t *chunk_points
 }
 
 template <class Up, class Down>
-int run_pipeline(HostPipe *pipe, int device, int chunks, Up up, Down down, void (*before_first_download)(void *) = nullptr,
-                 void *hook_arg = nullptr) {
+int run_pipeline(HostPipe *pipe, int device, int chunks, Up up, Down down) {
   if (chunks > pipe->n_events) return SPZ_AMD_ERR_INVALID_ARG;
   if (chunks == 1) {  // small calls: no second thread
     int rc = up(0);
     if (rc != SPZ_AMD_OK) return rc;
     SPZ_HIP_TRY(hipEventRecord(pipe->events[0], pipe->up));
     SPZ_HIP_TRY(hipStreamWaitEvent(pipe->down, pipe->events[0], 0));
-    if (before_first_download) before_first_download(hook_arg);
     rc = down(0);
     hipError_t e = hipStreamSynchronize(pipe->down);
     if (rc != SPZ_AMD_OK) return rc;
@@ -502,7 +500,6 @@ int run_pipeline(HostPipe *pipe, int device, int chunks, Up up, Down down, void 
   std::thread downloader([&]() {
     int rc = SPZ_AMD_OK;
     if (hipSetDevice(device) != hipSuccess) rc = SPZ_AMD_ERR_HIP;
-    if (before_first_download) before_first_download(hook_arg);  // e.g. the caller finishes mapping its output pages
     for (int k = 0; k < chunks && rc == SPZ_AMD_OK; ++k) {
       {
         std::unique_lock<std::mutex> lock(m);
@@ -856,22 +853,6 @@ int spz_amd_encode_host(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, in
 
 int spz_amd_decode_host_ex(const uint8_t *h_stream, size_t size, uint64_t max_points, int to_coord,
                            const spz_amd_cloud_out *h, int device) {
-  return spz_amd_decode_host_hook(h_stream, size, max_points, to_coord, h, device, nullptr, nullptr);
-}
-
-int spz_amd_decode_host_hook(const uint8_t *h_stream, size_t size, uint64_t max_points, int to_coord,
-                             const spz_amd_cloud_out *h, int device, void (*before_first_download)(void *), void *hook_arg) {
-  // the hook runs exactly once on every path that returns after it could matter: wrap the early returns
-  struct Once {
-    void (*fn)(void *);
-    void *arg;
-    bool done = false;
-    void run() {
-      if (fn && !done) fn(arg);
-      done = true;
-    }
-    ~Once() { run(); }
-  } once{before_first_download, hook_arg};
   if (h_stream == nullptr || h == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
   spz_amd_header hdr;
   int rc = spz_amd_peek_header_ex(h_stream, size, max_points, &hdr);
@@ -923,10 +904,7 @@ int spz_amd_decode_host_hook(const uint8_t *h_stream, size_t size, uint64_t max_
     }
     return SPZ_AMD_OK;
   };
-  struct Thunk {
-    static void call(void *p) { static_cast<Once *>(p)->run(); }
-  };
-  return run_pipeline(pipe, device, chunks, up, down, &Thunk::call, &once);
+  return run_pipeline(pipe, device, chunks, up, down);
 }
 
 int spz_amd_decode_host(const uint8_t *h_stream, size_t size, int to_coord, const spz_amd_cloud_out *h,

@@ -861,12 +861,10 @@ GaussianCloud unpackFromStream(const uint8_t *stream, size_t size, const UnpackO
   const size_t n = hdr.num_points;
   detail::Prefault prefault;
   sizeCloudArrays(&r, n, static_cast<size_t>(dimForDegree(hdr.sh_degree)), &prefault);
-  // the pages are mapped while the stream is uploaded and decoded; the first download waits for them
-  prefault.start(/*wait=*/false);
+  prefault.start();
   spz_amd_cloud_out out = {r.positions.data(), r.scales.data(), r.rotations.data(),
                            r.alphas.data(),    r.colors.data(), r.sh.empty() ? nullptr : r.sh.data()};
-  const int rc = spz_amd_decode_host_hook(stream, size, SPZ_AMD_REFERENCE_MAX_POINTS, static_cast<int>(o.to), &out,
-                                          deviceIndex(), &detail::Prefault::joinHook, &prefault);
+  const int rc = spz_amd_decode_host(stream, size, static_cast<int>(o.to), &out, deviceIndex());
   prefault.join();
   if (deviceFailed(rc, "decode")) return {};
   return r;
@@ -916,13 +914,12 @@ GaussianCloud unpackGaussians(const PackedGaussians &packed, const UnpackOptions
   if (n == 0) return r;
   detail::Prefault prefault;
   sizeCloudArrays(&r, n, static_cast<size_t>(shDim), &prefault);
-  prefault.start(/*wait=*/false);
+  prefault.start();
   spz_amd_cloud_out out = {r.positions.data(), r.scales.data(), r.rotations.data(),
                            r.alphas.data(),    r.colors.data(), r.sh.empty() ? nullptr : r.sh.data()};
   // no point limit here: the reference's 10 M cap lives in deserializePackedGaussians (load-spz.cc:549,561),
   // unpackGaussians (:467-531) has none
-  const int rc = spz_amd_decode_host_hook(stream.data(), stream.size(), 0, static_cast<int>(o.to), &out, deviceIndex(),
-                                          &detail::Prefault::joinHook, &prefault);
+  const int rc = spz_amd_decode_host_ex(stream.data(), stream.size(), 0, static_cast<int>(o.to), &out, deviceIndex());
   prefault.join();
   if (deviceFailed(rc, "decode")) return {};
   return r;

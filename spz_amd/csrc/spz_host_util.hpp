@@ -105,7 +105,8 @@ inline int prefaultThreads() {
 
 // The outputs are mapped BEFORE the device call starts (default).  Mapping them beside it (SPZ_AMD_PREFAULT_CONCURRENT=1)
 // looked better on paper and measured worse: the copies' own pinning of source and destination pages and the
-// populate threads contend in the kernel's mm (10 M SH3 unpack: 79 ms mapped first, 119 ms side by side).
+// populate threads contend in the kernel's mm (10 M SH3 unpack: 72-79 ms mapped first, 119 ms side by side; even
+// beside the UPLOAD only, the downloads waiting for the mapping to finish, 116 ms).
 inline bool prefaultJoinFirst() {
   static const bool v = []() {
     const char *e = std::getenv("SPZ_AMD_PREFAULT_CONCURRENT");
@@ -148,8 +149,7 @@ class Prefault {
     (void)bytes;
 #endif
   }
-  // wait = false: the caller joins itself at the point where the pages are needed (joinHook)
-  void start(bool wait = true) {
+  void start() {
     if (segs_.empty()) return;
     std::sort(segs_.begin(), segs_.end(), [](const Seg &x, const Seg &y) { return x.where < y.where; });
     const int threads = std::min<int>(prefaultThreads(), static_cast<int>(segs_.size()));
@@ -164,10 +164,8 @@ class Prefault {
         }
       });
     }
-    if (wait && prefaultJoinFirst()) join();
+    if (prefaultJoinFirst()) join();
   }
-  // for C callbacks: joins the Prefault passed as the argument
-  static void joinHook(void *self) { static_cast<Prefault *>(self)->join(); }
   void join() {
     for (auto &t : pool_) t.join();
     pool_.clear();

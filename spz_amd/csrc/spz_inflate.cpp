@@ -543,9 +543,11 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
       }
       dst[i] = sy < 256 ? static_cast<uint8_t>(sy) : c[sy - 256];
     }
-    std::vector<uint16_t>().swap(symbols[j]);
   });
   lap("place");
+  symbols.clear();  // not inside the loop: an munmap takes the address space's lock and stalls the other threads' faults
+  symbols.shrink_to_fit();
+  lap("free");
   if (!ok) return false;
 
   // ---- 5. CRC-32 and ISIZE

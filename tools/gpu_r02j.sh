@@ -5,7 +5,7 @@ O=$R/gpurun_out
 TAG=${1:-r02j}
 mkdir -p $O
 cd $R
-timeout -k 10 900 python -m pytest tests -m gpu -q -x > $O/pytest_gpu_$TAG.log 2>&1
+timeout -k 10 900 python -m pytest tests -m gpu -q -x -k "host or python_module or whole_file or ply" > $O/pytest_gpu_$TAG.log 2>&1
 rc=$?
 tail -n 6 $O/pytest_gpu_$TAG.log
 if [ $rc -ne 0 ]; then echo "pytest rc=$rc: stopping"; exit $rc; fi
