@@ -545,9 +545,11 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
     }
   });
   lap("place");
-  symbols.clear();  // not inside the loop: an munmap takes the address space's lock and stalls the other threads' faults
-  symbols.shrink_to_fit();
-  lap("free");
+  // Returning 2 bytes per output byte to the system costs ~50 ms per GB (munmap of huge pages) and nobody waits for
+  // it: a detached thread does it.  Not inside the loop above either: an munmap takes the address space's lock and
+  // stalls the other threads' page faults.
+  std::thread([dead = std::move(symbols)]() mutable { dead.clear(); }).detach();
+  symbols.clear();
   if (!ok) return false;
 
   // ---- 5. CRC-32 and ISIZE
