@@ -189,6 +189,12 @@ int spz_amd_rccl_comm_destroy(void *comm);
 int spz_amd_gatherv_rccl(void *comm, int rank, int world, int root, const uint64_t *first, const uint64_t *count,
                          int sh_degree, int version, const uint8_t *d_local_stream, uint8_t *d_global_stream,
                          unsigned section_mask, void *hip_stream);
+/* The mirror image for the decode direction when the stream starts on the root only: every rank receives its six
+ * fragments into a stream of its own (d_local_stream: layout of spz_amd_stream_layout(count[rank]); the header is the
+ * caller's to write) and decodes them with spz_amd_decode_device.  Same group construction, 65 B/point for SH3. */
+int spz_amd_scatterv_rccl(void *comm, int rank, int world, int root, const uint64_t *first, const uint64_t *count,
+                          int sh_degree, int version, const uint8_t *d_global_stream, uint8_t *d_local_stream,
+                          unsigned section_mask, void *hip_stream);
 #define SPZ_AMD_IPC_HANDLE_BYTES 64
 int spz_amd_ipc_alloc(size_t bytes, void **d_ptr, uint8_t handle[SPZ_AMD_IPC_HANDLE_BYTES]);
 int spz_amd_ipc_free(void *d_ptr);

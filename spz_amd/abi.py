@@ -47,7 +47,7 @@ EXPORTS = (
     "spz_amd_selftest_device",
     "spz_amd_encode_shard_sections_device", "spz_amd_shard_fragments",
     "spz_amd_rccl_available", "spz_amd_last_rccl_error", "spz_amd_rccl_unique_id", "spz_amd_rccl_comm_init",
-    "spz_amd_rccl_comm_destroy", "spz_amd_gatherv_rccl",
+    "spz_amd_rccl_comm_destroy", "spz_amd_gatherv_rccl", "spz_amd_scatterv_rccl",
     "spz_amd_ipc_alloc", "spz_amd_ipc_free", "spz_amd_ipc_open", "spz_amd_ipc_close",
 )
 
@@ -189,6 +189,8 @@ def bind(L):
     L.spz_amd_rccl_comm_destroy.argtypes = [vp]
     L.spz_amd_gatherv_rccl.restype = i32
     L.spz_amd_gatherv_rccl.argtypes = [vp, i32, i32, i32, C.POINTER(u64), C.POINTER(u64), i32, i32, vp, vp, u32, vp]
+    L.spz_amd_scatterv_rccl.restype = i32
+    L.spz_amd_scatterv_rccl.argtypes = [vp, i32, i32, i32, C.POINTER(u64), C.POINTER(u64), i32, i32, vp, vp, u32, vp]
     L.spz_amd_ipc_alloc.restype = i32
     L.spz_amd_ipc_alloc.argtypes = [sz, C.POINTER(vp), vp]
     L.spz_amd_ipc_free.restype = i32

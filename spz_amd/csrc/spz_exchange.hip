@@ -127,9 +127,13 @@ int spz_amd_rccl_comm_destroy(void *comm) {
   return SPZ_AMD_OK;
 }
 
-int spz_amd_gatherv_rccl(void *comm, int rank, int world, int root, const uint64_t *first, const uint64_t *count,
-                         int sh_degree, int version, const uint8_t *d_local_stream, uint8_t *d_global_stream,
-                         unsigned section_mask, void *hip_stream) {
+namespace {
+
+// One ncclGroupStart/End moving every selected fragment between the root's global stream and the ranks' own streams:
+// toward the root (gather) or away from it (scatter).
+int exchange_rccl(bool gather, void *comm, int rank, int world, int root, const uint64_t *first, const uint64_t *count,
+                  int sh_degree, int version, uint8_t *d_local_stream, uint8_t *d_global_stream, unsigned section_mask,
+                  void *hip_stream) {
   if (comm == nullptr || first == nullptr || count == nullptr || world < 1 || rank < 0 || rank >= world || root < 0 ||
       root >= world) {
     return SPZ_AMD_ERR_INVALID_ARG;
@@ -152,22 +156,26 @@ int spz_amd_gatherv_rccl(void *comm, int rank, int world, int root, const uint64
   }
   SPZ_RCCL_TRY(rccl().GroupStart());
   ncclResult_t bad = ncclSuccess;
+  auto send = [&](const void *p, size_t n, int peer) {
+    if (bad == ncclSuccess) bad = rccl().Send(p, n, ncclUint8, peer, c, st);
+  };
+  auto recv = [&](void *p, size_t n, int peer) {
+    if (bad == ncclSuccess) bad = rccl().Recv(p, n, ncclUint8, peer, c, st);
+  };
   for (int r = 0; r < world; ++r) {
-    // the root's own fragments travel too (send to self) when it encoded into a stream of its own instead
-    // of straight into the global one
+    // the root's own fragments travel too (to / from itself) when it keeps a stream of its own besides the global one
     const bool local_on_root = (r == root && d_local_stream != nullptr);
     if (r == root && !local_on_root) continue;
     if (rank != root && rank != r) continue;
     (void)spz_amd_shard_fragments(first[r], count[r], total, sh_degree, version, &f);
     for (int s = 0; s < SPZ_AMD_NUM_SECTIONS; ++s) {
       if (!((section_mask >> s) & 1u) || f.bytes[s] == 0) continue;
-      if (rank == r && bad == ncclSuccess) {
-        const ncclResult_t e = rccl().Send(d_local_stream + f.local_offset[s], f.bytes[s], ncclUint8, root, c, st);
-        bad = e != ncclSuccess ? e : bad;
-      }
-      if (rank == root && bad == ncclSuccess) {
-        const ncclResult_t e = rccl().Recv(d_global_stream + f.global_offset[s], f.bytes[s], ncclUint8, r, c, st);
-        bad = e != ncclSuccess ? e : bad;
+      if (gather) {
+        if (rank == r) send(d_local_stream + f.local_offset[s], f.bytes[s], root);
+        if (rank == root) recv(d_global_stream + f.global_offset[s], f.bytes[s], r);
+      } else {
+        if (rank == root) send(d_global_stream + f.global_offset[s], f.bytes[s], r);
+        if (rank == r) recv(d_local_stream + f.local_offset[s], f.bytes[s], root);
       }
     }
   }
@@ -175,6 +183,22 @@ int spz_amd_gatherv_rccl(void *comm, int rank, int world, int root, const uint64
   SPZ_RCCL_TRY(bad);
   SPZ_RCCL_TRY(end);
   return SPZ_AMD_OK;
+}
+
+}  // namespace
+
+int spz_amd_gatherv_rccl(void *comm, int rank, int world, int root, const uint64_t *first, const uint64_t *count,
+                         int sh_degree, int version, const uint8_t *d_local_stream, uint8_t *d_global_stream,
+                         unsigned section_mask, void *hip_stream) {
+  return exchange_rccl(true, comm, rank, world, root, first, count, sh_degree, version,
+                       const_cast<uint8_t *>(d_local_stream), d_global_stream, section_mask, hip_stream);
+}
+
+int spz_amd_scatterv_rccl(void *comm, int rank, int world, int root, const uint64_t *first, const uint64_t *count,
+                          int sh_degree, int version, const uint8_t *d_global_stream, uint8_t *d_local_stream,
+                          unsigned section_mask, void *hip_stream) {
+  return exchange_rccl(false, comm, rank, world, root, first, count, sh_degree, version, d_local_stream,
+                       const_cast<uint8_t *>(d_global_stream), section_mask, hip_stream);
 }
 
 int spz_amd_ipc_alloc(size_t bytes, void **d_ptr, uint8_t handle[SPZ_AMD_IPC_HANDLE_BYTES]) {

@@ -1060,6 +1060,13 @@ def test_rccl_gatherv_native_on_one_gpu(dev, oracle):
         want = oracle.pack(c, n, deg, True, 6)
         assert_bytes_equal(glob.cpu().numpy()[16:], want[16:], "fragments after the self-exchange")
         assert not glob[:16].any(), "the gatherv moves fragments only; the header is the root's to write"
+        # the mirror image: the global stream's fragments back into a stream of the rank's own, then decoded there
+        back = torch.zeros_like(local)
+        back[:16] = local[:16]
+        rc = L.spz_amd_scatterv_rccl(comm, 0, 1, 0, first, count, deg, 3, glob.data_ptr(), back.data_ptr(), abi.ALL_SECTIONS, s)
+        assert rc == 0, (rc, L.spz_amd_last_rccl_error())
+        torch.cuda.synchronize()
+        assert_bytes_equal(back.cpu().numpy(), want, "scatterv back into the rank's own stream")
         # argument checks: ranges must be contiguous in rank order, the root needs a destination
         bad_first = (C.c_uint64 * 1)(5)
         assert L.spz_amd_gatherv_rccl(comm, 0, 1, 0, bad_first, count, deg, 3, local.data_ptr(), glob.data_ptr(), 0x3f, s) == abi.ERR_INVALID_ARG

@@ -40,6 +40,9 @@ VARIANTS = {
     "il_rot_g8": {"enc": "rotation tiles only, runs of 8", "dec": "same", "defs": dict(_IL, SPZ_IL_ONLY_ROT=1, SPZ_IL_GROUP=8)},
     "policy": {"enc": "shipped: interleave by policy, runs of 8", "dec": "same", "defs": {}},
     "policy_b": {"enc": "shipped, second copy (noise floor)", "dec": "same", "defs": {}},
+    "enc_nts": {"enc": "policy + non-temporal stores in encode", "dec": "policy", "defs": {"SPZ_ENC_NTS": 1}},
+    "dec_ld": {"enc": "policy", "dec": "policy, ordinary (cached) loads", "defs": {"SPZ_DEC_NTL": 0}},
+    "dec_st": {"enc": "policy", "dec": "policy, ordinary stores", "defs": {"SPZ_DEC_NTS": 0}},
     "u8_policy": {"enc": "256 x 8 units, policy", "dec": "256 x 8 units, policy", "defs": {"SPZ_ENC_UNROLL": 8, "SPZ_DEC_UNROLL": 8}},
 }
 
