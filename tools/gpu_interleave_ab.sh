@@ -1,5 +1,5 @@
 #!/bin/bash
-# quick session: what kind of box is this, and the interleave A/B on it
+# quick session: what kind of box is this, and the grid-order A/B on it (sequential vs interleaved, run lengths)
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out

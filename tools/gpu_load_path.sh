@@ -1,11 +1,12 @@
 #!/bin/bash
+# load path on the GPU box: parity subset, smoke, C++ host bench incl. saveSpz/loadSpz with the inflate laps, gunzip by thread count
 set -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 TAG=${1:-r02j}
 mkdir -p $O
 cd $R
-timeout -k 10 900 python -m pytest tests -m gpu -q -x -k "host or python_module or whole_file or ply" > $O/pytest_gpu_$TAG.log 2>&1
+timeout -k 10 900 python -m pytest tests -m gpu -q -x > $O/pytest_gpu_$TAG.log 2>&1
 rc=$?
 tail -n 6 $O/pytest_gpu_$TAG.log
 if [ $rc -ne 0 ]; then echo "pytest rc=$rc: stopping"; exit $rc; fi
