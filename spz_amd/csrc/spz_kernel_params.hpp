@@ -53,9 +53,11 @@ namespace spz_amd_detail {
 #endif
 // 0: one tile per block ("flat" grid, measured faster than a persistent grid-stride loop: a wave's
 // next loads would queue behind its own stores in the in-order vmcnt).  k > 0: at most k blocks per CU.
-// Optional second __launch_bounds__ argument (minimum waves per SIMD) for the encode kernel.
+// Second __launch_bounds__ argument (minimum waves per SIMD) for the encode kernel.  6: the allocator then fits
+// the kernel into 78 VGPRs without scratch (left alone it takes 89-90 = 5 waves per SIMD): SH0 encode +3 %, the
+// other workloads unchanged (profiles/r02_tune_o_*).  8 spills (round 1).
 #ifndef SPZ_ENC_MIN_WAVES
-#define SPZ_ENC_MIN_WAVES 1
+#define SPZ_ENC_MIN_WAVES 6
 #endif
 // 1: a scheduling barrier after every unit of an encode tile, so the compiler does not interleave the
 // arithmetic of the four units (fewer live registers, more waves per SIMD).

@@ -40,6 +40,8 @@ VARIANTS = {
     "il_rot_g8": {"enc": "rotation tiles only, runs of 8", "dec": "same", "defs": dict(_IL, SPZ_IL_ONLY_ROT=1, SPZ_IL_GROUP=8)},
     "policy": {"enc": "shipped: interleave by policy, runs of 8", "dec": "same", "defs": {}},
     "policy_b": {"enc": "shipped, second copy (noise floor)", "dec": "same", "defs": {}},
+    "mw1": {"enc": "policy, no minimum-waves bound (89 VGPRs, 5 waves per SIMD)", "dec": "policy", "defs": {"SPZ_ENC_MIN_WAVES": 1}},
+    "mw7": {"enc": "policy, __launch_bounds__(256, 7)", "dec": "policy", "defs": {"SPZ_ENC_MIN_WAVES": 7}},
     "enc_nts": {"enc": "policy + non-temporal stores in encode", "dec": "policy", "defs": {"SPZ_ENC_NTS": 1}},
     "dec_ld": {"enc": "policy", "dec": "policy, ordinary (cached) loads", "defs": {"SPZ_DEC_NTL": 0}},
     "dec_st": {"enc": "policy", "dec": "policy, ordinary stores", "defs": {"SPZ_DEC_NTS": 0}},
