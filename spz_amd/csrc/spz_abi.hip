@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <system_error>
 #include <thread>
 
 #include "spz_amd.h"
@@ -497,7 +498,7 @@ int run_pipeline(HostPipe *pipe, int device, int chunks, Up up, Down down) {
   int recorded = 0;      // events[0 .. recorded) have been recorded on pipe->up
   bool stop = false;     // the uploader failed: the downloader must not wait for more
   int down_rc = SPZ_AMD_OK, down_hip = 0;
-  std::thread downloader([&]() {
+  auto download_all = [&]() {
     int rc = SPZ_AMD_OK;
     if (hipSetDevice(device) != hipSuccess) rc = SPZ_AMD_ERR_HIP;
     for (int k = 0; k < chunks && rc == SPZ_AMD_OK; ++k) {
@@ -516,7 +517,23 @@ int run_pipeline(HostPipe *pipe, int device, int chunks, Up up, Down down) {
     }
     down_rc = rc;
     down_hip = g_last_hip_error;
-  });
+  };
+  std::thread downloader;
+  try {
+    downloader = std::thread(download_all);
+  } catch (const std::system_error &) {
+    // no second thread to be had: the chunks one after the other on this one (correct, not overlapped)
+    for (int k = 0; k < chunks; ++k) {
+      int rc = up(k);
+      if (rc != SPZ_AMD_OK) return rc;
+      SPZ_HIP_TRY(hipEventRecord(pipe->events[k], pipe->up));
+      SPZ_HIP_TRY(hipStreamWaitEvent(pipe->down, pipe->events[k], 0));
+      rc = down(k);
+      if (rc != SPZ_AMD_OK) return rc;
+    }
+    SPZ_HIP_TRY(hipStreamSynchronize(pipe->down));
+    return SPZ_AMD_OK;
+  }
   int rc = SPZ_AMD_OK;
   for (int k = 0; k < chunks && rc == SPZ_AMD_OK; ++k) {
     rc = up(k);

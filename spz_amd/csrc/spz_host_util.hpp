@@ -18,6 +18,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <system_error>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -34,15 +35,16 @@ void resizeUninitialized(std::vector<T> *v, size_t n) {
   static_assert(std::is_trivial<T>::value, "only for trivial element types");
 #if defined(__GLIBCXX__) && !defined(__SANITIZE_ADDRESS__)
   if (n > v->size() && (n - v->size()) * sizeof(T) >= (size_t(1) << 20)) {
-    v->reserve(n);
     T *rep[3];
-    static_assert(sizeof(std::vector<T>) == sizeof(rep), "unexpected std::vector representation");
-    std::memcpy(rep, static_cast<const void *>(v), sizeof(rep));
-    if (rep[0] == v->data() && rep[1] == v->data() + v->size() && rep[2] == v->data() + v->capacity() &&
-        v->capacity() >= n) {
-      rep[1] = rep[0] + n;
-      std::memcpy(static_cast<void *>(v), rep, sizeof(rep));
-      return;
+    if constexpr (sizeof(std::vector<T>) == sizeof(rep)) {  // not so with _GLIBCXX_DEBUG: ordinary resize then
+      v->reserve(n);
+      std::memcpy(rep, static_cast<const void *>(v), sizeof(rep));
+      if (rep[0] == v->data() && rep[1] == v->data() + v->size() && rep[2] == v->data() + v->capacity() &&
+          v->capacity() >= n) {
+        rep[1] = rep[0] + n;
+        std::memcpy(static_cast<void *>(v), rep, sizeof(rep));
+        return;
+      }
     }
   }
 #endif
@@ -153,16 +155,20 @@ class Prefault {
     if (segs_.empty()) return;
     std::sort(segs_.begin(), segs_.end(), [](const Seg &x, const Seg &y) { return x.where < y.where; });
     const int threads = std::min<int>(prefaultThreads(), static_cast<int>(segs_.size()));
-    for (int t = 0; t < threads; ++t) {
-      pool_.emplace_back([this]() {
-        for (;;) {
-          const size_t i = next_.fetch_add(1);
-          if (i >= segs_.size()) return;
+    try {
+      for (int t = 0; t < threads; ++t) {
+        pool_.emplace_back([this]() {
+          for (;;) {
+            const size_t i = next_.fetch_add(1);
+            if (i >= segs_.size()) return;
 #ifdef MADV_POPULATE_WRITE
-          (void)madvise(reinterpret_cast<void *>(segs_[i].addr), segs_[i].len, MADV_POPULATE_WRITE);
+            (void)madvise(reinterpret_cast<void *>(segs_[i].addr), segs_[i].len, MADV_POPULATE_WRITE);
 #endif
-        }
-      });
+          }
+        });
+      }
+    } catch (const std::system_error &) {
+      // no thread to be had: whatever is not mapped by the threads that did start faults in on first use
     }
     if (prefaultJoinFirst()) join();
   }

@@ -28,6 +28,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <system_error>
 #include <thread>
 
 namespace spz {
@@ -548,7 +549,11 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
   // Returning 2 bytes per output byte to the system costs ~50 ms per GB (munmap of huge pages) and nobody waits for
   // it: a detached thread does it.  Not inside the loop above either: an munmap takes the address space's lock and
   // stalls the other threads' page faults.
-  std::thread([dead = std::move(symbols)]() mutable { dead.clear(); }).detach();
+  try {
+    std::thread([dead = std::move(symbols)]() mutable { dead.clear(); }).detach();
+  } catch (const std::system_error &) {
+    // no thread to be had: the buffers go when `symbols` does
+  }
   symbols.clear();
   if (!ok) return false;
 

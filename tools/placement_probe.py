@@ -22,7 +22,9 @@ def main():
     dev = torch.device("cuda:0")
     n, deg = 10_000_000, 3
     trials = int(sys.argv[1]) if len(sys.argv) > 1 else 40
-    libs = {name: abi.bind(C.CDLL(os.path.join(ROOT, "build", "variants", f"libspz_amd_{name}.so"))) for name in ("seq", "policy")}
+    names = (sys.argv[2] if len(sys.argv) > 2 else "seq,policy").split(",")
+    fresh_cloud = len(sys.argv) > 3 and sys.argv[3] == "fresh"   # re-allocate the input arrays too (placement then varies within a process)
+    libs = {name: abi.bind(C.CDLL(os.path.join(ROOT, "build", "variants", f"libspz_amd_{name}.so"))) for name in names}
     s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     lay = abi.stream_layout(n, deg, 3)
     hdr = abi.Header(3, n, deg, 12, 0, 0)
@@ -33,6 +35,12 @@ def main():
     g = torch.Generator().manual_seed(7)
     spacers = []
     for trial in range(trials):
+        if fresh_cloud:
+            del cloud
+            torch.cuda.empty_cache()
+            cloud = {k: torch.from_numpy(host[k]).to(dev) for k in FIELDS}
+            pin = abi.CloudPtrs(*[cloud[k].data_ptr() for k in FIELDS])
+
         def spacer():
             spacers.append(torch.empty(int(torch.randint(1, 200, (1,), generator=g)) << 20, dtype=torch.uint8, device=dev))
         out = {}

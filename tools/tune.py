@@ -42,6 +42,10 @@ VARIANTS = {
     "policy_b": {"enc": "shipped, second copy (noise floor)", "dec": "same", "defs": {}},
     "mw1": {"enc": "policy, no minimum-waves bound (89 VGPRs, 5 waves per SIMD)", "dec": "policy", "defs": {"SPZ_ENC_MIN_WAVES": 1}},
     "mw7": {"enc": "policy, __launch_bounds__(256, 7)", "dec": "policy", "defs": {"SPZ_ENC_MIN_WAVES": 7}},
+    "dec_wc": {"enc": "policy", "dec": "policy, a wave owns one contiguous 4 KiB span of its tile", "defs": {"SPZ_DEC_WC": 1}},
+    "dec_u2": {"enc": "policy", "dec": "policy, 256 x 2 units (8 KiB of floats per block)", "defs": {"SPZ_DEC_UNROLL": 2}},
+    "dec_u8": {"enc": "policy", "dec": "policy, 256 x 8 units (32 KiB of floats per block)", "defs": {"SPZ_DEC_UNROLL": 8}},
+    "dec_b512": {"enc": "policy", "dec": "policy, 512 threads x 4 units", "defs": {"SPZ_DEC_BLOCK": 512}},
     "enc_nts": {"enc": "policy + non-temporal stores in encode", "dec": "policy", "defs": {"SPZ_ENC_NTS": 1}},
     "dec_ld": {"enc": "policy", "dec": "policy, ordinary (cached) loads", "defs": {"SPZ_DEC_NTL": 0}},
     "dec_st": {"enc": "policy", "dec": "policy, ordinary stores", "defs": {"SPZ_DEC_NTS": 0}},
