@@ -63,8 +63,17 @@ struct Bits {  // the deflate data of the member
 };
 
 // Canonical Huffman decoder: a direct table for codes up to `fast` bits, canonical walk for longer ones.
+// Packed decode entry of a literal/length or distance code: everything the inner loop needs in one 32-bit load.
+//   bits 0-3  code length (0: the code is longer than the fast table, take the canonical walk)
+//   bits 4-7  number of extra bits (length / distance codes)
+//   bit  8    literal, bit 9 end of block, bit 10 invalid symbol (286, 287 / distance 30, 31)
+//   bits 16-31 the literal byte, or the base length / base distance
+constexpr uint32_t ENT_LITERAL = 1u << 8, ENT_EOB = 1u << 9, ENT_INVALID = 1u << 10;
+
 struct Huff {
   uint16_t fast[1 << FAST_L];
+  uint32_t packed[1 << FAST_L];  // filled by pack(): same index as fast[]
+  uint32_t ent[288];             // per symbol, without the code length (slow path)
   uint16_t count[16];
   uint16_t symbol[288];
   int fastbits = 0;
@@ -104,6 +113,33 @@ struct Huff {
     }
     return true;
   }
+  // Builds the packed tables from fast[]; `dist` selects the distance alphabet's bases.
+  void pack(bool dist) {
+    const int nsym = dist ? 32 : 288;
+    for (int sym = 0; sym < nsym; ++sym) {
+      uint32_t e;
+      if (dist) e = sym < 30 ? (static_cast<uint32_t>(kDistExtra[sym]) << 4) | (static_cast<uint32_t>(kDistBase[sym]) << 16) : ENT_INVALID;
+      else if (sym < 256) e = ENT_LITERAL | (static_cast<uint32_t>(sym) << 16);
+      else if (sym == 256) e = ENT_EOB;
+      else if (sym < 286) e = (static_cast<uint32_t>(kLenExtra[sym - 257]) << 4) | (static_cast<uint32_t>(kLenBase[sym - 257]) << 16);
+      else e = ENT_INVALID;
+      ent[sym] = e;
+    }
+    const uint32_t n = 1u << fastbits;
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint16_t f = fast[i];
+      packed[i] = f ? (ent[f >> 4] | (f & 15u)) : 0u;
+    }
+  }
+  // packed entry of the next code (code length in its low 4 bits); 0 if there is no such code
+  inline uint32_t lookup(uint64_t bits) const {
+    const uint32_t e = packed[bits & ((1u << fastbits) - 1)];
+    if (e) return e;
+    int len;
+    const int sym = decode(bits, &len);
+    if (sym < 0) return 0u;
+    return ent[sym] | static_cast<uint32_t>(len);  // len <= 15
+  }
   // returns the symbol and sets *len, or -1
   inline int decode(uint64_t bits, int *len) const {
     const uint16_t e = fast[bits & ((1u << fastbits) - 1)];
@@ -138,9 +174,11 @@ struct StaticHuff {
     for (int i = 256; i < 280; ++i) l[i] = 7;
     for (int i = 280; i < 288; ++i) l[i] = 8;
     lit.build(l, 288, FAST_L);
+    lit.pack(false);
     uint8_t d[30];
     for (int i = 0; i < 30; ++i) d[i] = 5;
     dist.build(d, 30, FAST_D);
+    dist.pack(true);
   }
 };
 const StaticHuff &staticHuff() {
@@ -203,6 +241,8 @@ bool readDynamic(const Bits &in, uint64_t *at, Huff *lit, Huff *dist) {
   if (!lit->build(lens, hlit, FAST_L)) return false;
   if (!dist->build(lens + hlit, hdist, FAST_D)) return false;
   if (lit->ncodes < 2) return false;  // zlib never writes fewer; keeps the block-start search strict
+  lit->pack(false);
+  dist->pack(true);
   *at = pos;
   return true;
 }
@@ -273,35 +313,46 @@ bool decodeHuffBlock(const Bits &in, uint64_t *at, const Huff &L, const Huff &D,
   uint64_t pos = *at;
   for (;;) {
     if (pos >= in.nbits) return false;
-    uint64_t bits = in.peek(pos);
-    int len;
-    int sym = L.decode(bits, &len);
-    if (sym < 0) return false;
-    if (sym < 256) {
-      if (!sink.lit(static_cast<uint8_t>(sym))) return false;
-      pos += static_cast<uint64_t>(len);
-      continue;
+    uint64_t bits = in.peek(pos);  // >= 56 valid bits
+    uint32_t e = L.lookup(bits);
+    // up to three literals per refill (3 x 15 bits <= 56)
+    if (e & ENT_LITERAL) {
+      if (!sink.lit(static_cast<uint8_t>(e >> 16))) return false;
+      pos += e & 15u;
+      bits >>= e & 15u;
+      e = L.lookup(bits);
+      if (e & ENT_LITERAL) {
+        if (!sink.lit(static_cast<uint8_t>(e >> 16))) return false;
+        pos += e & 15u;
+        bits >>= e & 15u;
+        e = L.lookup(bits);
+        if (e & ENT_LITERAL) {
+          if (!sink.lit(static_cast<uint8_t>(e >> 16))) return false;
+          pos += e & 15u;
+        }
+      }
+      continue;  // refill before anything that needs more than a code
     }
-    if (sym == 256) {
-      pos += static_cast<uint64_t>(len);
+    if (e == 0u || (e & ENT_INVALID)) return false;
+    uint32_t used = e & 15u;
+    if (e & ENT_EOB) {
+      pos += used;
       if (pos > in.nbits) return false;
       *at = pos;
       return true;
     }
-    sym -= 257;
-    if (sym >= 29) return false;
-    bits >>= len;
-    int used = len;
-    const uint32_t length = kLenBase[sym] + static_cast<uint32_t>(bits & ((1u << kLenExtra[sym]) - 1));
-    bits >>= kLenExtra[sym];
-    used += kLenExtra[sym];
-    const int dsym = D.decode(bits, &len);
-    if (dsym < 0 || dsym >= 30) return false;
-    bits >>= len;
-    used += len;
-    const uint32_t dist = kDistBase[dsym] + static_cast<uint32_t>(bits & ((1u << kDistExtra[dsym]) - 1));
-    used += kDistExtra[dsym];
-    pos += static_cast<uint64_t>(used);
+    bits >>= used;
+    const uint32_t lextra = (e >> 4) & 15u;
+    const uint32_t length = (e >> 16) + static_cast<uint32_t>(bits & ((1u << lextra) - 1u));
+    bits >>= lextra;
+    used += lextra;  // <= 20
+    const uint32_t d = D.lookup(bits);
+    if (d == 0u || (d & ENT_INVALID)) return false;
+    bits >>= d & 15u;
+    const uint32_t dextra = (d >> 4) & 15u;
+    const uint32_t dist = (d >> 16) + static_cast<uint32_t>(bits & ((1u << dextra) - 1u));
+    used += (d & 15u) + dextra;  // <= 48 of the >= 56 bits
+    pos += used;
     if (pos > in.nbits) return false;
     if (!sink.match(length, dist)) return false;
   }
@@ -546,16 +597,6 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
     }
   });
   lap("place");
-  // Returning 2 bytes per output byte to the system costs ~50 ms per GB (munmap of huge pages) and nobody waits for
-  // it: a detached thread does it.  Not inside the loop above either: an munmap takes the address space's lock and
-  // stalls the other threads' page faults.
-  try {
-    std::thread([dead = std::move(symbols)]() mutable { dead.clear(); }).detach();
-  } catch (const std::system_error &) {
-    // no thread to be had: the buffers go when `symbols` does
-  }
-  symbols.clear();
-  if (!ok) return false;
 
   // ---- 5. CRC-32 and ISIZE
   const uint64_t total = offset[n];
@@ -576,6 +617,16 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
   lap("crc");
   uLong crc = crcs[0];
   for (size_t i = 1; i < pieces; ++i) crc = crc32_combine(crc, crcs[i], static_cast<z_off_t>(cut[i + 1] - cut[i]));
+  // Returning the symbol buffers (2 bytes per output byte) to the system costs ~50 ms per GB (munmap of huge pages) and
+  // nobody waits for it: a detached thread does it — after the CRC pass, whose threads its TLB shoot-downs would
+  // otherwise interrupt (27 ms became 90), and not inside the placing loop either, where an munmap's hold on the
+  // address space's lock stalls the other threads' page faults.
+  try {
+    std::thread([dead = std::move(symbols)]() mutable { dead.clear(); }).detach();
+  } catch (const std::system_error &) {
+    // no thread to be had: the buffers go when `symbols` does
+  }
+  symbols.clear();
   if (static_cast<uint32_t>(crc) != want_crc) return false;
   g_successes.fetch_add(1);
   return true;
