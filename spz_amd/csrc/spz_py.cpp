@@ -7,6 +7,7 @@
 // this image; pybind11 is, so the dtype/ndim gate that nanobind's ndarray caster applies
 // (numeric dtypes convert to float32, anything else -> TypeError "incompatible function
 // arguments") is written out by hand in `toFloatVector`.
+#include <chrono>
 #include <pybind11/numpy.h>
 #include <pybind11/pybind11.h>
 #include <pybind11/stl.h>
@@ -321,6 +322,19 @@ PYBIND11_MODULE(spz, m) {
     if (g.numPoints == 0) raiseIfDeviceUnusable();
     return g;
   }, py::arg("data"), py::arg("options") = spz::UnpackOptions(), "Cloud of a raw (pre-gzip) stream: loadSpz without the gunzip step.");
+  m.def("_pack_unpack_seconds", [](const spz::GaussianCloud &g, const spz::PackOptions &o, const spz::UnpackOptions &u) {
+    // spz::packToStream / spz::unpackFromStream timed around the C++ calls themselves (fresh vectors), without the copy
+    // into a Python bytes object that _pack_to_stream pays on top
+    std::vector<uint8_t> stream;
+    auto t0 = std::chrono::steady_clock::now();
+    const bool ok = spz::packToStream(g, o, &stream);
+    const double pack_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!ok) raiseIfDeviceUnusable();
+    t0 = std::chrono::steady_clock::now();
+    spz::GaussianCloud back = spz::unpackFromStream(stream.data(), stream.size(), u);
+    const double unpack_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return py::make_tuple(pack_s, unpack_s, static_cast<int64_t>(back.numPoints));
+  }, py::arg("gaussians"), py::arg("pack_options"), py::arg("unpack_options"), "Seconds of packToStream and unpackFromStream at the C++ boundary.");
   m.def("_pack_to_stream", [](const spz::GaussianCloud &g, const spz::PackOptions &o) -> py::object {
     std::vector<uint8_t> out;
     if (!spz::packToStream(g, o, &out)) {

@@ -14,6 +14,21 @@ import spz_amd.spz as spz
 NAMES = ["UNSPECIFIED", "LDB", "RDB", "LUB", "RUB", "LDF", "RDF", "LUF", "RUF"]
 
 
+def test_reference_module_name_imports():
+    """`import spz` (the reference's package name, src/python/spz/__init__.py:1-2) resolves to this implementation with
+    the shim's public names."""
+    import importlib
+    from conftest import ROOT
+    import sys
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    ref_name = importlib.import_module("spz")
+    for k in ("GaussianCloud", "PackOptions", "UnpackOptions", "CoordinateSystem", "load_spz", "save_spz",
+              "load_splat_from_ply", "save_splat_to_ply", "RUB", "RDF"):
+        assert getattr(ref_name, k) is getattr(spz, k), k
+    assert not any(n.startswith("_") for n in ref_name.__all__)
+
+
 def test_coordinate_system_enum_values():
     """load_spz_test.py:233-261; numeric order of splat-types.h:33-43."""
     assert hasattr(spz, "CoordinateSystem")

@@ -29,6 +29,12 @@ def main():
     t0 = time.perf_counter(); raw = spz._pack_to_stream(g, o); res["pack_to_stream_s"] = round(time.perf_counter() - t0, 4)
     t0 = time.perf_counter(); raw = spz._pack_to_stream(g, o); res["pack_to_stream_warm_s"] = round(time.perf_counter() - t0, 4)
     res["stream_bytes"] = len(raw)
+    # the same two calls timed at the C++ boundary (fresh std::vectors, no copy into a Python bytes object: that copy,
+    # 650 MB into freshly mapped memory for a 10 M-point cloud, is what the two figures above carry on top)
+    u0 = spz.UnpackOptions()
+    u0.to_coord = spz.RDF
+    best = [min(x) for x in zip(*[spz._pack_unpack_seconds(g, o, u0)[:2] for _ in range(3)])]
+    res["cpp_pack_to_stream_s"], res["cpp_unpack_from_stream_s"] = round(best[0], 4), round(best[1], 4)
     # the reference's container (byte-identical .spz): zlib itself, then the exact multi-threaded writer
     os.environ["SPZ_AMD_GZIP_EXACT_THREADS"] = "1"
     t0 = time.perf_counter(); z_ref = spz._compress_gzipped(raw); res["gzip_zlib_single_stream_s"] = round(time.perf_counter() - t0, 3)
