@@ -25,6 +25,20 @@
 namespace py = pybind11;
 
 namespace {
+// The bytes of a Python bytes object, in place (the std::string conversion would copy them: 409 MB for a 10 M-point file).
+struct BytesView {
+  const uint8_t *p;
+  size_t n;
+};
+BytesView viewOf(const py::bytes &b) {
+  char *buf = nullptr;
+  Py_ssize_t len = 0;
+  if (PyBytes_AsStringAndSize(b.ptr(), &buf, &len) != 0) throw py::error_already_set();
+  return {reinterpret_cast<const uint8_t *>(buf), static_cast<size_t>(len)};
+}
+}  // namespace
+
+namespace {
 
 // Accepts what nb::ndarray<numpy, float, ndim<1>, c_contig, device::cpu> accepts: a 1-D array (or
 // array-like) of a bool/int/uint/float dtype, converted to float32.  Everything else is the
@@ -216,31 +230,31 @@ PYBIND11_MODULE(spz, m) {
         py::arg("gaussians"), py::arg("options"), py::arg("filename"), "Save a GaussianCloud to a *.spz* file.");
   // Extras of this implementation (underscore-prefixed: not part of the reference surface).
   m.def("_compress_gzipped", [](const py::bytes &data) {
-    const std::string in = data;
+    const BytesView in = viewOf(data);
     std::vector<uint8_t> out;
-    if (!spz::compressGzipped(reinterpret_cast<const uint8_t *>(in.data()), in.size(), &out)) {
+    if (!spz::compressGzipped(in.p, in.n, &out)) {
       throw std::runtime_error("compressGzipped failed");
     }
     return py::bytes(reinterpret_cast<const char *>(out.data()), out.size());
   }, "gzip wrapper of saveSpz (host zlib, parameters of load-spz.cc:190).");
   m.def("_compress_gzipped_parallel", [](const py::bytes &data, int threads) {
-    const std::string in = data;
+    const BytesView in = viewOf(data);
     std::vector<uint8_t> out;
     bool ok;
     {
       py::gil_scoped_release release;
-      ok = spz::compressGzippedParallel(reinterpret_cast<const uint8_t *>(in.data()), in.size(), &out, threads);
+      ok = spz::compressGzippedParallel(in.p, in.n, &out, threads);
     }
     if (!ok) throw std::runtime_error("compressGzippedParallel failed");
     return py::bytes(reinterpret_cast<const char *>(out.data()), out.size());
   }, py::arg("data"), py::arg("threads"), "Opt-in multi-threaded gzip (one member, independent deflate blocks).");
   m.def("_compress_gzipped_exact", [](const py::bytes &data, int threads, int windows_per_chunk, size_t verify_prefix) -> py::object {
-    const std::string in = data;
+    const BytesView in = viewOf(data);
     std::vector<uint8_t> out;
     bool ok;
     {
       py::gil_scoped_release release;
-      ok = spz::exactgz::compress(reinterpret_cast<const uint8_t *>(in.data()), in.size(), threads, windows_per_chunk, &out,
+      ok = spz::exactgz::compress(in.p, in.n, threads, windows_per_chunk, &out,
                                   verify_prefix);
     }
     if (!ok) return py::none();
@@ -252,9 +266,9 @@ PYBIND11_MODULE(spz, m) {
   m.def("_parallel_inflate_count", []() { return spz::pinflate::successCount(); },
         "Members inflated by the parallel single-stream reader so far in this process.");
   m.def("_decompress_gzipped", [](const py::bytes &data) -> py::object {
-    const std::string in = data;
+    const BytesView in = viewOf(data);
     std::vector<uint8_t> out;
-    if (!spz::decompressGzipped(reinterpret_cast<const uint8_t *>(in.data()), in.size(), &out)) return py::none();
+    if (!spz::decompressGzipped(in.p, in.n, &out)) return py::none();
     return py::bytes(reinterpret_cast<const char *>(out.data()), out.size());
   }, "Inverse of _compress_gzipped; None on failure.");
   m.def("_save_spz_bytes", [](const spz::GaussianCloud &g, const spz::PackOptions &o) -> py::object {
@@ -266,9 +280,8 @@ PYBIND11_MODULE(spz, m) {
     return py::bytes(reinterpret_cast<const char *>(out.data()), out.size());
   }, py::arg("gaussians"), py::arg("options"), "saveSpz(cloud, options, &vector) -> .spz bytes in memory.");
   m.def("_load_spz_bytes", [](const py::bytes &data, const spz::UnpackOptions &o) {
-    const std::string in = data;
-    spz::GaussianCloud g = spz::loadSpz(reinterpret_cast<const uint8_t *>(in.data()),
-                                        static_cast<int32_t>(in.size()), o);
+    const BytesView in = viewOf(data);
+    spz::GaussianCloud g = spz::loadSpz(in.p, static_cast<int32_t>(in.n), o);
     if (g.numPoints == 0) raiseIfDeviceUnusable();
     return g;
   }, py::arg("data"), py::arg("options") = spz::UnpackOptions(), "loadSpz(ptr, size, options) from .spz bytes.");
@@ -276,12 +289,12 @@ PYBIND11_MODULE(spz, m) {
                               bool gzipped) -> py::object {
     // loadSpzPacked (or deserializePackedGaussians for a raw stream) + PackedGaussians::at / unpack:
     // returns (65 packed bytes, 59 floats) in the field order of PackedGaussian / UnpackedGaussian.
-    const std::string in = data;
+    const BytesView in = viewOf(data);
     spz::PackedGaussians packed;
     if (gzipped) {
-      packed = spz::loadSpzPacked(reinterpret_cast<const uint8_t *>(in.data()), static_cast<int32_t>(in.size()));
+      packed = spz::loadSpzPacked(in.p, static_cast<int32_t>(in.n));
     } else {
-      std::istringstream ss(in);
+      std::istringstream ss(std::string(reinterpret_cast<const char *>(in.p), in.n));
       packed = spz::deserializePackedGaussians(ss);
     }
     if (index < 0 || index >= packed.numPoints) return py::none();
@@ -302,12 +315,12 @@ PYBIND11_MODULE(spz, m) {
      "PackedGaussians::at(i) bytes and PackedGaussians::unpack(i, coordinateConverter(from, to)) floats.");
   m.def("_unpack_indices", [](const py::bytes &data, const std::vector<uint32_t> &indices, const spz::UnpackOptions &o,
                                bool gzipped) {
-    const std::string in = data;
+    const BytesView in = viewOf(data);
     spz::PackedGaussians packed;
     if (gzipped) {
-      packed = spz::loadSpzPacked(reinterpret_cast<const uint8_t *>(in.data()), static_cast<int32_t>(in.size()));
+      packed = spz::loadSpzPacked(in.p, static_cast<int32_t>(in.n));
     } else {
-      std::istringstream ss(in);
+      std::istringstream ss(std::string(reinterpret_cast<const char *>(in.p), in.n));
       packed = spz::deserializePackedGaussians(ss);
     }
     spz::setLastDeviceStatus(SPZ_AMD_OK);
@@ -317,8 +330,8 @@ PYBIND11_MODULE(spz, m) {
   }, py::arg("data"), py::arg("indices"), py::arg("options") = spz::UnpackOptions(), py::arg("gzipped") = true,
      "unpackIndices(loadSpzPacked(data), indices, options): one gather launch.");
   m.def("_unpack_from_stream", [](const py::bytes &data, const spz::UnpackOptions &o) {
-    const std::string in = data;
-    spz::GaussianCloud g = spz::unpackFromStream(reinterpret_cast<const uint8_t *>(in.data()), in.size(), o);
+    const BytesView in = viewOf(data);
+    spz::GaussianCloud g = spz::unpackFromStream(in.p, in.n, o);
     if (g.numPoints == 0) raiseIfDeviceUnusable();
     return g;
   }, py::arg("data"), py::arg("options") = spz::UnpackOptions(), "Cloud of a raw (pre-gzip) stream: loadSpz without the gunzip step.");
