@@ -363,6 +363,38 @@ def test_shards_reassemble_to_the_single_stream(dev):
             assert torch.equal(part[k].view(torch.int32), full[k][a * f:b * f].view(torch.int32)), (a, b, k)
 
 
+def test_section_masked_encodes_add_up_to_the_full_stream(dev, oracle):
+    """spz_amd_encode_shard_sections_device: the five small sections in one launch (with the header), the sh section in
+    another — what a rank of the multi-GPU path does so that its small fragments travel while sh is still encoding —
+    give the oracle's stream; so do six launches of one section each, for a shard in the middle of a larger stream
+    too.  SH0 has no sh section: its mask launches nothing and must not fail."""
+    import torch
+    from spz_amd import abi, device as D
+    from spz_amd.synth import make_cloud_numpy, floats_per_point
+    for n, deg in ((250_007, 3), (40_003, 1), (70_001, 0)):
+        c = make_cloud_numpy(n, deg, 90 + deg)
+        t = D.to_device(c, dev)
+        want = oracle.pack(c, n, deg, True, 6)
+        out = torch.zeros(want.size, dtype=torch.uint8, device=dev)
+        D.encode_shard(t, 0, n, n, deg, out, antialiased=True, from_coord=6, write_header=True, section_mask=abi.SMALL_SECTIONS)
+        D.encode_shard(t, 0, n, n, deg, out, antialiased=True, from_coord=6, section_mask=abi.SH_SECTION)
+        torch.cuda.synchronize()
+        assert_bytes_equal(out.cpu().numpy(), want, f"small sections + sh, degree {deg}")
+        out.zero_()
+        a, b = n // 3 // 16 * 16, n // 3 * 2
+        for first, count in ((0, a), (a, b - a), (b, n - b)):
+            sub = {k: t[k][first * floats_per_point(k, deg):(first + count) * floats_per_point(k, deg)].contiguous() for k in FIELDS}
+            for sec in range(6):
+                D.encode_shard(sub, first, count, n, deg, out, antialiased=True, from_coord=6,
+                               write_header=(first == 0 and sec == 0), section_mask=1 << sec)
+        torch.cuda.synchronize()
+        assert_bytes_equal(out.cpu().numpy(), want, f"eighteen single-section shard launches, degree {deg}")
+    L = abi.load_library()
+    p = D._ptrs(t, 0, n, dev)
+    assert L.spz_amd_encode_shard_sections_device(C.byref(p), 0, n, n, 0, 0, 0, 3, 0, 0x40, out.data_ptr(), out.numel(), None) \
+        == abi.ERR_INVALID_ARG
+
+
 def test_host_pointer_entry_points(dev, oracle):
     """spz_amd_encode_host / spz_amd_decode_host (what the C++ saveSpz/loadSpz layer calls)."""
     from spz_amd import abi
@@ -1060,6 +1092,39 @@ def test_rccl_gatherv_native_on_one_gpu(dev, oracle):
         want = oracle.pack(c, n, deg, True, 6)
         assert_bytes_equal(glob.cpu().numpy()[16:], want[16:], "fragments after the self-exchange")
         assert not glob[:16].any(), "the gatherv moves fragments only; the header is the root's to write"
+        # the choreography of bench.py's native route, on this one rank: small sections encoded, their fragments sent on a
+        # communication stream while the sh section encodes, double-buffered over several steps with different clouds
+        from spz_amd import shard as S
+        t = D.to_device(c, dev)
+        comm_stream = torch.cuda.Stream(device=dev)
+        bufs = [torch.zeros_like(local) for _ in range(2)]
+        globs = [torch.zeros_like(local) for _ in range(2)]
+        done = [None, None]
+        wants = []
+        for step in range(5):
+            b = step % 2
+            if done[b] is not None:
+                torch.cuda.current_stream().wait_event(done[b])
+            cs = make_cloud_numpy(n, deg, 200 + step)
+            ts = D.to_device(cs, dev)
+            wants.append(oracle.pack(cs, n, deg, False, 6))
+            ev_small, ev_sh = torch.cuda.Event(), torch.cuda.Event()
+            D.encode_shard(ts, 0, n, n, deg, bufs[b], from_coord=6, write_header=True, section_mask=abi.SMALL_SECTIONS)
+            ev_small.record()
+            D.encode_shard(ts, 0, n, n, deg, bufs[b], from_coord=6, section_mask=abi.SH_SECTION)
+            ev_sh.record()
+            for ev, mask in ((ev_small, abi.SMALL_SECTIONS), (ev_sh, abi.SH_SECTION)):
+                comm_stream.wait_event(ev)
+                rc = L.spz_amd_gatherv_rccl(comm, 0, 1, 0, first, count, deg, 3, bufs[b].data_ptr(), globs[b].data_ptr(), mask,
+                                            comm_stream.cuda_stream)
+                assert rc == 0, (rc, L.spz_amd_last_rccl_error())
+            done[b] = torch.cuda.Event()
+            done[b].record(comm_stream)
+            if step >= 1:   # the previous step's buffer has landed by the time its event has passed
+                pb = (step - 1) % 2
+                done[pb].synchronize()
+                assert_bytes_equal(globs[pb].cpu().numpy()[16:], wants[step - 1][16:], f"overlapped exchange, step {step - 1}")
+        del ts, t
         # the mirror image: the global stream's fragments back into a stream of the rank's own, then decoded there
         back = torch.zeros_like(local)
         back[:16] = local[:16]
