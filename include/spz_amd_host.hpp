@@ -145,7 +145,10 @@ GaussianCloud loadSplatFromPly(const std::string &filename, const UnpackOptions 
 void serializePackedGaussians(const PackedGaussians &packed, std::ostream *out);
 // load-spz.cc:186-214.  The bytes are zlib's (level 6, one deflate stream, gzip wrapper): for inputs of
 // 1 MiB and more they are produced by a multi-threaded writer that reproduces zlib 1.2.11's output exactly
-// (SPZ_AMD_GZIP_EXACT_THREADS, default min(cores, 32); 1 = zlib itself), otherwise by zlib.
+// (SPZ_AMD_GZIP_EXACT_THREADS, default min(usable CPUs, 32); 1 = zlib itself), otherwise by zlib — and by zlib
+// too when the machine has less free memory than 4.5 x the input (the writer holds ~3 bytes per input byte
+// until it assembles the member).  SPZ_AMD_GZIP_VERIFY=1 inflates the finished member and compares it with the
+// input before returning it, =2 also compares it byte for byte with zlib's own member; a failed check returns zlib's.
 bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out);
 
 // External-linkage internals of the reference (load-spz.cc:257,467,548), kept because
@@ -167,8 +170,9 @@ bool decompressGzipped(const uint8_t *compressed, size_t size, std::vector<uint8
 // every gzip reader including the reference's loadSpz, NOT byte-identical to compressGzipped.  saveSpz uses it when the environment sets SPZ_AMD_GZIP_THREADS > 1.
 bool compressGzippedParallel(const uint8_t *data, size_t size, std::vector<uint8_t> *out, int threads);
 // Bulk random access: the points `indices` of a packed cloud, decoded by one gather
-// launch into a GaussianCloud of indices.size() points (same arithmetic as unpackGaussians; indices
-// past the end are clamped to the last point).  Empty cloud on failure.
+// launch into a GaussianCloud of indices.size() points (same arithmetic as unpackGaussians).  An index
+// past the end is an error: empty cloud + log line, lastDeviceStatus() = SPZ_AMD_ERR_INVALID_ARG (the
+// device-pointer form spz_amd_decode_gather_device clamps instead, as its header says).  Empty cloud on failure.
 GaussianCloud unpackIndices(const PackedGaussians &packed, const std::vector<uint32_t> &indices,
                             const UnpackOptions &o);
 // Raw (pre-gzip) stream <-> cloud, i.e. saveSpz / loadSpz without the zlib step.
