@@ -983,27 +983,50 @@ int spz_amd_convert_coordinates_host(float *h_positions, float *h_rotations, flo
   DeviceGuard guard;
   int rc = guard.enter(device);
   if (rc != SPZ_AMD_OK) return rc;
-  const size_t cnt[3] = {n * 3, n * 4, n * (size_t)sd * 3};
+  const size_t fpp[3] = {3, 4, (size_t)sd * 3};  // floats per point: positions, rotations, sh
   float *hp[3] = {h_positions, h_rotations, h_sh};
-  size_t total = 0;
-  for (int i = 0; i < 3; ++i) total += (hp[i] && cnt[i]) ? Workspace::aligned(cnt[i] * sizeof(float)) : 0;
+  size_t total = 0, bytes_per_point = 0;
+  for (int i = 0; i < 3; ++i) {
+    if (!hp[i] || !fpp[i]) continue;
+    total += Workspace::aligned(n * fpp[i] * sizeof(float));
+    bytes_per_point += fpp[i] * sizeof(float);
+  }
+  if (total == 0) return SPZ_AMD_OK;
   Workspace ws;
   rc = ws.open(device, total);
   if (rc != SPZ_AMD_OK) return rc;
-  void *b[3] = {nullptr, nullptr, nullptr};
+  float *b[3] = {nullptr, nullptr, nullptr};
   for (int i = 0; i < 3; ++i) {
-    if (!hp[i] || !cnt[i]) continue;
-    b[i] = ws.take(cnt[i] * sizeof(float));
-    SPZ_HIP_TRY(hipMemcpyAsync(b[i], hp[i], cnt[i] * sizeof(float), hipMemcpyHostToDevice, nullptr));
+    if (hp[i] && fpp[i]) b[i] = static_cast<float *>(ws.take(n * fpp[i] * sizeof(float)));
   }
-  rc = spz_amd_convert_coordinates_device((float *)b[0], (float *)b[1], (float *)b[2], n, sh_degree, from_coord,
-                                          to_coord, nullptr);
-  if (rc != SPZ_AMD_OK) return rc;
-  for (int i = 0; i < 3; ++i) {
-    if (b[i]) SPZ_HIP_TRY(hipMemcpyAsync(hp[i], b[i], cnt[i] * sizeof(float), hipMemcpyDeviceToHost, nullptr));
-  }
-  SPZ_HIP_TRY(hipStreamSynchronize(nullptr));
-  return SPZ_AMD_OK;
+  HostPipe *pipe = ws.pipe();
+  uint64_t cp = 0;
+  const int chunks = plan_chunks(n, bytes_per_point, &cp);
+  // the same pipeline as encode / decode: chunk k+1 goes up and is flipped while chunk k-1 comes back (the pass is
+  // element-wise and its sh pattern repeats per point, so any point range is a pass of its own)
+  auto up = [&](int k) -> int {
+    const uint64_t first = (uint64_t)k * cp, count = std::min<uint64_t>(cp, n - first);
+    for (int i = 0; i < 3; ++i) {
+      if (b[i]) {
+        SPZ_HIP_TRY(hipMemcpyAsync(b[i] + first * fpp[i], hp[i] + first * fpp[i], count * fpp[i] * sizeof(float),
+                                   hipMemcpyHostToDevice, pipe->up));
+      }
+    }
+    return spz_amd_convert_coordinates_device(b[0] ? b[0] + first * 3 : nullptr, b[1] ? b[1] + first * 4 : nullptr,
+                                              b[2] ? b[2] + first * fpp[2] : nullptr, count, sh_degree, from_coord, to_coord,
+                                              pipe->up);
+  };
+  auto down = [&](int k) -> int {
+    const uint64_t first = (uint64_t)k * cp, count = std::min<uint64_t>(cp, n - first);
+    for (int i = 0; i < 3; ++i) {
+      if (b[i]) {
+        SPZ_HIP_TRY(hipMemcpyAsync(hp[i] + first * fpp[i], b[i] + first * fpp[i], count * fpp[i] * sizeof(float),
+                                   hipMemcpyDeviceToHost, pipe->down));
+      }
+    }
+    return SPZ_AMD_OK;
+  };
+  return run_pipeline(pipe, device, chunks, up, down);
 }
 
 int spz_amd_selftest_device(int mode, uint64_t begin, uint64_t count, uint64_t result[3], void *hip_stream) {

@@ -455,6 +455,16 @@ def test_host_pipeline_of_several_chunks(dev, oracle):
     assert back.num_points == n and back.sh_degree == deg and back.antialiased
     for k in FIELDS:
         assert_bits_equal(np.asarray(getattr(back, k)), w[k], f"unpackFromStream, 4 chunks: {k}")
+    # GaussianCloud::convertCoordinates on host arrays runs through the same pipeline (7 chunks here)
+    m3 = 3_000_001
+    c3 = make_cloud_numpy(m3, deg, 63)
+    want_p, want_r, want_s = oracle.convert_coordinates(c3["positions"], c3["rotations"], c3["sh"], m3, deg, abi.RDF, abi.LUF)
+    hp, hr, hs = c3["positions"].copy(), c3["rotations"].copy(), c3["sh"].copy()
+    abi.check(L.spz_amd_convert_coordinates_host(hp.ctypes.data, hr.ctypes.data, hs.ctypes.data, m3, deg, abi.RDF, abi.LUF, 0),
+              "convert_coordinates_host")
+    assert_bits_equal(hp, want_p, "convertCoordinates host, positions")
+    assert_bits_equal(hr, want_r, "convertCoordinates host, rotations")
+    assert_bits_equal(hs, want_s, "convertCoordinates host, sh")
     # no point limit on the unpackGaussians route (load-spz.cc:467-531); the loadSpz route keeps the reader's cap
     m = 16_000_000
     big = np.zeros(abi.stream_layout(m, 0, 3).total_bytes, np.uint8)

@@ -116,6 +116,18 @@ int main(int argc, char **argv) {
          "\"pack_GBps_over_pcie\": %.1f, \"unpack_GBps_over_pcie\": %.1f, \"stream_checksum\": \"%016llx\", \"floats_checksum\": \"%016llx\"",
          n, deg, fb / 1e9, sb / 1e9, std::thread::hardware_concurrency(), first_pack, pack_fresh, pack_reuse, first_unpack, unpack,
          abi_enc, abi_dec, (fb + sb) / 1e9 / pack_fresh, (fb + sb) / 1e9 / unpack, (unsigned long long)sum_stream, (unsigned long long)sum_floats);
+  {  // GaussianCloud::convertCoordinates on the host arrays (positions, rotations, sh up, flipped, down): there and back
+    spz::GaussianCloud c = g;
+    double best = 1e30;
+    for (int r = 0; r < reps; ++r) {
+      const double t0 = now();
+      c.convertCoordinates(spz::CoordinateSystem::RDF, spz::CoordinateSystem::LUF);
+      c.convertCoordinates(spz::CoordinateSystem::LUF, spz::CoordinateSystem::RDF);
+      best = std::min(best, (now() - t0) / 2);
+    }
+    const bool same = std::memcmp(c.sh.data(), g.sh.data(), g.sh.size() * 4) == 0 && std::memcmp(c.positions.data(), g.positions.data(), g.positions.size() * 4) == 0;
+    printf(", \"convert_coordinates_s\": %.4f, \"convert_coordinates_round_trip_identical\": %s", best, same ? "true" : "false");
+  }
   if (gzip) {
     std::vector<uint8_t> file;
     double t0 = now();
