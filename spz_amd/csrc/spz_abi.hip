@@ -307,6 +307,17 @@ void interleave_sections(KParams *p) {
   }
 }
 
+// SPZ_AMD_GRID_ORDER (read at every launch): "sequential" / "interleaved" override the per-launch policy of the tile
+// order — which of the two is faster for an sh3 decode depends on where the buffers lie, so a caller that
+// can measure its own placement may want to choose.  Anything else: the policy.
+int grid_order_override() {
+  const char *e = std::getenv("SPZ_AMD_GRID_ORDER");
+  if (e == nullptr) return 0;
+  if (std::strcmp(e, "sequential") == 0) return 1;
+  if (std::strcmp(e, "interleaved") == 0) return 2;
+  return 0;
+}
+
 int layout_impl(uint64_t n, int sh_degree, int version, spz_amd_layout *out) {
   const int sd = sh_dim_for_degree(sh_degree);
   if (sd < 0 || version < 1 || version > 3 || out == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
@@ -372,7 +383,10 @@ int encode_impl(const spz_amd_cloud_in *cl, uint64_t first, uint64_t count, uint
     p.header_words[3] = (uint32_t)sh_degree | (12u << 8) | ((antialiased ? 1u : 0u) << 16);
   }
   if (p.total_tiles == 0 && !write_header) return SPZ_AMD_OK;
-  if (SPZ_ENC_INTERLEAVE == 1 || (SPZ_ENC_INTERLEAVE == 2 && sd == 0)) interleave_sections(&p);
+  {
+    const int order = grid_order_override();
+    if (order == 2 || (order == 0 && (SPZ_ENC_INTERLEAVE == 1 || (SPZ_ENC_INTERLEAVE == 2 && sd == 0)))) interleave_sections(&p);
+  }
   uint32_t grid = 1;
   rc = grid_for(device, p.total_tiles, &grid);
   if (rc != SPZ_AMD_OK) return rc;
@@ -449,7 +463,10 @@ int decode_impl(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr,
 #endif
   // policy: with an sh section (every box measured gains at degrees 1 and 2; at degree 3 with runs of 8 tiles, see
   // SPZ_IL_GROUP); not without sh (loses up to 13 %)
-  if (!SPZ_DEC_REVERSE && (SPZ_DEC_INTERLEAVE == 1 || (SPZ_DEC_INTERLEAVE == 2 && sd > 0))) interleave_sections(&p);
+  if (!SPZ_DEC_REVERSE) {
+    const int order = grid_order_override();
+    if (order == 2 || (order == 0 && (SPZ_DEC_INTERLEAVE == 1 || (SPZ_DEC_INTERLEAVE == 2 && sd > 0)))) interleave_sections(&p);
+  }
   uint32_t grid = 1;
   rc = grid_for(device, p.total_tiles, &grid);
   if (rc != SPZ_AMD_OK) return rc;

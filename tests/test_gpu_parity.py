@@ -395,6 +395,26 @@ def test_section_masked_encodes_add_up_to_the_full_stream(dev, oracle):
         == abi.ERR_INVALID_ARG
 
 
+def test_grid_order_override_changes_nothing_but_the_order(dev, oracle):
+    """SPZ_AMD_GRID_ORDER=sequential / interleaved (read at every launch) forces the tile order of both kernels; bytes and
+    floats are the oracle's either way, for every degree, and for a size with a ragged tail of tiles."""
+    import os
+    from spz_amd.synth import make_cloud_numpy
+    try:
+        for deg, n in ((3, 400_003), (2, 250_001), (1, 300_007), (0, 700_001)):
+            c = make_cloud_numpy(n, deg, 120 + deg)
+            want = oracle.pack(c, n, deg, True, 6)
+            rc, w = oracle.unpack(want, 7)
+            for order in ("sequential", "interleaved", "policy"):
+                os.environ["SPZ_AMD_GRID_ORDER"] = order
+                assert_bytes_equal(gpu_encode(c, n, deg, True, 6, dev), want, f"encode, {order}, degree {deg}")
+                _, u = gpu_decode(want, 7, dev)
+                for k in FIELDS:
+                    assert_bits_equal(u[k], w[k], f"decode {k}, {order}, degree {deg}")
+    finally:
+        os.environ.pop("SPZ_AMD_GRID_ORDER", None)
+
+
 def test_host_pointer_entry_points(dev, oracle):
     """spz_amd_encode_host / spz_amd_decode_host (what the C++ saveSpz/loadSpz layer calls)."""
     from spz_amd import abi
