@@ -1,7 +1,7 @@
 # Top-level build: everything is built IN-TREE (the .so files travel to the GPU box with
 # gpurun; they are git-ignored).  `python -c "import __graft_entry__ as g; g.build()"` runs this.
 #
-#   spz_amd/lib/libspz_amd.so    HIP kernels (spz_kernels.hip, spz_ply_kernels.hip, spz_median.hip) + C ABI (spz_abi.hip, spz_exchange.hip)   (hipcc, gfx950)
+#   spz_amd/lib/libspz_amd.so    HIP kernels (spz_kernels.hip, spz_ply_kernels.hip, spz_median.hip) + C ABI (spz_abi.hip, spz_hostpath.hip, spz_exchange.hip)   (hipcc, gfx950)
 #   spz_amd/lib/libspz_host.so   C++ drop-in layer spz::saveSpz/loadSpz + gzip (g++, zlib)
 #   spz_amd/spz*.so              Python module `spz` (pybind11) over the C++ layer
 #   spz_amd/bin/{ply_to_spz,spz_to_ply,spz_info}   the reference's three CLI tools over the C++ layer
@@ -31,7 +31,7 @@ host:   $(LIBDIR)/libspz_host.so
 python: $(ROOT)spz_amd/spz$(PYEXT)
 cli:    $(ROOT)spz_amd/bin/spz_tool $(ROOT)spz_amd/bin/dropin_user_test $(ROOT)spz_amd/bin/host_bench
 
-DEVICE_SRCS := $(CSRC)/spz_kernels.hip $(CSRC)/spz_abi.hip $(CSRC)/spz_ply_kernels.hip $(CSRC)/spz_median.hip $(CSRC)/spz_exchange.hip
+DEVICE_SRCS := $(CSRC)/spz_kernels.hip $(CSRC)/spz_abi.hip $(CSRC)/spz_hostpath.hip $(CSRC)/spz_ply_kernels.hip $(CSRC)/spz_median.hip $(CSRC)/spz_exchange.hip
 $(LIBDIR)/libspz_amd.so: $(DEVICE_SRCS) $(CSRC)/spz_common.hpp $(CSRC)/spz_kernel_params.hpp $(INC)/spz_amd.h
 	mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(DEVICE_SRCS) -ldl

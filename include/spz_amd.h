@@ -216,7 +216,7 @@ int spz_amd_convert_coordinates_device(float *d_positions, float *d_rotations, f
                                        uint64_t num_points, int sh_degree, int from_coord,
                                        int to_coord, void *hip_stream);
 
-/* ---- host-pointer entry points: H2D, kernel, D2H on `device`; blocking.  Calls of more than ~96 MB of
+/* ---- host-pointer entry points: H2D, kernel, D2H on `device`; blocking.  Calls of more than 160 MiB of
  *      floats run as a pipeline of point-range chunks (upload of chunk k+1, kernel on chunk k and
  *      download of chunk k-1 overlap; environment SPZ_AMD_HOST_CHUNK_MIB sets the chunk size).  The device
  *      staging memory is one grow-only allocation per device, kept until spz_amd_release_device_memory().

@@ -4,7 +4,9 @@ Layout:
   csrc/spz_kernels.hip  hand-written HIP pack/unpack/flip kernels (gfx950)
   csrc/spz_ply_kernels.hip  .ply row <-> cloud shuffles
   csrc/spz_median.hip   radix selection of the median scale sum (medianVolume)
-  csrc/spz_abi.hip      the C ABI (include/spz_amd.h) over them
+  csrc/spz_abi.hip      the C ABI (include/spz_amd.h) over them: device-pointer entry points
+  csrc/spz_hostpath.hip host-pointer entry points: device workspace + chunked H2D/kernel/D2H pipeline
+  csrc/spz_exchange.hip multi-GPU exchange: native RCCL gatherv/scatterv, IPC-mapped root stream
   csrc/spz_host.cpp     C++ drop-in layer: namespace spz saveSpz/loadSpz/... + host gzip
   csrc/spz_deflate.cpp  multi-threaded gzip writer with zlib's exact bytes (the default container stage)
   csrc/spz_inflate.cpp  multi-threaded, CRC-verified inflate of ordinary single-stream members

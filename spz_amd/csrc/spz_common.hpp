@@ -1,5 +1,6 @@
 // spz_common.hpp — pieces shared by the HIP translation units of libspz_amd.so
-// (spz_kernels.hip: pack/unpack/flip kernels + C ABI; spz_ply_kernels.hip: .ply row shuffles).
+// (spz_kernels.hip + spz_abi.hip: pack/unpack/flip kernels and their device entry points; spz_hostpath.hip: the
+// host-pointer entry points; spz_ply_kernels.hip: .ply row shuffles; spz_median.hip; spz_exchange.hip).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -65,6 +66,16 @@ inline FlipMasks flip_masks(int from, int to) {
 
 inline bool valid_coord(int c) { return c >= 0 && c <= 8; }
 
+inline int sh_dim_for_degree(int d) {  // load-spz.cc:58-72
+  switch (d) {
+    case 0: return 0;
+    case 1: return 3;
+    case 2: return 8;
+    case 3: return 15;
+    default: return -1;
+  }
+}
+
 // Current HIP device, or SPZ_AMD_ERR_NO_DEVICE when the runtime has none.
 inline int current_device(int *device) {
   int n = 0;
@@ -82,7 +93,7 @@ inline int current_device(int *device) {
 // (a 10 M-point SH3 save needs 3 GB of it; allocating and freeing that per call cost more than the
 // copies), guarded by a per-device mutex that is held for the duration of the host call and released by
 // spz_amd_release_device_memory().  With it live the two copy streams and the events of the chunked
-// H2D / kernel / D2H pipeline (spz_abi.hip).
+// H2D / kernel / D2H pipeline (spz_hostpath.hip).
 constexpr int kPipeChunksMax = 64;
 struct HostPipe {
   hipStream_t up = nullptr, down = nullptr;   // uploads + kernels / downloads

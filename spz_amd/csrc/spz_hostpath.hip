@@ -1,0 +1,420 @@
+// spz_hostpath.hip — the host-pointer (PCIe) entry points of include/spz_amd.h: what GaussianCloud-level
+// callers reach (saveSpz/loadSpz hand over host vectors, load-spz.cc:258-331,483-531).  The cached device
+// workspace, the two copy streams and the chunked upload / kernel / download pipeline live here; the
+// kernels are reached only through the device entry points of spz_abi.hip, so nothing in this file
+// decides what a kernel launch looks like (it is not one of the sources profiles/pmc_traffic.json hashes).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdint>
+#include <cstdlib>
+#include <mutex>
+#include <system_error>
+#include <thread>
+
+#include "spz_amd.h"
+#include "spz_common.hpp"
+
+namespace spz_amd_detail {
+
+namespace {
+std::mutex g_ws_mutex[kMaxDevices];
+void *g_ws_ptr[kMaxDevices] = {};
+size_t g_ws_cap[kMaxDevices] = {};
+HostPipe g_pipe[kMaxDevices];
+constexpr int kPipeEvents = kPipeChunksMax;  // one event per chunk of a host call
+
+hipError_t pipe_create(HostPipe *p) {
+  if (p->up) return hipSuccess;
+  hipError_t e = hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking);
+  if (e == hipSuccess) {
+    p->events = new hipEvent_t[kPipeEvents];
+    for (p->n_events = 0; p->n_events < kPipeEvents && e == hipSuccess; ++p->n_events) {
+      e = hipEventCreateWithFlags(&p->events[p->n_events], hipEventDisableTiming);
+    }
+  }
+  return e;
+}
+
+void pipe_destroy(HostPipe *p) {
+  for (int i = 0; i < p->n_events; ++i) (void)hipEventDestroy(p->events[i]);
+  delete[] p->events;
+  if (p->up) (void)hipStreamDestroy(p->up);
+  if (p->down) (void)hipStreamDestroy(p->down);
+  *p = HostPipe();
+}
+}  // namespace
+
+int workspace_acquire(int device, size_t bytes, void **base, HostPipe **pipe) {
+  if (device < 0 || device >= kMaxDevices) return SPZ_AMD_ERR_INVALID_ARG;
+  g_ws_mutex[device].lock();
+  *base = nullptr;
+  hipError_t e = pipe_create(&g_pipe[device]);
+  if (e == hipSuccess && g_ws_cap[device] < bytes) {
+    if (g_ws_ptr[device]) (void)hipFree(g_ws_ptr[device]);
+    g_ws_ptr[device] = nullptr;
+    g_ws_cap[device] = 0;
+    size_t want = bytes < (size_t(1) << 20) ? (size_t(1) << 20) : bytes;
+    e = hipMalloc(&g_ws_ptr[device], want);
+    if (e == hipSuccess) g_ws_cap[device] = want;
+  }
+  if (e != hipSuccess) {
+    g_last_hip_error = (int)e;
+    g_ws_mutex[device].unlock();
+    return SPZ_AMD_ERR_HIP;
+  }
+  *base = g_ws_ptr[device];
+  *pipe = &g_pipe[device];
+  return SPZ_AMD_OK;
+}
+
+void workspace_release(int device) { g_ws_mutex[device].unlock(); }
+
+void workspace_free_all() {
+  int prev = 0;
+  if (hipGetDevice(&prev) != hipSuccess) return;
+  for (int d = 0; d < kMaxDevices; ++d) {
+    std::lock_guard<std::mutex> lock(g_ws_mutex[d]);
+    if (g_ws_ptr[d] || g_pipe[d].up) {
+      if (hipSetDevice(d) == hipSuccess) {
+        if (g_ws_ptr[d]) (void)hipFree(g_ws_ptr[d]);
+        pipe_destroy(&g_pipe[d]);
+      }
+      g_ws_ptr[d] = nullptr;
+      g_ws_cap[d] = 0;
+    }
+  }
+  (void)hipSetDevice(prev);
+}
+}  // namespace spz_amd_detail
+
+namespace {
+
+using namespace spz_amd_detail;
+
+// ---- chunked host pipeline -------------------------------------------------------------------
+// PCIe is full duplex and the kernels are ~50x faster than the link, so a host-pointer call is cut into
+// point-range chunks (the stream is attribute-major: a chunk is six fragments, exactly the shard entry
+// points' geometry): the calling thread uploads chunk k and launches its kernel on pipe->up while a
+// second thread downloads the results of chunk k-1 on pipe->down.  Two host threads because a copy
+// between device and PAGEABLE host memory may occupy the thread that issues it.
+int plan_chunks(uint64_t n, size_t float_bytes_per_point, uint64_t *chunk_points) {
+  static const size_t target = []() {
+    const char *e = std::getenv("SPZ_AMD_HOST_CHUNK_MIB");
+    const long v = e ? std::atol(e) : 0;
+    return (size_t)(v > 0 ? v : 160) << 20;  // profiles/r02_host_chunk_scan.txt
+  }();
+  const unsigned long long total = n * float_bytes_per_point;
+  unsigned long long chunks = (total + target - 1) / target;
+  chunks = chunks < 1 ? 1 : (chunks > (unsigned long long)kPipeChunksMax ? (unsigned long long)kPipeChunksMax : chunks);
+  unsigned long long cp = (n + chunks - 1) / chunks;
+  cp = (cp + 1023ull) & ~1023ull;
+  *chunk_points = cp;
+  return (int)((n + cp - 1) / cp);
+}
+
+template <class Up, class Down>
+int run_pipeline(HostPipe *pipe, int device, int chunks, Up up, Down down) {
+  if (chunks > pipe->n_events) return SPZ_AMD_ERR_INVALID_ARG;
+  if (chunks == 1) {  // small calls: no second thread
+    int rc = up(0);
+    if (rc != SPZ_AMD_OK) return rc;
+    SPZ_HIP_TRY(hipEventRecord(pipe->events[0], pipe->up));
+    SPZ_HIP_TRY(hipStreamWaitEvent(pipe->down, pipe->events[0], 0));
+    rc = down(0);
+    hipError_t e = hipStreamSynchronize(pipe->down);
+    if (rc != SPZ_AMD_OK) return rc;
+    SPZ_HIP_TRY(e);
+    return SPZ_AMD_OK;
+  }
+  std::mutex m;
+  std::condition_variable cv;
+  int recorded = 0;      // events[0 .. recorded) have been recorded on pipe->up
+  bool stop = false;     // the uploader failed: the downloader must not wait for more
+  int down_rc = SPZ_AMD_OK, down_hip = 0;
+  auto download_all = [&]() {
+    int rc = SPZ_AMD_OK;
+    if (hipSetDevice(device) != hipSuccess) rc = SPZ_AMD_ERR_HIP;
+    for (int k = 0; k < chunks && rc == SPZ_AMD_OK; ++k) {
+      {
+        std::unique_lock<std::mutex> lock(m);
+        cv.wait(lock, [&]() { return recorded > k || stop; });
+        if (recorded <= k) break;
+      }
+      if (hipStreamWaitEvent(pipe->down, pipe->events[k], 0) != hipSuccess) rc = SPZ_AMD_ERR_HIP;
+      else rc = down(k);
+    }
+    const hipError_t e = hipStreamSynchronize(pipe->down);
+    if (rc == SPZ_AMD_OK && e != hipSuccess) {
+      g_last_hip_error = (int)e;
+      rc = SPZ_AMD_ERR_HIP;
+    }
+    down_rc = rc;
+    down_hip = g_last_hip_error;
+  };
+  std::thread downloader;
+  try {
+    downloader = std::thread(download_all);
+  } catch (const std::system_error &) {
+    // no second thread to be had: the chunks one after the other on this one (correct, not overlapped)
+    for (int k = 0; k < chunks; ++k) {
+      int rc = up(k);
+      if (rc != SPZ_AMD_OK) return rc;
+      SPZ_HIP_TRY(hipEventRecord(pipe->events[k], pipe->up));
+      SPZ_HIP_TRY(hipStreamWaitEvent(pipe->down, pipe->events[k], 0));
+      rc = down(k);
+      if (rc != SPZ_AMD_OK) return rc;
+    }
+    SPZ_HIP_TRY(hipStreamSynchronize(pipe->down));
+    return SPZ_AMD_OK;
+  }
+  int rc = SPZ_AMD_OK;
+  for (int k = 0; k < chunks && rc == SPZ_AMD_OK; ++k) {
+    rc = up(k);
+    if (rc == SPZ_AMD_OK && hipEventRecord(pipe->events[k], pipe->up) != hipSuccess) rc = SPZ_AMD_ERR_HIP;
+    {
+      std::lock_guard<std::mutex> lock(m);
+      if (rc == SPZ_AMD_OK) recorded = k + 1;
+      else stop = true;
+    }
+    cv.notify_one();
+  }
+  downloader.join();
+  if (rc != SPZ_AMD_OK) {
+    (void)hipStreamSynchronize(pipe->up);
+    return rc;
+  }
+  if (down_rc != SPZ_AMD_OK) {
+    g_last_hip_error = down_hip;
+    (void)hipStreamSynchronize(pipe->up);
+  }
+  return down_rc;
+}
+
+}  // namespace
+
+extern "C" {
+
+int spz_amd_encode_host(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int antialiased, int from_coord,
+                        int version, uint8_t *h_stream, size_t capacity, int device) {
+  if (h == nullptr || h_stream == nullptr || !valid_coord(from_coord)) return SPZ_AMD_ERR_INVALID_ARG;
+  spz_amd_layout lay;
+  int rc = spz_amd_stream_layout(n, sh_degree, version, &lay);
+  if (rc != SPZ_AMD_OK) return rc;
+  if (version == 1) return SPZ_AMD_ERR_UNSUPPORTED;
+  if (capacity < lay.total_bytes) return SPZ_AMD_ERR_CAPACITY;
+  const int sd = sh_dim_for_degree(sh_degree);
+  if (n > 0 && (!h->positions || !h->scales || !h->rotations || !h->alphas || !h->colors || (sd > 0 && !h->sh))) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  if (n == 0) {  // a zero-point stream is its header (:534-539): nothing for a device to do
+    const spz_amd_header hdr = {(uint32_t)version, 0u, (uint8_t)sh_degree, 12, (uint8_t)(antialiased ? 1 : 0), 0};
+    return spz_amd_write_header(&hdr, h_stream);
+  }
+  DeviceGuard guard;
+  rc = guard.enter(device);
+  if (rc != SPZ_AMD_OK) return rc;
+  const size_t fpp[6] = {3, 3, 4, 1, 3, (size_t)sd * 3};  // floats per point, spz_amd_cloud_in order
+  const float *src[6] = {h->positions, h->scales, h->rotations, h->alphas, h->colors, h->sh};
+  size_t total = Workspace::aligned(lay.total_bytes);
+  for (int i = 0; i < 6; ++i) total += Workspace::aligned(n * fpp[i] * sizeof(float));
+  Workspace ws;
+  rc = ws.open(device, total);
+  if (rc != SPZ_AMD_OK) return rc;
+  float *fb[6];
+  for (int i = 0; i < 6; ++i) fb[i] = static_cast<float *>(ws.take(n * fpp[i] * sizeof(float)));
+  uint8_t *sb = static_cast<uint8_t *>(ws.take(lay.total_bytes));
+  HostPipe *pipe = ws.pipe();
+  uint64_t cp = 0;
+  const int chunks = plan_chunks(n, (14 + (size_t)sd * 3) * sizeof(float), &cp);
+  // chunk k: upload the floats of points [k cp, ...), encode them into their six fragments of the device
+  // stream; the downloader copies those fragments (and, with the first chunk, the header) to the host
+  auto up = [&](int k) -> int {
+    const uint64_t first = (uint64_t)k * cp, count = std::min<uint64_t>(cp, n - first);
+    for (int i = 0; i < 6; ++i) {
+      if (fpp[i]) {
+        SPZ_HIP_TRY(hipMemcpyAsync(fb[i] + first * fpp[i], src[i] + first * fpp[i], count * fpp[i] * sizeof(float),
+                                   hipMemcpyHostToDevice, pipe->up));
+      }
+    }
+    const spz_amd_cloud_in d = {fb[0] + first * 3, fb[1] + first * 3, fb[2] + first * 4,
+                                fb[3] + first,     fb[4] + first * 3, fb[5] + first * fpp[5]};
+    return spz_amd_encode_shard_device(&d, first, count, n, sh_degree, antialiased, from_coord, version, k == 0 ? 1 : 0,
+                                       sb, lay.total_bytes, pipe->up);
+  };
+  auto down = [&](int k) -> int {
+    const uint64_t first = (uint64_t)k * cp, count = std::min<uint64_t>(cp, n - first);
+    if (k == 0) SPZ_HIP_TRY(hipMemcpyAsync(h_stream, sb, 16, hipMemcpyDeviceToHost, pipe->down));
+    for (int sec = 0; sec < SPZ_AMD_NUM_SECTIONS; ++sec) {
+      const uint64_t off = lay.offset[sec] + first * lay.bytes_per_point[sec], len = count * lay.bytes_per_point[sec];
+      if (len) SPZ_HIP_TRY(hipMemcpyAsync(h_stream + off, sb + off, len, hipMemcpyDeviceToHost, pipe->down));
+    }
+    return SPZ_AMD_OK;
+  };
+  return run_pipeline(pipe, device, chunks, up, down);
+}
+
+int spz_amd_decode_host_ex(const uint8_t *h_stream, size_t size, uint64_t max_points, int to_coord,
+                           const spz_amd_cloud_out *h, int device) {
+  if (h_stream == nullptr || h == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  spz_amd_header hdr;
+  int rc = spz_amd_peek_header_ex(h_stream, size, max_points, &hdr);
+  if (rc != SPZ_AMD_OK) return rc;
+  const uint64_t n = hdr.num_points;
+  if (n == 0) return SPZ_AMD_OK;
+  if (!valid_coord(to_coord)) return SPZ_AMD_ERR_INVALID_ARG;
+  spz_amd_layout lay;
+  rc = spz_amd_stream_layout(n, hdr.sh_degree, (int)hdr.version, &lay);
+  if (rc != SPZ_AMD_OK) return rc;
+  const int sd = sh_dim_for_degree(hdr.sh_degree);
+  if (!h->positions || !h->scales || !h->rotations || !h->alphas || !h->colors || (sd > 0 && !h->sh)) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  DeviceGuard guard;
+  rc = guard.enter(device);
+  if (rc != SPZ_AMD_OK) return rc;
+  const size_t fpp[6] = {3, 3, 4, 1, 3, (size_t)sd * 3};
+  float *dst[6] = {h->positions, h->scales, h->rotations, h->alphas, h->colors, h->sh};
+  size_t total = Workspace::aligned(lay.total_bytes);
+  for (int i = 0; i < 6; ++i) total += Workspace::aligned(n * fpp[i] * sizeof(float));
+  Workspace ws;
+  rc = ws.open(device, total);
+  if (rc != SPZ_AMD_OK) return rc;
+  uint8_t *sb = static_cast<uint8_t *>(ws.take(lay.total_bytes));
+  float *fb[6];
+  for (int i = 0; i < 6; ++i) fb[i] = static_cast<float *>(ws.take(n * fpp[i] * sizeof(float)));
+  HostPipe *pipe = ws.pipe();
+  uint64_t cp = 0;
+  const int chunks = plan_chunks(n, (14 + (size_t)sd * 3) * sizeof(float), &cp);
+  // chunk k: upload the six fragments of points [k cp, ...), decode them; the downloader copies the floats out
+  auto up = [&](int k) -> int {
+    const uint64_t first = (uint64_t)k * cp, count = std::min<uint64_t>(cp, n - first);
+    for (int sec = 0; sec < SPZ_AMD_NUM_SECTIONS; ++sec) {
+      const uint64_t off = lay.offset[sec] + first * lay.bytes_per_point[sec], len = count * lay.bytes_per_point[sec];
+      if (len) SPZ_HIP_TRY(hipMemcpyAsync(sb + off, h_stream + off, len, hipMemcpyHostToDevice, pipe->up));
+    }
+    const spz_amd_cloud_out d = {fb[0] + first * 3, fb[1] + first * 3, fb[2] + first * 4,
+                                 fb[3] + first,     fb[4] + first * 3, fb[5] + first * fpp[5]};
+    return spz_amd_decode_shard_device(sb, lay.total_bytes, &hdr, first, count, to_coord, &d, pipe->up);
+  };
+  auto down = [&](int k) -> int {
+    const uint64_t first = (uint64_t)k * cp, count = std::min<uint64_t>(cp, n - first);
+    for (int i = 0; i < 6; ++i) {
+      if (fpp[i]) {
+        SPZ_HIP_TRY(hipMemcpyAsync(dst[i] + first * fpp[i], fb[i] + first * fpp[i], count * fpp[i] * sizeof(float),
+                                   hipMemcpyDeviceToHost, pipe->down));
+      }
+    }
+    return SPZ_AMD_OK;
+  };
+  return run_pipeline(pipe, device, chunks, up, down);
+}
+
+int spz_amd_decode_host(const uint8_t *h_stream, size_t size, int to_coord, const spz_amd_cloud_out *h,
+                        int device) {
+  return spz_amd_decode_host_ex(h_stream, size, SPZ_AMD_REFERENCE_MAX_POINTS, to_coord, h, device);
+}
+
+int spz_amd_decode_gather_host(const uint8_t *h_stream, size_t size, uint64_t max_points, const uint32_t *h_indices,
+                               uint64_t count, int to_coord, const spz_amd_cloud_out *h, int device) {
+  if (h_stream == nullptr || h == nullptr || !valid_coord(to_coord)) return SPZ_AMD_ERR_INVALID_ARG;
+  spz_amd_header hdr;
+  int rc = spz_amd_peek_header_ex(h_stream, size, max_points, &hdr);
+  if (rc != SPZ_AMD_OK) return rc;
+  spz_amd_layout lay;
+  rc = spz_amd_stream_layout(hdr.num_points, hdr.sh_degree, (int)hdr.version, &lay);
+  if (rc != SPZ_AMD_OK) return rc;
+  if (size < lay.total_bytes) return SPZ_AMD_ERR_SHORT_STREAM;
+  if (count == 0) return SPZ_AMD_OK;
+  const int sd = sh_dim_for_degree(hdr.sh_degree);
+  if (hdr.num_points == 0 || h_indices == nullptr || !h->positions || !h->scales || !h->rotations || !h->alphas ||
+      !h->colors || (sd > 0 && !h->sh)) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  for (uint64_t i = 0; i < count; ++i) {
+    if (h_indices[i] >= hdr.num_points) return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  DeviceGuard guard;
+  rc = guard.enter(device);
+  if (rc != SPZ_AMD_OK) return rc;
+  const size_t cnt[6] = {count * 3, count * 3, count * 4, count, count * 3, count * (size_t)sd * 3};
+  float *dst[6] = {h->positions, h->scales, h->rotations, h->alphas, h->colors, h->sh};
+  size_t total = Workspace::aligned(lay.total_bytes) + Workspace::aligned(count * sizeof(uint32_t));
+  for (int i = 0; i < 6; ++i) total += Workspace::aligned(cnt[i] * sizeof(float));
+  Workspace ws;
+  rc = ws.open(device, total);
+  if (rc != SPZ_AMD_OK) return rc;
+  void *sb = ws.take(lay.total_bytes);
+  SPZ_HIP_TRY(hipMemcpyAsync(sb, h_stream, lay.total_bytes, hipMemcpyHostToDevice, nullptr));
+  void *ib = ws.take(count * sizeof(uint32_t));
+  SPZ_HIP_TRY(hipMemcpyAsync(ib, h_indices, count * sizeof(uint32_t), hipMemcpyHostToDevice, nullptr));
+  void *fb[6];
+  for (int i = 0; i < 6; ++i) fb[i] = ws.take(cnt[i] * sizeof(float));
+  spz_amd_cloud_out d = {(float *)fb[0], (float *)fb[1], (float *)fb[2], (float *)fb[3], (float *)fb[4], (float *)fb[5]};
+  rc = spz_amd_decode_gather_device((const uint8_t *)sb, lay.total_bytes, &hdr, (const uint32_t *)ib, count, to_coord, &d,
+                                    nullptr);
+  if (rc != SPZ_AMD_OK) return rc;
+  for (int i = 0; i < 6; ++i) {
+    if (cnt[i]) SPZ_HIP_TRY(hipMemcpyAsync(dst[i], fb[i], cnt[i] * sizeof(float), hipMemcpyDeviceToHost, nullptr));
+  }
+  SPZ_HIP_TRY(hipStreamSynchronize(nullptr));
+  return SPZ_AMD_OK;
+}
+
+int spz_amd_convert_coordinates_host(float *h_positions, float *h_rotations, float *h_sh, uint64_t n,
+                                     int sh_degree, int from_coord, int to_coord, int device) {
+  const int sd = sh_dim_for_degree(sh_degree);
+  if (sd < 0 || !valid_coord(from_coord) || !valid_coord(to_coord)) return SPZ_AMD_ERR_INVALID_ARG;
+  if (n == 0) return SPZ_AMD_OK;
+  DeviceGuard guard;
+  int rc = guard.enter(device);
+  if (rc != SPZ_AMD_OK) return rc;
+  const size_t fpp[3] = {3, 4, (size_t)sd * 3};  // floats per point: positions, rotations, sh
+  float *hp[3] = {h_positions, h_rotations, h_sh};
+  size_t total = 0, bytes_per_point = 0;
+  for (int i = 0; i < 3; ++i) {
+    if (!hp[i] || !fpp[i]) continue;
+    total += Workspace::aligned(n * fpp[i] * sizeof(float));
+    bytes_per_point += fpp[i] * sizeof(float);
+  }
+  if (total == 0) return SPZ_AMD_OK;
+  Workspace ws;
+  rc = ws.open(device, total);
+  if (rc != SPZ_AMD_OK) return rc;
+  float *b[3] = {nullptr, nullptr, nullptr};
+  for (int i = 0; i < 3; ++i) {
+    if (hp[i] && fpp[i]) b[i] = static_cast<float *>(ws.take(n * fpp[i] * sizeof(float)));
+  }
+  HostPipe *pipe = ws.pipe();
+  uint64_t cp = 0;
+  const int chunks = plan_chunks(n, bytes_per_point, &cp);
+  // the same pipeline as encode / decode: chunk k+1 goes up and is flipped while chunk k-1 comes back (the pass is
+  // element-wise and its sh pattern repeats per point, so any point range is a pass of its own)
+  auto up = [&](int k) -> int {
+    const uint64_t first = (uint64_t)k * cp, count = std::min<uint64_t>(cp, n - first);
+    for (int i = 0; i < 3; ++i) {
+      if (b[i]) {
+        SPZ_HIP_TRY(hipMemcpyAsync(b[i] + first * fpp[i], hp[i] + first * fpp[i], count * fpp[i] * sizeof(float),
+                                   hipMemcpyHostToDevice, pipe->up));
+      }
+    }
+    return spz_amd_convert_coordinates_device(b[0] ? b[0] + first * 3 : nullptr, b[1] ? b[1] + first * 4 : nullptr,
+                                              b[2] ? b[2] + first * fpp[2] : nullptr, count, sh_degree, from_coord, to_coord,
+                                              pipe->up);
+  };
+  auto down = [&](int k) -> int {
+    const uint64_t first = (uint64_t)k * cp, count = std::min<uint64_t>(cp, n - first);
+    for (int i = 0; i < 3; ++i) {
+      if (b[i]) {
+        SPZ_HIP_TRY(hipMemcpyAsync(hp[i] + first * fpp[i], b[i] + first * fpp[i], count * fpp[i] * sizeof(float),
+                                   hipMemcpyDeviceToHost, pipe->down));
+      }
+    }
+    return SPZ_AMD_OK;
+  };
+  return run_pipeline(pipe, device, chunks, up, down);
+}
+
+}  // extern "C"

@@ -438,7 +438,7 @@ def test_host_pointer_entry_points(dev, oracle):
 
 def test_host_pipeline_of_several_chunks(dev, oracle):
     """A host-pointer call big enough to run as a pipeline of point-range chunks (upload k+1 | kernel k |
-    download k-1 on two streams and two host threads): 1.3 M + 7 SH3 Gaussians = 4 chunks of 96 MB, the last
+    download k-1 on two streams and two host threads): 2.2 M + 7 SH3 Gaussians = 4 chunks of up to 160 MiB of floats, the last
     one ragged.  Bytes and floats equal the oracle's over the whole cloud; the C++ layer on top (fresh,
     not zero-filled vectors; pages mapped in the background) returns the same; a 16 M-point SH0 stream
     decodes through the unpackGaussians route although it is past the reference reader's 10 M cap."""
@@ -446,7 +446,7 @@ def test_host_pipeline_of_several_chunks(dev, oracle):
     from spz_amd import abi
     from spz_amd.synth import make_cloud_numpy
     L = abi.load_library()
-    n, deg = 1_300_007, 3
+    n, deg = 2_200_007, 3
     c = make_cloud_numpy(n, deg, 62)
     lay = abi.stream_layout(n, deg, 3)
     out = np.full(lay.total_bytes, 0xa5, np.uint8)
