@@ -36,8 +36,8 @@ $(LIBDIR)/libspz_amd.so: $(DEVICE_SRCS) $(CSRC)/spz_common.hpp $(CSRC)/spz_kerne
 	mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(DEVICE_SRCS) -ldl
 
-$(LIBDIR)/libspz_host.so: $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp $(CSRC)/spz_deflate.cpp $(CSRC)/spz_deflate.hpp $(CSRC)/spz_inflate.cpp $(CSRC)/spz_inflate.hpp $(CSRC)/spz_host_util.hpp $(INC)/spz_amd_host.hpp $(INC)/spz_amd.h $(LIBDIR)/libspz_amd.so
-	$(CXX) $(CXXFLAGS) -shared -o $@ $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp $(CSRC)/spz_deflate.cpp $(CSRC)/spz_inflate.cpp -L$(LIBDIR) -lspz_amd -lz -ldl -lpthread \
+$(LIBDIR)/libspz_host.so: $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp $(CSRC)/spz_deflate.cpp $(CSRC)/spz_lz77_model.cpp $(CSRC)/spz_lz77_core.hpp $(CSRC)/spz_deflate.hpp $(CSRC)/spz_inflate.cpp $(CSRC)/spz_inflate.hpp $(CSRC)/spz_host_util.hpp $(INC)/spz_amd_host.hpp $(INC)/spz_amd.h $(LIBDIR)/libspz_amd.so
+	$(CXX) $(CXXFLAGS) -shared -o $@ $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp $(CSRC)/spz_deflate.cpp $(CSRC)/spz_lz77_model.cpp $(CSRC)/spz_inflate.cpp -L$(LIBDIR) -lspz_amd -lz -ldl -lpthread \
 	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 
 $(ROOT)spz_amd/spz$(PYEXT): $(CSRC)/spz_py.cpp $(INC)/spz_amd_host.hpp $(LIBDIR)/libspz_host.so
@@ -89,6 +89,6 @@ fuzz: $(LIBDIR)/libspz_amd.so
 	mkdir -p $(ROOT)build
 	for t in gunzip_fuzz ply_fuzz deflate_fuzz inflate_fuzz; do \
 	  $(CXX) -O1 -g -fsanitize=address,undefined -fno-omit-frame-pointer -std=gnu++17 -I$(INC) -o $(ROOT)build/$$t \
-	    $(ROOT)tools/fuzz/$$t.cpp $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp $(CSRC)/spz_deflate.cpp $(CSRC)/spz_inflate.cpp -L$(LIBDIR) -lspz_amd -lz -ldl -lpthread \
+	    $(ROOT)tools/fuzz/$$t.cpp $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp $(CSRC)/spz_deflate.cpp $(CSRC)/spz_lz77_model.cpp $(CSRC)/spz_inflate.cpp -L$(LIBDIR) -lspz_amd -lz -ldl -lpthread \
 	    -Wl,-rpath,$(abspath $(LIBDIR)) && ASAN_OPTIONS=detect_leaks=0 $(ROOT)build/$$t || exit 1; \
 	done

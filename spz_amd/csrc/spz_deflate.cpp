@@ -25,6 +25,8 @@
 //  * Reads past the end of the input (the matcher looks up to 258 bytes ahead) see what zlib's window
 //    holds there: the bytes 32 KiB earlier (stale upper half of the window), reproduced in a padded tail.
 #include "spz_deflate.hpp"
+#include "spz_host_util.hpp"
+#include "spz_lz77_core.hpp"
 
 #include <zlib.h>
 
@@ -628,6 +630,131 @@ void parallel_for(size_t n, int threads, F fn) {
   for (auto &t : pool) t.join();
 }
 
+// ---- from the spliced symbol stream to the gzip member ------------------------------------------------
+// `parts`: the symbol stream in order, in pieces; `tail_literal`: its last symbol is the pending literal zlib
+// tallies after the loop; `crc`: CRC-32 of the input.
+template <class Lap>
+bool finish_member(const uint8_t *data, size_t size, int threads, const std::vector<Seg> &parts, bool tail_literal,
+                   uLong crc, std::vector<uint8_t> *out, size_t verify_prefix, Lap &lap) {
+  const size_t nparts = parts.size();
+  std::vector<uint64_t> goff(nparts + 1, 0);  // global symbol index of each part's first symbol
+  for (size_t i = 0; i < nparts; ++i) goff[i + 1] = goff[i] + parts[i].n;
+  const uint64_t total_syms = goff[nparts];
+
+  // ---- blocks: a block is flushed when the symbol buffer fills (BLOCK_SYMS) and at Z_FINISH, where the
+  // final (possibly empty) block carries the last-block flag.  The literal that is still pending when the
+  // input ends is tallied without a buffer check, so if it is the one that fills the buffer, that full block
+  // is the final one.
+  size_t nblocks = static_cast<size_t>(total_syms / BLOCK_SYMS) + 1;
+  if (total_syms > 0 && total_syms % BLOCK_SYMS == 0 && tail_literal) nblocks -= 1;
+  std::vector<Block> blocks(nblocks);
+  {
+    size_t part = 0;
+    for (size_t bi = 0; bi < nblocks; ++bi) {
+      Block &b = blocks[bi];
+      const uint64_t g0 = static_cast<uint64_t>(bi) * BLOCK_SYMS, g1 = std::min<uint64_t>(total_syms, g0 + BLOCK_SYMS);
+      b.nsyms = static_cast<size_t>(g1 - g0);
+      b.last = (bi + 1 == nblocks);
+      uint64_t g = g0;
+      while (g < g1) {
+        while (goff[part + 1] <= g) ++part;
+        const uint64_t take = std::min<uint64_t>(g1, goff[part + 1]) - g;
+        const size_t off = static_cast<size_t>(g - goff[part]);
+        b.segs.push_back({parts[part].dist + off, parts[part].lc + off, static_cast<size_t>(take)});
+        g += take;
+      }
+    }
+  }
+  lap("blocks");
+  parallel_for(nblocks, threads, [&](size_t bi) { plan_block(blocks[bi]); });
+  lap("plan");
+
+  // ---- serial: positions, stored / static / dynamic, bit offsets (the rest of _tr_flush_block's decision)
+  uint64_t pos = 0, bit = 0;
+  for (size_t bi = 0; bi < nblocks; ++bi) {
+    Block &b = blocks[bi];
+    b.start = pos;
+    pos += b.bytes;
+    // loop top of the iteration that tallied the block's last symbol (Z_FINISH flush: the end of the input)
+    const uint64_t s_flush = b.last ? size : (pos - b.last_sym_len + 1);
+    const bool buf_in_window = b.start >= base_at(s_flush, size);
+    int64_t opt_lenb = (b.opt_len + 3 + 7) >> 3;
+    const int64_t static_lenb = (b.static_len + 3 + 7) >> 3;
+    if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+    b.bit_start = bit;
+    if (static_cast<int64_t>(b.bytes) + 4 <= opt_lenb && buf_in_window) {
+      if (b.bytes > 0xffff) return false;
+      b.choice = STORED;
+      const uint64_t after_type = bit + 3;
+      b.bit_len = 3 + ((8 - (after_type & 7)) & 7) + 32 + 8 * b.bytes;
+    } else if (static_lenb == opt_lenb) {
+      b.choice = STATIC;
+      b.bit_len = 3 + static_cast<uint64_t>(b.static_len);
+    } else {
+      b.choice = DYNAMIC;
+      b.bit_len = 3 + static_cast<uint64_t>(b.opt_len);
+    }
+    if (b.last) b.bit_len += (8 - ((bit + b.bit_len) & 7)) & 7;  // bi_windup
+    bit += b.bit_len;
+  }
+  if (pos != size) return false;
+  std::atomic<bool> bad{false};
+  parallel_for(nblocks, threads, [&](size_t bi) {
+    const uint64_t planned = blocks[bi].bit_len;
+    encode_block(blocks[bi], data);
+    if (blocks[bi].bit_len != planned) bad = true;
+  });
+  if (bad) return false;
+  lap("encode");
+
+  // ---- assemble: 10-byte header (deflate.c: no flags, mtime 0, xfl 0, OS_CODE 3), bit strings, CRC-32, ISIZE
+  const uint64_t deflate_bytes = bit / 8;
+  out->assign(static_cast<size_t>(10 + deflate_bytes + 8), 0);
+  const uint8_t header[10] = {0x1f, 0x8b, 0x08, 0x00, 0, 0, 0, 0, 0x00, 0x03};
+  std::memcpy(out->data(), header, 10);
+  uint8_t *body = out->data() + 10;
+  for (const Block &b : blocks) {
+    const size_t at = static_cast<size_t>(b.bit_start / 8);
+    if (b.bits.empty()) continue;
+    body[at] |= b.bits[0];
+    if (b.bits.size() > 1) std::memcpy(body + at + 1, b.bits.data() + 1, b.bits.size() - 1);
+  }
+  uint8_t *trailer = body + deflate_bytes;
+  for (int k = 0; k < 4; ++k) trailer[k] = static_cast<uint8_t>(crc >> (8 * k));
+  for (int k = 0; k < 4; ++k) trailer[4 + k] = static_cast<uint8_t>((size & 0xffffffffu) >> (8 * k));
+  lap("assemble");
+
+  // ---- self-check against the linked zlib: deflate the first `verify` input bytes with zlib itself and
+  // compare every output byte that cannot depend on where that prefix ends (whole blocks that end at least
+  // 1 KiB before it).  Guards against a zlib whose algorithm differs from the one restated here.
+  if (verify_prefix > 0) {
+    const uint64_t verify = std::min<uint64_t>(size, verify_prefix);
+    uint64_t safe_bits = 0;
+    for (const Block &b : blocks) {
+      const uint64_t end_pos = b.start + b.bytes;
+      if (verify == size || end_pos + 1024 <= verify) safe_bits = b.bit_start + b.bit_len;
+      else break;
+    }
+    const size_t safe_bytes = 10 + static_cast<size_t>(safe_bits / 8) + (verify == size ? 8 : 0);
+    std::vector<uint8_t> z(compressBound(static_cast<uLong>(verify)) + 64);
+    z_stream zs = {};
+    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 9, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+    zs.next_in = const_cast<Bytef *>(data);
+    zs.avail_in = static_cast<uInt>(verify);
+    zs.next_out = z.data();
+    zs.avail_out = static_cast<uInt>(z.size());
+    const int rc = deflate(&zs, Z_FINISH);
+    const size_t zn = zs.total_out;
+    deflateEnd(&zs);
+    if (rc != Z_STREAM_END || zn < safe_bytes || out->size() < safe_bytes ||
+        std::memcmp(z.data(), out->data(), safe_bytes) != 0) {
+      return false;
+    }
+    lap("verify");
+  }
+  return true;
+}
+
 }  // namespace
 
 bool compress(const uint8_t *data, size_t size, int threads, int windows_per_chunk, std::vector<uint8_t> *out,
@@ -708,127 +835,97 @@ bool compress(const uint8_t *data, size_t size, int threads, int windows_per_chu
     }
     if (!found || hi[i] < lo[i]) return false;
   }
-  std::vector<uint64_t> goff(njobs + 1, 0);  // global symbol index of each job's first contributed symbol
-  for (size_t i = 0; i < njobs; ++i) goff[i + 1] = goff[i] + (hi[i] - lo[i]);
-  const uint64_t total_syms = goff[njobs];
-
-  // ---- blocks: a block is flushed when the symbol buffer fills (BLOCK_SYMS) and at Z_FINISH, where the
-  // final (possibly empty) block carries the last-block flag.  The literal that is still pending when the
-  // input ends is tallied without a buffer check, so if it is the one that fills the buffer, that full block
-  // is the final one.
-  size_t nblocks = static_cast<size_t>(total_syms / BLOCK_SYMS) + 1;
-  if (total_syms > 0 && total_syms % BLOCK_SYMS == 0 && jobs[njobs - 1].tail_literal) nblocks -= 1;
-  std::vector<Block> blocks(nblocks);
-  {
-    size_t job = 0;
-    for (size_t bi = 0; bi < nblocks; ++bi) {
-      Block &b = blocks[bi];
-      const uint64_t g0 = static_cast<uint64_t>(bi) * BLOCK_SYMS, g1 = std::min<uint64_t>(total_syms, g0 + BLOCK_SYMS);
-      b.nsyms = static_cast<size_t>(g1 - g0);
-      b.last = (bi + 1 == nblocks);
-      uint64_t g = g0;
-      while (g < g1) {
-        while (goff[job + 1] <= g) ++job;
-        const uint64_t take = std::min<uint64_t>(g1, goff[job + 1]) - g;
-        const size_t off = lo[job] + static_cast<size_t>(g - goff[job]);
-        b.segs.push_back({jobs[job].sym_dist.data() + off, jobs[job].sym_lc.data() + off, static_cast<size_t>(take)});
-        g += take;
-      }
-    }
-  }
+  std::vector<Seg> parts(njobs);
+  for (size_t i = 0; i < njobs; ++i) parts[i] = {jobs[i].sym_dist.data() + lo[i], jobs[i].sym_lc.data() + lo[i], hi[i] - lo[i]};
   lap("splice");
-  parallel_for(nblocks, threads, [&](size_t bi) { plan_block(blocks[bi]); });
-  lap("plan");
-
-  // ---- serial: positions, stored / static / dynamic, bit offsets (the rest of _tr_flush_block's decision)
-  uint64_t pos = 0, bit = 0;
-  for (size_t bi = 0; bi < nblocks; ++bi) {
-    Block &b = blocks[bi];
-    b.start = pos;
-    pos += b.bytes;
-    // loop top of the iteration that tallied the block's last symbol (Z_FINISH flush: the end of the input)
-    const uint64_t s_flush = b.last ? size : (pos - b.last_sym_len + 1);
-    const bool buf_in_window = b.start >= base_at(s_flush, size);
-    int64_t opt_lenb = (b.opt_len + 3 + 7) >> 3;
-    const int64_t static_lenb = (b.static_len + 3 + 7) >> 3;
-    if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
-    b.bit_start = bit;
-    if (static_cast<int64_t>(b.bytes) + 4 <= opt_lenb && buf_in_window) {
-      if (b.bytes > 0xffff) return false;
-      b.choice = STORED;
-      const uint64_t after_type = bit + 3;
-      b.bit_len = 3 + ((8 - (after_type & 7)) & 7) + 32 + 8 * b.bytes;
-    } else if (static_lenb == opt_lenb) {
-      b.choice = STATIC;
-      b.bit_len = 3 + static_cast<uint64_t>(b.static_len);
-    } else {
-      b.choice = DYNAMIC;
-      b.bit_len = 3 + static_cast<uint64_t>(b.opt_len);
-    }
-    if (b.last) b.bit_len += (8 - ((bit + b.bit_len) & 7)) & 7;  // bi_windup
-    bit += b.bit_len;
-  }
-  if (pos != size) return false;
-  std::atomic<bool> bad{false};
-  parallel_for(nblocks, threads, [&](size_t bi) {
-    const uint64_t planned = blocks[bi].bit_len;
-    encode_block(blocks[bi], data);
-    if (blocks[bi].bit_len != planned) bad = true;
-  });
-  if (bad) return false;
-  lap("encode");
-
-  // ---- assemble: 10-byte header (deflate.c: no flags, mtime 0, xfl 0, OS_CODE 3), bit strings, CRC-32, ISIZE
-  const uint64_t deflate_bytes = bit / 8;
-  out->assign(static_cast<size_t>(10 + deflate_bytes + 8), 0);
-  const uint8_t header[10] = {0x1f, 0x8b, 0x08, 0x00, 0, 0, 0, 0, 0x00, 0x03};
-  std::memcpy(out->data(), header, 10);
-  uint8_t *body = out->data() + 10;
-  for (const Block &b : blocks) {
-    const size_t at = static_cast<size_t>(b.bit_start / 8);
-    if (b.bits.empty()) continue;
-    body[at] |= b.bits[0];
-    if (b.bits.size() > 1) std::memcpy(body + at + 1, b.bits.data() + 1, b.bits.size() - 1);
-  }
   uLong crc = crcs[0];
   for (size_t i = 1; i < njobs; ++i) {
     const uint64_t n = (jobs[i].last ? size : (i + 1) * C) - jobs[i].begin;
     crc = crc32_combine(crc, crcs[i], static_cast<z_off_t>(n));
   }
-  uint8_t *trailer = body + deflate_bytes;
-  for (int k = 0; k < 4; ++k) trailer[k] = static_cast<uint8_t>(crc >> (8 * k));
-  for (int k = 0; k < 4; ++k) trailer[4 + k] = static_cast<uint8_t>((size & 0xffffffffu) >> (8 * k));
-  lap("assemble");
+  return finish_member(data, size, threads, parts, jobs[njobs - 1].tail_literal, crc, out, verify_prefix, lap);
+}
 
-  // ---- self-check against the linked zlib: deflate the first `verify` input bytes with zlib itself and
-  // compare every output byte that cannot depend on where that prefix ends (whole blocks that end at least
-  // 1 KiB before it).  Guards against a zlib whose algorithm differs from the one restated here.
-  if (verify_prefix > 0) {
-    const uint64_t verify = std::min<uint64_t>(size, verify_prefix);
-    uint64_t safe_bits = 0;
-    for (const Block &b : blocks) {
-      const uint64_t end_pos = b.start + b.bytes;
-      if (verify == size || end_pos + 1024 <= verify) safe_bits = b.bit_start + b.bit_len;
-      else break;
+bool compressWithHeadParser(const uint8_t *data, size_t size, int threads, HeadParser &parser,
+                            std::vector<uint8_t> *out, size_t verify_prefix) {
+  static_assert(sizeof(TopRec) == 8, "records travel as {state, symcount} pairs");
+  if (data == nullptr || out == nullptr || threads < 1) return false;
+  if (size < 16 * W || size >= (uint64_t(1) << 32) - 2 * W) return false;
+  static const bool timing = std::getenv("SPZ_AMD_EXACT_GZIP_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[exactgz] %-10s %.3f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
+  // CRC-32 of the input on the host's threads while the parse runs elsewhere
+  const size_t ncrc = static_cast<size_t>((size + (size_t(4) << 20) - 1) / (size_t(4) << 20));
+  std::vector<uLong> crcs(ncrc);
+  std::thread crc_thread([&]() {
+    parallel_for(ncrc, threads, [&](size_t i) {
+      const size_t lo = i * (size_t(4) << 20), hi = std::min(size, lo + (size_t(4) << 20));
+      crcs[i] = crc32(crc32(0L, Z_NULL, 0), data + lo, static_cast<uInt>(hi - lo));
+    });
+  });
+  struct Joiner {
+    std::thread &t;
+    ~Joiner() {
+      if (t.joinable()) t.join();
     }
-    const size_t safe_bytes = 10 + static_cast<size_t>(safe_bits / 8) + (verify == size ? 8 : 0);
-    std::vector<uint8_t> z(compressBound(static_cast<uLong>(verify)) + 64);
-    z_stream zs = {};
-    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 9, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-    zs.next_in = const_cast<Bytef *>(data);
-    zs.avail_in = static_cast<uInt>(verify);
-    zs.next_out = z.data();
-    zs.avail_out = static_cast<uInt>(z.size());
-    const int rc = deflate(&zs, Z_FINISH);
-    const size_t zn = zs.total_out;
-    deflateEnd(&zs);
-    if (rc != Z_STREAM_END || zn < safe_bytes || out->size() < safe_bytes ||
-        std::memcmp(z.data(), out->data(), safe_bytes) != 0) {
-      return false;
-    }
-    lap("verify");
+  } joiner{crc_thread};
+
+  // the serial tail job: the last 64 ... 96 KiB, with the reads past the end of the input as zlib's window has them
+  const uint64_t tail_begin = (size - 2 * W) / W * W;
+  const uint64_t tail_lo = tail_begin - W;
+  std::vector<uint8_t> tail(static_cast<size_t>(size - tail_lo) + MAX_MATCH + 8);
+  std::memcpy(tail.data(), data + tail_lo, static_cast<size_t>(size - tail_lo));
+  for (uint64_t abs = size; abs < size + MAX_MATCH + 8; ++abs) tail[static_cast<size_t>(abs - tail_lo)] = data[abs - W];
+  Job tj;
+  tj.size = size;
+  tj.begin = tail_begin;
+  tj.last = true;
+  tj.stop = size;
+  tj.d = tail.data() - tail_lo;
+  tj.rec_succ_lo = tail_begin;
+  tj.rec_succ.assign(OVERLAP + MAX_MATCH + 2, TopRec{});
+  tj.run();
+  if (!tj.phase_ok) return false;
+  lap("tail job");
+
+  uint64_t nhead = 0;
+  uint32_t tail_first = 0;
+  const uint32_t n_rec = static_cast<uint32_t>(std::min<size_t>(tj.rec_succ.size(), spz_lz::kRecordWindow));
+  if (!parser.parse(data, size, tail_begin, reinterpret_cast<const uint32_t *>(tj.rec_succ.data()), n_rec, &nhead,
+                    &tail_first)) {
+    return false;
   }
-  return true;
+  lap("head parse");
+  if (tail_first > tj.sym_lc.size() || nhead > size) return false;
+  std::vector<uint16_t> hd;
+  std::vector<uint8_t> hl;
+  detail::resizeUninitialized(&hd, static_cast<size_t>(nhead));
+  detail::resizeUninitialized(&hl, static_cast<size_t>(nhead));
+  {
+    detail::Prefault pf;
+    pf.add(hd.data(), hd.size() * sizeof(uint16_t));
+    pf.add(hl.data(), hl.size());
+    pf.start();
+    pf.join();
+  }
+  if (!parser.fetch(hd.data(), hl.data())) return false;
+  lap("fetch");
+  std::vector<Seg> parts(2);
+  parts[0] = {hd.data(), hl.data(), static_cast<size_t>(nhead)};
+  parts[1] = {tj.sym_dist.data() + tail_first, tj.sym_lc.data() + tail_first, tj.sym_lc.size() - tail_first};
+  crc_thread.join();
+  uLong crc = crcs[0];
+  for (size_t i = 1; i < ncrc; ++i) {
+    const size_t lo = i * (size_t(4) << 20), hi = std::min(size, lo + (size_t(4) << 20));
+    crc = crc32_combine(crc, crcs[i], static_cast<z_off_t>(hi - lo));
+  }
+  lap("crc join");
+  return finish_member(data, size, threads, parts, tj.tail_literal, crc, out, verify_prefix, lap);
 }
 
 }  // namespace exactgz

@@ -20,5 +20,25 @@ namespace exactgz {
 bool compress(const uint8_t *data, size_t size, int threads, int windows_per_chunk, std::vector<uint8_t> *out,
               size_t verify_prefix = 0);
 
+// The same member with the LZ77 parse of everything but the last 64-96 KiB done by `parser` — the MI355X
+// (spz_lz77.hip behind the C ABI's spz_amd_zlib_parse_*) or, in tests, the serial host model of the same
+// three stages (spz_lz77_model.cpp).  The end of the input, where zlib's lookahead runs out, stays with the
+// serial job of spz_deflate.cpp; the two symbol streams are spliced where their lazy-match states agree.
+struct HeadParser {
+  virtual ~HeadParser() = default;
+  // Parses the loop tops before the splice.  `tail_rec`: n_rec pairs {state, symbol count} the tail job recorded
+  // at its loop tops tail_begin + k (state 0: not a loop top).  Out: the number of head symbols and the index of the
+  // tail job's first contributed symbol.  false = declined (the caller parses on the host).
+  virtual bool parse(const uint8_t *data, size_t size, uint64_t tail_begin, const uint32_t *tail_rec, uint32_t n_rec,
+                     uint64_t *num_symbols, uint32_t *tail_first_symbol) = 0;
+  // Copies the head symbols out: distance (0 = literal) and literal byte / match length - 3.
+  virtual bool fetch(uint16_t *dist, uint8_t *lc) = 0;
+};
+bool compressWithHeadParser(const uint8_t *data, size_t size, int threads, HeadParser &parser,
+                            std::vector<uint8_t> *out, size_t verify_prefix = 0);
+
+// Serial host model of the data-parallel parse (stages and job geometry of spz_lz77_core.hpp), for tests.
+HeadParser *newModelHeadParser();
+
 }  // namespace exactgz
 }  // namespace spz

@@ -1,0 +1,122 @@
+// spz_lz77_model.cpp — serial host model of the data-parallel zlib parse (spz_lz77_core.hpp), with the SAME
+// stage functions and job geometry as the HIP kernels of spz_lz77.hip.  Test infrastructure: it lets the CPU
+// suite prove that links -> match tables -> lazy state machine -> record-window splice reproduces zlib's
+// symbols before a GPU is involved (tests/test_exact_gzip.py); nothing in the product path calls it.
+#include <algorithm>
+#include <cstring>
+#include <vector>
+
+#include "spz_deflate.hpp"
+#include "spz_lz77_core.hpp"
+
+namespace spz {
+namespace exactgz {
+namespace {
+
+using namespace spz_lz;
+
+struct ModelParser final : HeadParser {
+  std::vector<uint16_t> dist;
+  std::vector<uint8_t> lc;
+
+  bool parse(const uint8_t *data, size_t size, uint64_t tail_begin, const uint32_t *tail_rec, uint32_t n_rec,
+             uint64_t *num_symbols, uint32_t *tail_first_symbol) override {
+    if (tail_begin == 0 || tail_begin % W != 0 || n_rec < kRecordWindow) return false;
+    const uint64_t n_pos = tail_begin + kTableSlack;        // positions the tables cover
+    if (n_pos + kReadAhead + MIN_LOOKAHEAD > size) return false;
+    // ---- stage 1: links (zlib's head[] / prev[] as one pass with a 32-bit head table)
+    std::vector<uint16_t> link(n_pos, 0);
+    {
+      std::vector<uint64_t> head(HASH_MASK + 1, ~uint64_t(0));
+      for (uint64_t p = 0; p < n_pos; ++p) {
+        const uint32_t h = hash3(data[p], data[p + 1], data[p + 2]);
+        const uint64_t q = head[h];
+        link[p] = (q != ~uint64_t(0) && p - q < W) ? static_cast<uint16_t>(p - q) : 0;
+        head[h] = p;
+      }
+    }
+    // ---- stage 2: match tables
+    std::vector<uint32_t> r128(n_pos), r32(n_pos);
+    struct Data {
+      const uint8_t *d;
+      uint32_t load4(uint64_t pos) const {
+        uint32_t v;
+        std::memcpy(&v, d + pos, 4);
+        return v;
+      }
+    } dacc{data};
+    auto lacc = [&](uint64_t pos) { return static_cast<uint32_t>(link[pos]); };
+    for (uint64_t p = 0; p < n_pos; ++p) find_matches(dacc, lacc, p, size, &r128[p], &r32[p]);
+    // ---- stage 3: jobs; pass 0 records the first kRecordWindow loop tops of every job but the first
+    const uint64_t njobs = (tail_begin + kJobBytes - 1) / kJobBytes;
+    std::vector<uint32_t> rec((njobs + 1) * size_t(kRecordWindow) * 2, 0);  // {state, symcount}
+    std::memcpy(&rec[njobs * size_t(kRecordWindow) * 2], tail_rec, size_t(kRecordWindow) * 8);
+    auto a128 = [&](uint64_t pos) { return r128[pos]; };
+    auto a32 = [&](uint64_t pos) { return r32[pos]; };
+    auto abyte = [&](uint64_t pos) { return data[pos]; };
+    for (uint64_t j = 1; j < njobs; ++j) {
+      const uint64_t begin = j * kJobBytes;
+      uint64_t s = begin;
+      LazyState st;
+      uint32_t nsym = 0;
+      auto count = [&](uint32_t, uint32_t) { ++nsym; };
+      while (s - begin < kRecordWindow) {
+        uint32_t *r = &rec[(j * size_t(kRecordWindow) + (s - begin)) * 2];
+        r[0] = pack_state(st, s);
+        r[1] = nsym;
+        lazy_step(s, st, a128, a32, abyte, count);
+      }
+    }
+    // pass 1: every job emits until it meets its successor's record
+    std::vector<std::vector<uint16_t>> jd(njobs);
+    std::vector<std::vector<uint8_t>> jl(njobs);
+    std::vector<uint32_t> lo(njobs + 1, 0), hi(njobs, 0);
+    for (uint64_t j = 0; j < njobs; ++j) {
+      const uint64_t begin = j * kJobBytes, next = std::min<uint64_t>(begin + kJobBytes, tail_begin);
+      uint64_t s = begin;
+      LazyState st;
+      auto emit = [&](uint32_t d, uint32_t l) {
+        jd[j].push_back(static_cast<uint16_t>(d));
+        jl[j].push_back(static_cast<uint8_t>(l));
+      };
+      bool spliced = false;
+      for (;;) {
+        if (s >= next) {
+          if (s - next >= kRecordWindow) break;
+          const uint32_t *r = &rec[((j + 1) * size_t(kRecordWindow) + (s - next)) * 2];
+          if (r[0] == pack_state(st, s)) {
+            hi[j] = static_cast<uint32_t>(jl[j].size());
+            lo[j + 1] = r[1];
+            spliced = true;
+            break;
+          }
+        }
+        lazy_step(s, st, a128, a32, abyte, emit);
+        if (jl[j].size() > kJobSymbolStride) return false;
+      }
+      if (!spliced || hi[j] < lo[j]) return false;
+    }
+    dist.clear();
+    lc.clear();
+    for (uint64_t j = 0; j < njobs; ++j) {
+      dist.insert(dist.end(), jd[j].begin() + lo[j], jd[j].begin() + hi[j]);
+      lc.insert(lc.end(), jl[j].begin() + lo[j], jl[j].begin() + hi[j]);
+    }
+    *num_symbols = lc.size();
+    *tail_first_symbol = lo[njobs];
+    return true;
+  }
+
+  bool fetch(uint16_t *d, uint8_t *l) override {
+    std::memcpy(d, dist.data(), dist.size() * sizeof(uint16_t));
+    std::memcpy(l, lc.data(), lc.size());
+    return true;
+  }
+};
+
+}  // namespace
+
+HeadParser *newModelHeadParser() { return new ModelParser(); }
+
+}  // namespace exactgz
+}  // namespace spz

@@ -14,6 +14,7 @@
 
 #include <cstring>
 #include <sstream>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -261,6 +262,20 @@ PYBIND11_MODULE(spz, m) {
     return py::bytes(reinterpret_cast<const char *>(out.data()), out.size());
   }, py::arg("data"), py::arg("threads") = 8, py::arg("windows_per_chunk") = 32, py::arg("verify_prefix") = 0,
      "The multi-threaded writer with zlib's exact bytes (None when it declines the input).");
+  m.def("_compress_gzipped_exact_model", [](const py::bytes &data, int threads, size_t verify_prefix) -> py::object {
+    const BytesView in = viewOf(data);
+    std::vector<uint8_t> out;
+    bool ok;
+    {
+      py::gil_scoped_release release;
+      std::unique_ptr<spz::exactgz::HeadParser> parser(spz::exactgz::newModelHeadParser());
+      ok = spz::exactgz::compressWithHeadParser(in.p, in.n, threads, *parser, &out, verify_prefix);
+    }
+    if (!ok) return py::none();
+    return py::bytes(reinterpret_cast<const char *>(out.data()), out.size());
+  }, py::arg("data"), py::arg("threads") = 4, py::arg("verify_prefix") = 0,
+     "Test hook: the exact writer with its parse done by the serial host model of the device stages "
+     "(links, match tables, lazy state machine, record-window splice); None when declined.");
   m.def("_effective_cpu_count", []() { return spz::effectiveCpuCount(); },
         "CPUs the worker pools of the container stage size themselves by (online, affinity mask, cgroup quota).");
   m.def("_parallel_inflate_count", []() { return spz::pinflate::successCount(); },
