@@ -181,6 +181,10 @@ GaussianCloud unpackFromStream(const uint8_t *stream, size_t size, const UnpackO
 // CPUs this process may use (online count, affinity mask, cgroup quota): what the thread-count defaults of the
 // gzip writer / readers derive from.
 unsigned effectiveCpuCount();
+// Members compressGzipped has written in this process with their LZ77 parse done on the device (spz_lz77.hip;
+// environment SPZ_AMD_GZIP_DEVICE = 0 never, 1 always, unset: inputs of 8 MiB and more).  The bytes are zlib's
+// whichever way the parse ran; this says which way it was.
+uint64_t deviceGzipParseCount();
 // Status (spz_amd.h codes) of the last device call made by this thread; 0 = ok.
 int lastDeviceStatus();
 void setLastDeviceStatus(int status);

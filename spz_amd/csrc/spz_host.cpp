@@ -410,14 +410,59 @@ bool verifiedExact(const uint8_t *data, size_t size, const std::vector<uint8_t> 
   return true;
 }
 
+// The LZ77 parse of the exact writer on the MI355X (spz_lz77.hip): SPZ_AMD_GZIP_DEVICE = 0 never, 1 whenever a
+// device answers, unset: for inputs of 8 MiB and more when a device answers.
+struct DeviceHeadParser final : exactgz::HeadParser {
+  void *ctx = nullptr;
+  int status = SPZ_AMD_OK;
+  ~DeviceHeadParser() override { spz_amd_zlib_parse_close(ctx); }
+  bool parse(const uint8_t *data, size_t size, uint64_t tail_begin, const uint32_t *tail_rec, uint32_t n_rec,
+             uint64_t *num_symbols, uint32_t *tail_first_symbol) override {
+    status = spz_amd_zlib_parse_open(data, size, tail_begin, tail_rec, n_rec, deviceIndex(), &ctx, num_symbols,
+                                     tail_first_symbol);
+    return status == SPZ_AMD_OK;
+  }
+  bool fetch(uint16_t *dist, uint8_t *lc) override {
+    status = spz_amd_zlib_parse_fetch(ctx, dist, lc);
+    return status == SPZ_AMD_OK;
+  }
+};
+
+bool deviceParseWanted(size_t size) {
+  const char *e = std::getenv("SPZ_AMD_GZIP_DEVICE");
+  if (e && e[0] == '0') return false;
+  const bool forced = e && e[0] == '1';
+  if (!forced && size < (size_t(8) << 20)) return false;
+  return spz_amd_device_count() > 0;
+}
+
+std::atomic<uint64_t> g_device_parses{0};
+
 }  // namespace
 
+uint64_t deviceGzipParseCount() { return g_device_parses.load(); }
+
 bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out) {
-  // Large inputs: the multi-threaded writer that reproduces zlib's bytes exactly (it checks itself against
-  // zlib on a prefix, and declines inputs it cannot split); zlib itself otherwise and as the fallback.
+  // Large inputs: the writer that reproduces zlib's bytes exactly with its parse on the device or on all
+  // cores (it checks itself against zlib on a prefix, and declines inputs it cannot split); zlib itself
+  // otherwise and as the fallback.
   constexpr size_t kExactMinBytes = size_t(1) << 20;
   if (size >= kExactMinBytes && std::strcmp(zlibVersion(), "1.2.11") == 0) {
     const int threads = exactGzipThreads();
+    if (threads >= 1 && deviceParseWanted(size)) {
+      const size_t verify = std::min<size_t>(size_t(256) << 10, std::max<size_t>(size_t(64) << 10, size / 16));
+      const size_t avail = availablePhysicalBytes();
+      if (avail == 0 || size / 2 * 9 < avail) {
+        DeviceHeadParser parser;
+        if (exactgz::compressWithHeadParser(data, size, std::max(threads, 1), parser, out, verify)) {
+          const int level = gzipVerifyLevel();
+          if (level == 0 || verifiedExact(data, size, *out, level)) {
+            g_device_parses.fetch_add(1);
+            return true;
+          }
+        }
+      }
+    }
     // parse jobs of 1 MiB; smaller ones (down to 128 KiB) when that is what it takes to give every thread two
     const int windows = static_cast<int>(std::min<size_t>(32, std::max<size_t>(4, size / (size_t(threads > 0 ? threads : 1) * 2 * 32768))));
     const size_t verify = std::min<size_t>(size_t(256) << 10, std::max<size_t>(size_t(64) << 10, size / 16));

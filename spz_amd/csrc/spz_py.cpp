@@ -276,6 +276,8 @@ PYBIND11_MODULE(spz, m) {
   }, py::arg("data"), py::arg("threads") = 4, py::arg("verify_prefix") = 0,
      "Test hook: the exact writer with its parse done by the serial host model of the device stages "
      "(links, match tables, lazy state machine, record-window splice); None when declined.");
+  m.def("_device_gzip_parse_count", []() { return spz::deviceGzipParseCount(); },
+        "gzip members written so far with their LZ77 parse done on the device.");
   m.def("_effective_cpu_count", []() { return spz::effectiveCpuCount(); },
         "CPUs the worker pools of the container stage size themselves by (online, affinity mask, cgroup quota).");
   m.def("_parallel_inflate_count", []() { return spz::pinflate::successCount(); },

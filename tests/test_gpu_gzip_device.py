@@ -1,0 +1,75 @@
+"""The exact gzip writer with its LZ77 parse on the MI355X (spz_amd/csrc/spz_lz77.hip behind
+spz_amd_zlib_parse_*): compressGzipped must return, byte for byte, what zlib 1.2.11 returns with the
+reference's parameters (load-spz.cc:186-214) — the same oracle as tests/test_exact_gzip.py — and the
+device must actually have done the parse (a counter says which way it ran)."""
+import os
+import zlib
+
+import numpy as np
+import pytest
+
+import spz_amd.spz as spz
+from test_exact_gzip import make, zlib_gzip
+
+pytestmark = [pytest.mark.gpu,
+              pytest.mark.skipif(zlib.ZLIB_RUNTIME_VERSION != "1.2.11", reason="the exact writer restates zlib 1.2.11")]
+
+
+@pytest.fixture(autouse=True)
+def force_device_parse():
+    old = os.environ.get("SPZ_AMD_GZIP_DEVICE")
+    os.environ["SPZ_AMD_GZIP_DEVICE"] = "1"
+    yield
+    if old is None:
+        os.environ.pop("SPZ_AMD_GZIP_DEVICE", None)
+    else:
+        os.environ["SPZ_AMD_GZIP_DEVICE"] = old
+
+
+@pytest.mark.parametrize("kind", ["nibbles", "bytes", "words", "runs", "sh_like"])
+def test_device_parse_bytes_equal_zlib(kind):
+    """Sizes around the job (64 KiB), tile (16 KiB) and link-segment (512 KiB) boundaries of the kernels."""
+    rng = np.random.default_rng(sum(kind.encode()) + 1)
+    for n in ((1 << 20), (1 << 20) + 1, 1_300_001, (1 << 21) + 32768, 3_000_017):
+        data = make(kind, n, rng)
+        before = spz._device_gzip_parse_count()
+        got = spz._compress_gzipped(data)
+        assert got == zlib_gzip(data), f"{kind} n={n}: differs from zlib"
+        assert spz._device_gzip_parse_count() == before + 1, f"{kind} n={n}: the device did not do the parse"
+
+
+def test_device_parse_of_a_real_stream_and_of_its_save(tmp_path):
+    """A 400 k-point SH3 stream (26 MB: 400 jobs, 50 link segments) and the whole saveSpz path on top."""
+    from spz_amd.synth import make_cloud_numpy
+    n, deg = 400_000, 3
+    c = make_cloud_numpy(n, deg, 77)
+    g = spz.GaussianCloud()
+    g.sh_degree = deg
+    g.antialiased = True
+    for k in ("positions", "scales", "rotations", "alphas", "colors", "sh"):
+        setattr(g, k, c[k])
+    o = spz.PackOptions()
+    o.from_coord = spz.RDF
+    raw = spz._pack_to_stream(g, o)
+    before = spz._device_gzip_parse_count()
+    member = spz._compress_gzipped(raw)
+    assert spz._device_gzip_parse_count() == before + 1
+    assert member == zlib_gzip(raw)
+    path = str(tmp_path / "c.spz")
+    assert spz.save_spz(g, o, path)
+    assert open(path, "rb").read() == member
+
+
+def test_device_parse_is_off_below_the_threshold_and_when_disabled():
+    rng = np.random.default_rng(5)
+    data = make("sh_like", 2_000_000, rng)
+    want = zlib_gzip(data)
+    os.environ.pop("SPZ_AMD_GZIP_DEVICE")           # default: 8 MiB and more
+    before = spz._device_gzip_parse_count()
+    assert spz._compress_gzipped(data) == want
+    assert spz._device_gzip_parse_count() == before
+    os.environ["SPZ_AMD_GZIP_DEVICE"] = "0"
+    big = make("sh_like", 9_000_000, rng)
+    assert spz._compress_gzipped(big) == zlib_gzip(big)
+    assert spz._device_gzip_parse_count() == before
+    os.environ["SPZ_AMD_GZIP_DEVICE"] = "1"
