@@ -648,25 +648,23 @@ bool finish_member(const uint8_t *data, size_t size, int threads, const std::vec
   size_t nblocks = static_cast<size_t>(total_syms / BLOCK_SYMS) + 1;
   if (total_syms > 0 && total_syms % BLOCK_SYMS == 0 && tail_literal) nblocks -= 1;
   std::vector<Block> blocks(nblocks);
-  {
-    size_t part = 0;
-    for (size_t bi = 0; bi < nblocks; ++bi) {
-      Block &b = blocks[bi];
-      const uint64_t g0 = static_cast<uint64_t>(bi) * BLOCK_SYMS, g1 = std::min<uint64_t>(total_syms, g0 + BLOCK_SYMS);
-      b.nsyms = static_cast<size_t>(g1 - g0);
-      b.last = (bi + 1 == nblocks);
-      uint64_t g = g0;
-      while (g < g1) {
-        while (goff[part + 1] <= g) ++part;
-        const uint64_t take = std::min<uint64_t>(g1, goff[part + 1]) - g;
-        const size_t off = static_cast<size_t>(g - goff[part]);
-        b.segs.push_back({parts[part].dist + off, parts[part].lc + off, static_cast<size_t>(take)});
-        g += take;
-      }
+  parallel_for(nblocks, threads, [&](size_t bi) {
+    Block &b = blocks[bi];
+    const uint64_t g0 = static_cast<uint64_t>(bi) * BLOCK_SYMS, g1 = std::min<uint64_t>(total_syms, g0 + BLOCK_SYMS);
+    b.nsyms = static_cast<size_t>(g1 - g0);
+    b.last = (bi + 1 == nblocks);
+    size_t part = static_cast<size_t>(std::upper_bound(goff.begin(), goff.end(), g0) - goff.begin());
+    part = part > 0 ? part - 1 : 0;
+    uint64_t g = g0;
+    while (g < g1) {
+      while (goff[part + 1] <= g) ++part;
+      const uint64_t take = std::min<uint64_t>(g1, goff[part + 1]) - g;
+      const size_t off = static_cast<size_t>(g - goff[part]);
+      b.segs.push_back({parts[part].dist + off, parts[part].lc + off, static_cast<size_t>(take)});
+      g += take;
     }
-  }
-  lap("blocks");
-  parallel_for(nblocks, threads, [&](size_t bi) { plan_block(blocks[bi]); });
+    plan_block(b);
+  });
   lap("plan");
 
   // ---- serial: positions, stored / static / dynamic, bit offsets (the rest of _tr_flush_block's decision)
@@ -709,15 +707,28 @@ bool finish_member(const uint8_t *data, size_t size, int threads, const std::vec
 
   // ---- assemble: 10-byte header (deflate.c: no flags, mtime 0, xfl 0, OS_CODE 3), bit strings, CRC-32, ISIZE
   const uint64_t deflate_bytes = bit / 8;
-  out->assign(static_cast<size_t>(10 + deflate_bytes + 8), 0);
+  out->clear();
+  detail::resizeUninitialized(out, static_cast<size_t>(10 + deflate_bytes + 8));
   const uint8_t header[10] = {0x1f, 0x8b, 0x08, 0x00, 0, 0, 0, 0, 0x00, 0x03};
   std::memcpy(out->data(), header, 10);
   uint8_t *body = out->data() + 10;
+  // a block's first and last byte may be shared with its neighbours (it is OR-ed into place): those are zeroed
+  // and OR-ed serially, the bytes in between are copied by all threads
   for (const Block &b : blocks) {
-    const size_t at = static_cast<size_t>(b.bit_start / 8);
     if (b.bits.empty()) continue;
+    const size_t at = static_cast<size_t>(b.bit_start / 8);
+    body[at] = 0;
+    body[at + b.bits.size() - 1] = 0;
+  }
+  parallel_for(nblocks, threads, [&](size_t bi) {
+    const Block &b = blocks[bi];
+    if (b.bits.size() > 2) std::memcpy(body + b.bit_start / 8 + 1, b.bits.data() + 1, b.bits.size() - 2);
+  });
+  for (const Block &b : blocks) {
+    if (b.bits.empty()) continue;
+    const size_t at = static_cast<size_t>(b.bit_start / 8);
     body[at] |= b.bits[0];
-    if (b.bits.size() > 1) std::memcpy(body + at + 1, b.bits.data() + 1, b.bits.size() - 1);
+    if (b.bits.size() > 1) body[at + b.bits.size() - 1] |= b.bits.back();
   }
   uint8_t *trailer = body + deflate_bytes;
   for (int k = 0; k < 4; ++k) trailer[k] = static_cast<uint8_t>(crc >> (8 * k));

@@ -16,7 +16,8 @@
 //                     their 96 KiB of links are staged in LDS (144 KiB of the CU's 160), every thread walks the
 //                     chains of 16 positions exactly like longest_match does — all reads are LDS reads — and
 //                     writes the two results per position (chain budget 128 and 32).
-//   lz_parse_kernel   one lane per 64 KiB job: deflate_slow's loop with the table lookup in place of the search.
+//   lz_parse_kernel   one lane per 64 KiB job: deflate_slow's loop with the table lookup in place of the search
+//                     (each lane keeps the 32 entries around its position in LDS: one HBM latency per 32 positions).
 //                     Pass 0 records each job's lazy state over its first 8192 loop tops, pass 1 emits symbols
 //                     and ends a job where its state equals its successor's record (spz_deflate.cpp's splice).
 //   lz_compact_kernel the jobs' contributed symbol ranges, concatenated.
@@ -103,17 +104,15 @@ constexpr uint32_t kMatchLinkDwords = (W + kMatchTile) / 2;
 
 struct LdsData {
   const uint32_t *s;
-  long long origin;
-  __device__ __forceinline__ uint32_t load4(uint64_t pos) const {
-    const uint32_t off = (uint32_t)((long long)pos - origin);
+  __device__ __forceinline__ uint32_t load4(int32_t pos) const {  // pos: bytes from the window's origin
+    const uint32_t off = (uint32_t)pos;
     const uint32_t a = s[off >> 2], b = s[(off >> 2) + 1];
     return __builtin_amdgcn_alignbyte(b, a, off & 3u);
   }
 };
 struct LdsLink {
   const uint16_t *s;
-  long long origin;
-  __device__ __forceinline__ uint32_t operator()(uint64_t pos) const { return s[(uint32_t)((long long)pos - origin)]; }
+  __device__ __forceinline__ uint32_t operator()(int32_t pos) const { return s[(uint32_t)pos]; }
 };
 
 __global__ __launch_bounds__(1024) void lz_match_kernel(const uint8_t *__restrict__ d, const uint16_t *__restrict__ link,
@@ -123,7 +122,7 @@ __global__ __launch_bounds__(1024) void lz_match_kernel(const uint8_t *__restric
   __shared__ uint32_t s_link[kMatchLinkDwords];
   const uint32_t tid = threadIdx.x;
   const uint64_t t0 = (uint64_t)blockIdx.x * kMatchTile;
-  const long long origin = (long long)t0 - (long long)W;  // a multiple of 16 KiB
+  const long long origin = (long long)t0 - (long long)W;  // a multiple of 16 KiB; window position 0
   const uint32_t *d32 = reinterpret_cast<const uint32_t *>(d);
   const uint32_t *l32 = reinterpret_cast<const uint32_t *>(link);
   for (uint32_t i = tid; i < kMatchDataDwords; i += kMatchThreads) {
@@ -135,15 +134,18 @@ __global__ __launch_bounds__(1024) void lz_match_kernel(const uint8_t *__restric
     s_link[i] = pos >= 0 ? l32[pos >> 1] : 0u;
   }
   __syncthreads();
-  const LdsData data = {s_data, origin};
-  const LdsLink lk = {reinterpret_cast<const uint16_t *>(s_link), origin};
+  const LdsData data = {s_data};
+  const LdsLink lk = {reinterpret_cast<const uint16_t *>(s_link)};
   for (uint32_t it = 0; it < kMatchTile / kMatchThreads; ++it) {
-    const uint64_t p = t0 + (uint64_t)it * kMatchThreads + tid;
+    const uint32_t local = it * kMatchThreads + tid;
+    const uint64_t p = t0 + local;
     if (p < n_pos) {
-      uint32_t a, b;
-      find_matches(data, lk, p, size, &a, &b);
-      r128[p] = a;
-      r32[p] = b;
+      // the window base in window coordinates; a base below the window is out of every candidate's reach
+      const long long b = (long long)base_at(p, size) - origin;
+      uint32_t e128, e32;
+      find_matches<int32_t>(data, lk, (int32_t)(W + local), (int32_t)(b > 0 ? b : 0), &e128, &e32);
+      r128[p] = e128;
+      r32[p] = e32;
     }
   }
 }
@@ -153,19 +155,40 @@ struct JobInfo {
   uint32_t lo, hi, spliced;
 };
 
-__global__ __launch_bounds__(64) void lz_parse_kernel(int pass, const uint8_t *__restrict__ d,
-                                                      const uint32_t *__restrict__ r128, const uint32_t *__restrict__ r32,
-                                                      uint64_t head_end, uint32_t n_jobs, uint2 *__restrict__ rec,
-                                                      uint16_t *__restrict__ sym_dist, uint8_t *__restrict__ sym_lc,
-                                                      JobInfo *__restrict__ info) {
-  const uint32_t j = blockIdx.x * 64u + threadIdx.x;
+constexpr uint32_t kParseWindow = 32;  // table entries a lane fetches at a time
+
+__global__ __launch_bounds__(64) void lz_parse_kernel(int pass, const uint32_t *__restrict__ r128,
+                                                      const uint32_t *__restrict__ r32, uint32_t head_end, uint32_t n_jobs,
+                                                      uint2 *__restrict__ rec, uint16_t *__restrict__ sym_dist,
+                                                      uint8_t *__restrict__ sym_lc, JobInfo *__restrict__ info) {
+  // The loop's next position depends on the entry it has just read, so a read from HBM per loop top would be all
+  // latency: each lane keeps the 32 entries around its position in LDS ([entry][lane]: conflict-free) and
+  // refills them with eight 16-byte loads when it leaves them.
+  __shared__ uint32_t s_win[kParseWindow * 64];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t j = blockIdx.x * 64u + lane;
   if (j >= n_jobs) return;
-  const uint64_t begin = (uint64_t)j * kJobBytes;
-  auto a128 = [&](uint64_t pos) { return r128[pos]; };
-  auto a32 = [&](uint64_t pos) { return r32[pos]; };
-  auto byte = [&](uint64_t pos) { return d[pos]; };
-  uint64_t s = begin;
-  LazyState st;
+  const uint32_t begin = j * kJobBytes;
+  uint32_t win_base = 0xffffffffu;
+  auto e128 = [&](uint32_t pos) {
+    const uint32_t b = pos & ~(kParseWindow - 1u);
+    if (b != win_base) {
+      const uint4 *src = reinterpret_cast<const uint4 *>(r128 + b);
+#pragma unroll
+      for (uint32_t q = 0; q < kParseWindow / 4; ++q) {
+        const uint4 v = src[q];
+        s_win[(4 * q + 0) * 64 + lane] = v.x;
+        s_win[(4 * q + 1) * 64 + lane] = v.y;
+        s_win[(4 * q + 2) * 64 + lane] = v.z;
+        s_win[(4 * q + 3) * 64 + lane] = v.w;
+      }
+      win_base = b;
+    }
+    return s_win[(pos - b) * 64 + lane];
+  };
+  auto e32 = [&](uint32_t pos) { return r32[pos]; };
+  uint32_t s = begin;
+  LazyState<uint32_t> st;
   uint32_t nsym = 0;
   if (pass == 0) {
     if (j == 0) return;  // nobody splices into the first job
@@ -173,11 +196,11 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(int pass, const uint8_t *_
     auto count = [&](uint32_t, uint32_t) { ++nsym; };
     while (s - begin < kRecordWindow) {
       r[s - begin] = make_uint2(pack_state(st, s), nsym);
-      lazy_step(s, st, a128, a32, byte, count);
+      lazy_step(s, st, e128, e32, count);
     }
     return;
   }
-  const uint64_t next = (begin + kJobBytes < head_end) ? begin + kJobBytes : head_end;
+  const uint32_t next = (begin + kJobBytes < head_end) ? begin + kJobBytes : head_end;
   const uint2 *succ = rec + (size_t)(j + 1) * kRecordWindow;
   uint16_t *od = sym_dist + (size_t)j * kJobSymbolStride;
   uint8_t *ol = sym_lc + (size_t)j * kJobSymbolStride;
@@ -199,7 +222,7 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(int pass, const uint8_t *_
       }
     }
     if (nsym + 1 >= kJobSymbolStride) break;
-    lazy_step(s, st, a128, a32, byte, emit);
+    lazy_step(s, st, e128, e32, emit);
   }
   info[j].spliced = spliced;
 }
@@ -322,11 +345,11 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
   SPZ_HIP_TRY(hipGetLastError());
   lap("matches");
   const uint32_t parse_blocks = (n_jobs + 63u) / 64u;
-  hipLaunchKernelGGL(lz_parse_kernel, dim3(parse_blocks), dim3(64), 0, st, 0, d_data, d_r128, d_r32, tail_begin, n_jobs, d_rec,
+  hipLaunchKernelGGL(lz_parse_kernel, dim3(parse_blocks), dim3(64), 0, st, 0, d_r128, d_r32, (uint32_t)tail_begin, n_jobs, d_rec,
                      d_sd, d_sl, d_info);
   SPZ_HIP_TRY(hipGetLastError());
   lap("records");
-  hipLaunchKernelGGL(lz_parse_kernel, dim3(parse_blocks), dim3(64), 0, st, 1, d_data, d_r128, d_r32, tail_begin, n_jobs, d_rec,
+  hipLaunchKernelGGL(lz_parse_kernel, dim3(parse_blocks), dim3(64), 0, st, 1, d_r128, d_r32, (uint32_t)tail_begin, n_jobs, d_rec,
                      d_sd, d_sl, d_info);
   SPZ_HIP_TRY(hipGetLastError());
   std::vector<JobInfo> info(n_jobs + 1);

@@ -5,7 +5,7 @@
 //   1. links    link[p] = distance from p to the nearest earlier position with the same 3-byte hash (zlib's
 //               prev[] chain), 0 when there is none within 32 KiB.  zlib inserts EVERY position into its hash
 //               chains at level >= 4, so the chains are a pure function of the input.
-//   2. matches  r128[p] / r32[p] = what longest_match() returns at a loop top at p with a chain budget of 128 /
+//   2. matches  r128[p] / r32[p] = the input byte at p and what longest_match() returns at a loop top at p with a chain budget of 128 /
 //               32 (the budget is 32 when the previous match is >= good_match) and no previous match.  A
 //               previous match of length L only raises the bar a candidate has to pass: longest_match with
 //               prev_length = L returns the same (length, start) when that length exceeds L, and "nothing
@@ -63,40 +63,41 @@ SPZ_LZ_HD uint64_t base_at(uint64_t s, uint64_t size) {
   return k * W;
 }
 
-SPZ_LZ_HD uint32_t encode_match(uint32_t len, uint32_t dist) { return len >= MIN_MATCH ? (len << 16) | dist : 0u; }
-
-SPZ_LZ_HD uint32_t ctz32(uint32_t x) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  return (uint32_t)__builtin_ctz(x);
-#else
-  return (uint32_t)__builtin_ctz(x);
-#endif
+// A table entry: the input byte at the position (what a literal there is), the match distance (< 32768) and
+// length - 3, and whether there is a match at all.
+SPZ_LZ_HD uint32_t encode_entry(uint32_t len, uint32_t dist, uint32_t byte) {
+  return len >= MIN_MATCH ? (0x80000000u | ((len - MIN_MATCH) << 23) | (dist << 8) | byte) : byte;
 }
+SPZ_LZ_HD uint32_t entry_length(uint32_t e) { return (e >> 31) ? ((e >> 23) & 0xffu) + MIN_MATCH : 0u; }
+SPZ_LZ_HD uint32_t entry_distance(uint32_t e) { return (e >> 8) & 0x7fffu; }
+SPZ_LZ_HD uint32_t entry_byte(uint32_t e) { return e & 0xffu; }
 
-// Stage 2 for one position.  `data.load4(pos)`: the four input bytes at pos, little endian (pos up to
-// p + kReadAhead); `link(pos)`: stage 1's value.  p must have a full lookahead (p + MIN_LOOKAHEAD <= size).
-template <class Data, class Link>
-SPZ_LZ_HD void find_matches(const Data &data, const Link &link, uint64_t p, uint64_t size, uint32_t *r128,
-                            uint32_t *r32) {
-  *r128 = 0;
-  *r32 = 0;
+// Stage 2 for one position p.  Positions are in the caller's coordinates (Pos: absolute int64_t on the host,
+// tile-relative int32_t in the kernel; signed, so that a link that leaves the tile's window makes a negative
+// position and ends the walk like any position below the limit).  `data.load4(pos)`: the four input bytes at
+// pos, little endian (pos up to p + kReadAhead); `link(pos)`: stage 1's value; `base`: base_at(p) in the same
+// coordinates (anything at or below p - W stands for "not in reach").  p has a full lookahead.
+template <class Pos, class Data, class Link>
+SPZ_LZ_HD void find_matches(const Data &data, const Link &link, Pos p, Pos base, uint32_t *r128, uint32_t *r32) {
+  const uint32_t s4 = data.load4(p);
+  const uint32_t none = encode_entry(0, 0, s4 & 0xffu);
+  *r128 = none;
+  *r32 = none;
   uint32_t gap = link(p);
   if (gap == 0 || gap > MAX_DIST) return;          // hash_head == NIL, or strstart - hash_head > MAX_DIST
-  const uint64_t base = base_at(p, size);
-  uint64_t cur = p - gap;
+  Pos cur = p - (Pos)gap;
   if (cur <= base) return;                           // the window has dropped it (index 0 is NIL too)
-  const uint64_t limit = (p - base > MAX_DIST) ? p - MAX_DIST : base;
-  uint32_t best = MIN_MATCH - 1, best_dist = 0, k = 0;
-  const uint32_t s4 = data.load4(p);
+  const Pos limit = (p - base > (Pos)MAX_DIST) ? p - (Pos)MAX_DIST : base;
+  uint32_t best = MIN_MATCH - 1, best_dist = 0, k = 0, stop_at = SHORT_CHAIN;
   for (;;) {
     const uint32_t m4 = data.load4(cur);
     if (((m4 ^ s4) & 0xffffffu) == 0u &&
-        (best < MIN_MATCH || ((data.load4(cur + best) ^ data.load4(p + best)) & 0xffu) == 0u)) {
+        (best < MIN_MATCH || ((data.load4(cur + (Pos)best) ^ data.load4(p + (Pos)best)) & 0xffu) == 0u)) {
       uint32_t len = MIN_MATCH;
       while (len < MAX_MATCH) {
-        const uint32_t x = data.load4(p + len) ^ data.load4(cur + len);
+        const uint32_t x = data.load4(p + (Pos)len) ^ data.load4(cur + (Pos)len);
         if (x != 0u) {
-          len += ctz32(x) >> 3;
+          len += (uint32_t)__builtin_ctz(x) >> 3;
           break;
         }
         len += 4;
@@ -105,64 +106,65 @@ SPZ_LZ_HD void find_matches(const Data &data, const Link &link, uint64_t p, uint
       if (len > best) {
         best = len;
         best_dist = (uint32_t)(p - cur);
-        if (len >= NICE_MATCH) {
-          const uint32_t r = encode_match(best, best_dist);
-          if (k < SHORT_CHAIN) *r32 = r;
-          *r128 = r;
-          return;
-        }
+        if (len >= NICE_MATCH) break;
       }
     }
-    ++k;
-    if (k == SHORT_CHAIN) *r32 = encode_match(best, best_dist);
-    if (k == MAX_CHAIN) break;
+    if (++k == stop_at) {
+      if (k == MAX_CHAIN) break;
+      *r32 = encode_entry(best, best_dist, s4 & 0xffu);  // what a budget of 32 has found
+      stop_at = MAX_CHAIN;
+    }
     gap = link(cur);
-    if (gap == 0 || gap > cur) break;
-    cur -= gap;
+    if (gap == 0) break;
+    cur -= (Pos)gap;
     if (cur <= limit) break;
   }
-  const uint32_t r = encode_match(best, best_dist);
-  if (k < SHORT_CHAIN) *r32 = r;
+  const uint32_t r = encode_entry(best, best_dist, s4 & 0xffu);
+  if (stop_at == SHORT_CHAIN) *r32 = r;  // the walk ended inside the short budget
   *r128 = r;
 }
 
 // ---- stage 3 -------------------------------------------------------------------------------------------
+template <class Pos>
 struct LazyState {
   uint32_t match_available = 0;
   uint32_t match_length = MIN_MATCH - 1;
-  uint64_t match_start = 0;
+  uint32_t byte_before = 0;  // input byte at strstart - 1, known whenever match_available is set
+  Pos match_start = 0;
 };
 
 // The record spz_deflate.cpp's jobs compare when they splice (TopRec::state).
-SPZ_LZ_HD uint32_t pack_state(const LazyState &st, uint64_t strstart) {
+template <class Pos>
+SPZ_LZ_HD uint32_t pack_state(const LazyState<Pos> &st, Pos strstart) {
   const uint32_t dist = st.match_length >= MIN_MATCH ? (uint32_t)(strstart - st.match_start) : 0u;
   return 0x80000000u | (st.match_available << 30) | st.match_length | ((dist & 0xffffu) << 9);
 }
 
-// One iteration of deflate_slow's loop at a loop top `strstart` with a full lookahead.  `r128(pos)`, `r32(pos)`:
-// stage 2's tables; `byte(pos)`: input byte; `emit(dist, lc)`: one symbol (dist 0 = literal lc, else a match of
-// lc + 3 bytes).
-template <class R128, class R32, class Byte, class Emit>
-SPZ_LZ_HD void lazy_step(uint64_t &strstart, LazyState &st, const R128 &r128, const R32 &r32, const Byte &byte,
-                         Emit &emit) {
+// One iteration of deflate_slow's loop at a loop top `strstart` with a full lookahead.  `e128(pos)`, `e32(pos)`:
+// stage 2's tables; `emit(dist, lc)`: one symbol (dist 0 = literal lc, else a match of lc + 3 bytes).  The literal
+// a loop top emits is the byte before it, and the loop top before it has read that position's entry.
+template <class Pos, class E128, class E32, class Emit>
+SPZ_LZ_HD void lazy_step(Pos &strstart, LazyState<Pos> &st, const E128 &e128, const E32 &e32, Emit &emit) {
   const uint32_t prev_length = st.match_length;
-  const uint64_t prev_match = st.match_start;
+  const Pos prev_match = st.match_start;
+  const uint32_t literal = st.byte_before;
   st.match_length = MIN_MATCH - 1;
   if (prev_length < MAX_LAZY) {
-    const uint32_t r = prev_length >= GOOD_MATCH ? r32(strstart) : r128(strstart);
-    const uint32_t len = r >> 16, dist = r & 0xffffu;
+    const uint32_t e = prev_length >= GOOD_MATCH ? e32(strstart) : e128(strstart);
+    const uint32_t len = entry_length(e), dist = entry_distance(e);
+    st.byte_before = entry_byte(e);  // for the next loop top, if it is strstart + 1
     if (len > prev_length) {
       st.match_length = (len == MIN_MATCH && dist > TOO_FAR) ? MIN_MATCH - 1 : len;
-      st.match_start = strstart - dist;
+      st.match_start = strstart - (Pos)dist;
     }
   }
   if (prev_length >= MIN_MATCH && st.match_length <= prev_length) {
     emit((uint32_t)(strstart - 1 - prev_match), prev_length - MIN_MATCH);
-    strstart += prev_length - 1;
+    strstart += (Pos)(prev_length - 1);
     st.match_available = 0;
     st.match_length = MIN_MATCH - 1;
   } else if (st.match_available) {
-    emit(0u, (uint32_t)byte(strstart - 1));
+    emit(0u, literal);
     ++strstart;
   } else {
     st.match_available = 1;

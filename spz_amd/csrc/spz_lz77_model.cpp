@@ -39,32 +39,33 @@ struct ModelParser final : HeadParser {
     std::vector<uint32_t> r128(n_pos), r32(n_pos);
     struct Data {
       const uint8_t *d;
-      uint32_t load4(uint64_t pos) const {
+      uint32_t load4(int64_t pos) const {
         uint32_t v;
         std::memcpy(&v, d + pos, 4);
         return v;
       }
     } dacc{data};
-    auto lacc = [&](uint64_t pos) { return static_cast<uint32_t>(link[pos]); };
-    for (uint64_t p = 0; p < n_pos; ++p) find_matches(dacc, lacc, p, size, &r128[p], &r32[p]);
+    auto lacc = [&](int64_t pos) { return static_cast<uint32_t>(link[pos]); };
+    for (uint64_t p = 0; p < n_pos; ++p) {
+      find_matches<int64_t>(dacc, lacc, static_cast<int64_t>(p), static_cast<int64_t>(base_at(p, size)), &r128[p], &r32[p]);
+    }
     // ---- stage 3: jobs; pass 0 records the first kRecordWindow loop tops of every job but the first
     const uint64_t njobs = (tail_begin + kJobBytes - 1) / kJobBytes;
     std::vector<uint32_t> rec((njobs + 1) * size_t(kRecordWindow) * 2, 0);  // {state, symcount}
     std::memcpy(&rec[njobs * size_t(kRecordWindow) * 2], tail_rec, size_t(kRecordWindow) * 8);
     auto a128 = [&](uint64_t pos) { return r128[pos]; };
     auto a32 = [&](uint64_t pos) { return r32[pos]; };
-    auto abyte = [&](uint64_t pos) { return data[pos]; };
     for (uint64_t j = 1; j < njobs; ++j) {
       const uint64_t begin = j * kJobBytes;
       uint64_t s = begin;
-      LazyState st;
+      LazyState<uint64_t> st;
       uint32_t nsym = 0;
       auto count = [&](uint32_t, uint32_t) { ++nsym; };
       while (s - begin < kRecordWindow) {
         uint32_t *r = &rec[(j * size_t(kRecordWindow) + (s - begin)) * 2];
         r[0] = pack_state(st, s);
         r[1] = nsym;
-        lazy_step(s, st, a128, a32, abyte, count);
+        lazy_step(s, st, a128, a32, count);
       }
     }
     // pass 1: every job emits until it meets its successor's record
@@ -74,7 +75,7 @@ struct ModelParser final : HeadParser {
     for (uint64_t j = 0; j < njobs; ++j) {
       const uint64_t begin = j * kJobBytes, next = std::min<uint64_t>(begin + kJobBytes, tail_begin);
       uint64_t s = begin;
-      LazyState st;
+      LazyState<uint64_t> st;
       auto emit = [&](uint32_t d, uint32_t l) {
         jd[j].push_back(static_cast<uint16_t>(d));
         jl[j].push_back(static_cast<uint8_t>(l));
@@ -91,7 +92,7 @@ struct ModelParser final : HeadParser {
             break;
           }
         }
-        lazy_step(s, st, a128, a32, abyte, emit);
+        lazy_step(s, st, a128, a32, emit);
         if (jl[j].size() > kJobSymbolStride) return false;
       }
       if (!spliced || hi[j] < lo[j]) return false;
