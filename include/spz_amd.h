@@ -309,18 +309,64 @@ int spz_amd_selftest_device(int mode, uint64_t begin, uint64_t count, uint64_t r
  *      the quantise step runs on the GPU, and its output has to stay the reference's bytes.  These entry points
  *      produce the literal/match symbols zlib 1.2.11's deflate_slow + longest_match produce for h_data[0 .. ) up to
  *      the point where they meet the caller's own serial parse of the input's end (`tail_begin`, a multiple of
- *      32768 with 64-96 KiB after it; h_tail_rec: 8192 pairs {lazy-match state, symbols emitted so far} recorded at the
+ *      32768 with 64-96 KiB after it; h_tail_rec: 16384 pairs {lazy-match state, symbols emitted so far} recorded at the
  *      loop tops tail_begin + k of that parse, state 0 where k is not a loop top — spz_deflate.cpp's TopRec).
  *      open: uploads, runs the stages (spz_lz77.hip), returns the symbol count and the index of the first symbol
  *      the tail parse contributes; fetch: copies the symbols out (distance, 0 = literal; literal byte or
  *      length - 3); close: frees the device memory.  SPZ_AMD_ERR_UNSUPPORTED = declined (two neighbouring jobs did not
- *      meet inside 8192 positions, or not enough free device memory: ~19 bytes per input byte): the caller parses on
+ *      meet inside 16384 positions, or not enough free device memory: ~21 bytes per input byte): the caller parses on
  *      the host, with the same result.  Blocking; Huffman coding and the gzip framing stay on the host. ---------- */
 int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_begin, const uint32_t *h_tail_rec,
                             uint32_t n_rec, int device, void **ctx, uint64_t *num_symbols,
                             uint32_t *tail_first_symbol);
 int spz_amd_zlib_parse_fetch(void *ctx, uint16_t *h_dist, uint8_t *h_lc);
 void spz_amd_zlib_parse_close(void *ctx);
+
+/* The Huffman stage of the same member, with the symbols still on the device (trees.c: _tr_tally's counts and
+ * compress_block's bit string; the trees — build_tree / gen_bitlen / gen_codes, the stored / static / dynamic
+ * choice and the tree headers — are built by the caller from the counts, spz_deflate.cpp).
+ *   append        the caller's own symbols of the input's end behind the device's;
+ *   block_stats   block b = symbols [b * block_symbols, ...): literal/length and distance frequencies
+ *                 ([num_blocks][286], [num_blocks][30]; END_BLOCK not counted), input bytes covered, length of the
+ *                 last symbol;
+ *   encode_blocks writes every block's header words (placed by the caller on the 32-bit grid of the deflate body,
+ *                 which starts at bit 0) and its symbols with the block's codes (or, choice 0, the stored input
+ *                 bytes) into a body of body_bytes and copies it to h_body; h_symbol_bits[b] = bits the block's
+ *                 symbols + END_BLOCK took (for the caller's check against its plan).
+ * The static tables of trees.c (length_code, dist_code, base_length, base_dist, extra bits) come from the caller. */
+typedef struct {
+  uint8_t length_code[256];
+  uint8_t dist_code[512];
+  uint16_t base_length[29];
+  uint16_t base_dist[30];
+  uint8_t extra_lbits[29];
+  uint8_t extra_dbits[30];
+  uint8_t pad_[3];
+} spz_amd_deflate_static;
+typedef struct {
+  uint64_t bit_start;          /* of the block in the deflate body */
+  uint32_t header_word_begin;  /* index into the header word array */
+  uint32_t header_words;       /* words, the first one aligned down to the 32-bit grid at bit_start */
+  uint32_t header_bits;        /* bits from bit_start to the first symbol (stored: to the first input byte) */
+  uint32_t choice;             /* 0 stored, 1 static, 2 dynamic */
+  uint32_t input_begin;        /* stored blocks: the input range */
+  uint32_t input_bytes;
+} spz_amd_deflate_block;
+typedef struct {
+  uint16_t lcode[286];
+  uint16_t dcode[30];
+  uint8_t llen[286];
+  uint8_t dlen[30];
+} spz_amd_deflate_codes;
+int spz_amd_zlib_parse_append(void *ctx, const uint16_t *h_dist, const uint8_t *h_lc, uint64_t n);
+int spz_amd_zlib_block_stats(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols,
+                             uint32_t num_blocks, uint16_t *h_lfreq, uint16_t *h_dfreq, uint32_t *h_bytes,
+                             uint32_t *h_last_len);
+int spz_amd_zlib_encode_blocks(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols,
+                               uint32_t num_blocks, const spz_amd_deflate_block *h_blocks,
+                               const spz_amd_deflate_codes *h_codes, const uint32_t *h_header_words,
+                               uint64_t num_header_words, uint64_t body_bytes, uint8_t *h_body,
+                               uint64_t *h_symbol_bits);
 
 #ifdef __cplusplus
 }

@@ -50,6 +50,7 @@ EXPORTS = (
     "spz_amd_rccl_comm_destroy", "spz_amd_gatherv_rccl", "spz_amd_scatterv_rccl",
     "spz_amd_ipc_alloc", "spz_amd_ipc_free", "spz_amd_ipc_open", "spz_amd_ipc_close",
     "spz_amd_zlib_parse_open", "spz_amd_zlib_parse_fetch", "spz_amd_zlib_parse_close",
+    "spz_amd_zlib_parse_append", "spz_amd_zlib_block_stats", "spz_amd_zlib_encode_blocks",
 )
 
 RCCL_UNIQUE_ID_BYTES = 128
@@ -208,6 +209,12 @@ def bind(L):
     L.spz_amd_zlib_parse_fetch.argtypes = [vp, vp, vp]
     L.spz_amd_zlib_parse_close.restype = None
     L.spz_amd_zlib_parse_close.argtypes = [vp]
+    L.spz_amd_zlib_parse_append.restype = i32
+    L.spz_amd_zlib_parse_append.argtypes = [vp, vp, vp, u64]
+    L.spz_amd_zlib_block_stats.restype = i32
+    L.spz_amd_zlib_block_stats.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp]
+    L.spz_amd_zlib_encode_blocks.restype = i32
+    L.spz_amd_zlib_encode_blocks.argtypes = [vp, vp, u32, u32, vp, vp, vp, u64, u64, vp, vp]
     return L
 
 

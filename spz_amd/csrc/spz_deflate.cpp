@@ -502,27 +502,9 @@ void walk_lengths(const Tree &t, int max_code, F emit) {
   }
 }
 
-void plan_block(Block &b) {  // the tally loop + the first half of _tr_flush_block
+void plan_trees(Block &b) {  // the first half of _tr_flush_block, from the tallied frequencies
   const StaticTables &T = tables();
   b.lt.freq[END_BLOCK] = 1;  // init_block
-  uint64_t bytes = 0;
-  uint32_t last_len = 0;
-  for (const Seg &s : b.segs) {
-    for (size_t i = 0; i < s.n; ++i) {
-      const unsigned dist = s.dist[i], lc = s.lc[i];
-      if (dist == 0) {
-        b.lt.freq[lc]++;
-        last_len = 1;
-      } else {
-        b.lt.freq[T.length_code[lc] + LITERALS + 1]++;
-        b.dt.freq[T.d_code(dist - 1)]++;
-        last_len = lc + MIN_MATCH;
-      }
-      bytes += last_len;
-    }
-  }
-  b.bytes = bytes;
-  b.last_sym_len = last_len;
   TreeBuilder tb;
   tb.build(b.lt, L_CODES, kExtraL, LITERALS + 1, MAX_BITS, T.sl_len);
   static const uint16_t kStaticDLen[D_CODES] = {5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5,
@@ -543,12 +525,32 @@ void plan_block(Block &b) {  // the tally loop + the first half of _tr_flush_blo
   b.static_len = tb.static_len;
 }
 
-void encode_block(Block &b, const uint8_t *data) {  // the second half of _tr_flush_block
+void plan_block(Block &b) {  // the tally loop, then the trees
   const StaticTables &T = tables();
-  BitWriter w;
-  w.out.reserve(static_cast<size_t>(b.bit_len / 8 + 16));
-  const int lead = static_cast<int>(b.bit_start & 7);
-  w.nbits = lead;  // leading zero bits: the block is OR-ed into place
+  uint64_t bytes = 0;
+  uint32_t last_len = 0;
+  for (const Seg &s : b.segs) {
+    for (size_t i = 0; i < s.n; ++i) {
+      const unsigned dist = s.dist[i], lc = s.lc[i];
+      if (dist == 0) {
+        b.lt.freq[lc]++;
+        last_len = 1;
+      } else {
+        b.lt.freq[T.length_code[lc] + LITERALS + 1]++;
+        b.dt.freq[T.d_code(dist - 1)]++;
+        last_len = lc + MIN_MATCH;
+      }
+      bytes += last_len;
+    }
+  }
+  b.bytes = bytes;
+  b.last_sym_len = last_len;
+  plan_trees(b);
+}
+
+// What a block writes before its first symbol: the type bits and, for a dynamic block, the trees; for a stored
+// block the padding and the two length words.
+void write_block_header(const Block &b, BitWriter &w) {
   const uint32_t last = b.last ? 1u : 0u;
   if (b.choice == STORED) {
     w.put((0u << 1) + last, 3);
@@ -556,6 +558,32 @@ void encode_block(Block &b, const uint8_t *data) {  // the second half of _tr_fl
     const uint32_t len = static_cast<uint32_t>(b.bytes);
     w.put(len & 0xffffu, 16);
     w.put(~len & 0xffffu, 16);
+  } else if (b.choice == STATIC) {
+    w.put((1u << 1) + last, 3);
+  } else {
+    w.put((2u << 1) + last, 3);
+    const int lcodes = b.lt.max_code + 1, dcodes = b.dt.max_code + 1, blcodes = b.max_blindex + 1;
+    w.put(static_cast<uint32_t>(lcodes - 257), 5);
+    w.put(static_cast<uint32_t>(dcodes - 1), 5);
+    w.put(static_cast<uint32_t>(blcodes - 4), 4);
+    for (int rank = 0; rank < blcodes; ++rank) w.put(b.bt.len[kBlOrder[rank]], 3);
+    auto send = [&](int code, int extra_value, int extra_bits) {
+      w.put(b.bt.code[code], b.bt.len[code]);
+      if (extra_bits) w.put(static_cast<uint32_t>(extra_value), extra_bits);
+    };
+    walk_lengths(b.lt, lcodes - 1, send);
+    walk_lengths(b.dt, dcodes - 1, send);
+  }
+}
+
+void encode_block(Block &b, const uint8_t *data) {  // the second half of _tr_flush_block
+  const StaticTables &T = tables();
+  BitWriter w;
+  w.out.reserve(static_cast<size_t>(b.bit_len / 8 + 16));
+  const int lead = static_cast<int>(b.bit_start & 7);
+  w.nbits = lead;  // leading zero bits: the block is OR-ed into place
+  write_block_header(b, w);
+  if (b.choice == STORED) {
     w.out.insert(w.out.end(), data + b.start, data + b.start + b.bytes);
     w.total += 8 * b.bytes;
   } else {
@@ -563,25 +591,12 @@ void encode_block(Block &b, const uint8_t *data) {  // the second half of _tr_fl
     uint16_t dlen_static[D_CODES];
     const uint16_t *dlen;
     if (b.choice == STATIC) {
-      w.put((1u << 1) + last, 3);
       llen = T.sl_len;
       lcode = T.sl_code;
       for (int i = 0; i < D_CODES; ++i) dlen_static[i] = 5;
       dlen = dlen_static;
       dcode = T.sd_code;
     } else {
-      w.put((2u << 1) + last, 3);
-      const int lcodes = b.lt.max_code + 1, dcodes = b.dt.max_code + 1, blcodes = b.max_blindex + 1;
-      w.put(static_cast<uint32_t>(lcodes - 257), 5);
-      w.put(static_cast<uint32_t>(dcodes - 1), 5);
-      w.put(static_cast<uint32_t>(blcodes - 4), 4);
-      for (int rank = 0; rank < blcodes; ++rank) w.put(b.bt.len[kBlOrder[rank]], 3);
-      auto send = [&](int code, int extra_value, int extra_bits) {
-        w.put(b.bt.code[code], b.bt.len[code]);
-        if (extra_bits) w.put(static_cast<uint32_t>(extra_value), extra_bits);
-      };
-      walk_lengths(b.lt, lcodes - 1, send);
-      walk_lengths(b.dt, dcodes - 1, send);
       llen = b.lt.len;
       lcode = b.lt.code;
       dlen = b.dt.len;
@@ -630,6 +645,67 @@ void parallel_for(size_t n, int threads, F fn) {
   for (auto &t : pool) t.join();
 }
 
+// ---- self-check against the linked zlib: deflate the first `verify` input bytes with zlib itself and
+// compare every output byte that cannot depend on where that prefix ends (whole blocks that end at least
+// 1 KiB before it).  Guards against a zlib whose algorithm differs from the one restated here.
+bool verify_against_zlib(const uint8_t *data, size_t size, const std::vector<Block> &blocks, const std::vector<uint8_t> &member,
+                         size_t verify_prefix) {
+  const uint64_t verify = std::min<uint64_t>(size, verify_prefix);
+  uint64_t safe_bits = 0;
+  for (const Block &b : blocks) {
+    const uint64_t end_pos = b.start + b.bytes;
+    if (verify == size || end_pos + 1024 <= verify) safe_bits = b.bit_start + b.bit_len;
+    else break;
+  }
+  const size_t safe_bytes = 10 + static_cast<size_t>(safe_bits / 8) + (verify == size ? 8 : 0);
+  std::vector<uint8_t> z(compressBound(static_cast<uLong>(verify)) + 64);
+  z_stream zs = {};
+  if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 9, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+  zs.next_in = const_cast<Bytef *>(data);
+  zs.avail_in = static_cast<uInt>(verify);
+  zs.next_out = z.data();
+  zs.avail_out = static_cast<uInt>(z.size());
+  const int rc = deflate(&zs, Z_FINISH);
+  const size_t zn = zs.total_out;
+  deflateEnd(&zs);
+  return rc == Z_STREAM_END && zn >= safe_bytes && member.size() >= safe_bytes &&
+         std::memcmp(z.data(), member.data(), safe_bytes) == 0;
+}
+
+// ---- serial: positions, stored / static / dynamic, bit offsets (the rest of _tr_flush_block's decision)
+bool layout_blocks(std::vector<Block> &blocks, size_t size, uint64_t *total_bits) {
+  uint64_t pos = 0, bit = 0;
+  for (size_t bi = 0; bi < blocks.size(); ++bi) {
+    Block &b = blocks[bi];
+    b.start = pos;
+    pos += b.bytes;
+    // loop top of the iteration that tallied the block's last symbol (Z_FINISH flush: the end of the input)
+    const uint64_t s_flush = b.last ? size : (pos - b.last_sym_len + 1);
+    const bool buf_in_window = b.start >= base_at(s_flush, size);
+    int64_t opt_lenb = (b.opt_len + 3 + 7) >> 3;
+    const int64_t static_lenb = (b.static_len + 3 + 7) >> 3;
+    if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
+    b.bit_start = bit;
+    if (static_cast<int64_t>(b.bytes) + 4 <= opt_lenb && buf_in_window) {
+      if (b.bytes > 0xffff) return false;
+      b.choice = STORED;
+      const uint64_t after_type = bit + 3;
+      b.bit_len = 3 + ((8 - (after_type & 7)) & 7) + 32 + 8 * b.bytes;
+    } else if (static_lenb == opt_lenb) {
+      b.choice = STATIC;
+      b.bit_len = 3 + static_cast<uint64_t>(b.static_len);
+    } else {
+      b.choice = DYNAMIC;
+      b.bit_len = 3 + static_cast<uint64_t>(b.opt_len);
+    }
+    if (b.last) b.bit_len += (8 - ((bit + b.bit_len) & 7)) & 7;  // bi_windup
+    bit += b.bit_len;
+  }
+  if (pos != size) return false;
+  *total_bits = bit;
+  return true;
+}
+
 // ---- from the spliced symbol stream to the gzip member ------------------------------------------------
 // `parts`: the symbol stream in order, in pieces; `tail_literal`: its last symbol is the pending literal zlib
 // tallies after the loop; `crc`: CRC-32 of the input.
@@ -667,35 +743,8 @@ bool finish_member(const uint8_t *data, size_t size, int threads, const std::vec
   });
   lap("plan");
 
-  // ---- serial: positions, stored / static / dynamic, bit offsets (the rest of _tr_flush_block's decision)
-  uint64_t pos = 0, bit = 0;
-  for (size_t bi = 0; bi < nblocks; ++bi) {
-    Block &b = blocks[bi];
-    b.start = pos;
-    pos += b.bytes;
-    // loop top of the iteration that tallied the block's last symbol (Z_FINISH flush: the end of the input)
-    const uint64_t s_flush = b.last ? size : (pos - b.last_sym_len + 1);
-    const bool buf_in_window = b.start >= base_at(s_flush, size);
-    int64_t opt_lenb = (b.opt_len + 3 + 7) >> 3;
-    const int64_t static_lenb = (b.static_len + 3 + 7) >> 3;
-    if (static_lenb <= opt_lenb) opt_lenb = static_lenb;
-    b.bit_start = bit;
-    if (static_cast<int64_t>(b.bytes) + 4 <= opt_lenb && buf_in_window) {
-      if (b.bytes > 0xffff) return false;
-      b.choice = STORED;
-      const uint64_t after_type = bit + 3;
-      b.bit_len = 3 + ((8 - (after_type & 7)) & 7) + 32 + 8 * b.bytes;
-    } else if (static_lenb == opt_lenb) {
-      b.choice = STATIC;
-      b.bit_len = 3 + static_cast<uint64_t>(b.static_len);
-    } else {
-      b.choice = DYNAMIC;
-      b.bit_len = 3 + static_cast<uint64_t>(b.opt_len);
-    }
-    if (b.last) b.bit_len += (8 - ((bit + b.bit_len) & 7)) & 7;  // bi_windup
-    bit += b.bit_len;
-  }
-  if (pos != size) return false;
+  uint64_t bit = 0;
+  if (!layout_blocks(blocks, size, &bit)) return false;
   std::atomic<bool> bad{false};
   parallel_for(nblocks, threads, [&](size_t bi) {
     const uint64_t planned = blocks[bi].bit_len;
@@ -735,34 +784,135 @@ bool finish_member(const uint8_t *data, size_t size, int threads, const std::vec
   for (int k = 0; k < 4; ++k) trailer[4 + k] = static_cast<uint8_t>((size & 0xffffffffu) >> (8 * k));
   lap("assemble");
 
-  // ---- self-check against the linked zlib: deflate the first `verify` input bytes with zlib itself and
-  // compare every output byte that cannot depend on where that prefix ends (whole blocks that end at least
-  // 1 KiB before it).  Guards against a zlib whose algorithm differs from the one restated here.
   if (verify_prefix > 0) {
-    const uint64_t verify = std::min<uint64_t>(size, verify_prefix);
-    uint64_t safe_bits = 0;
-    for (const Block &b : blocks) {
-      const uint64_t end_pos = b.start + b.bytes;
-      if (verify == size || end_pos + 1024 <= verify) safe_bits = b.bit_start + b.bit_len;
-      else break;
-    }
-    const size_t safe_bytes = 10 + static_cast<size_t>(safe_bits / 8) + (verify == size ? 8 : 0);
-    std::vector<uint8_t> z(compressBound(static_cast<uLong>(verify)) + 64);
-    z_stream zs = {};
-    if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 9, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-    zs.next_in = const_cast<Bytef *>(data);
-    zs.avail_in = static_cast<uInt>(verify);
-    zs.next_out = z.data();
-    zs.avail_out = static_cast<uInt>(z.size());
-    const int rc = deflate(&zs, Z_FINISH);
-    const size_t zn = zs.total_out;
-    deflateEnd(&zs);
-    if (rc != Z_STREAM_END || zn < safe_bytes || out->size() < safe_bytes ||
-        std::memcmp(z.data(), out->data(), safe_bytes) != 0) {
-      return false;
-    }
+    if (!verify_against_zlib(data, size, blocks, *out, verify_prefix)) return false;
     lap("verify");
   }
+  return true;
+}
+
+// ---- the same, with the symbols on the parser's side (the device): counts come back, trees and block layout are
+// made here, codes and headers go out, the finished deflate body comes back.
+template <class Lap>
+bool finish_member_on_parser(HeadParser &parser, const uint8_t *data, size_t size, int threads, uint64_t total_syms,
+                             bool tail_literal, uLong crc, std::vector<uint8_t> *out, size_t verify_prefix, Lap &lap) {
+  const StaticTables &T = tables();
+  spz_amd_deflate_static st = {};
+  std::memcpy(st.length_code, T.length_code, sizeof(st.length_code));
+  std::memcpy(st.dist_code, T.dist_code, sizeof(st.dist_code));
+  for (int i = 0; i < 29; ++i) {
+    st.base_length[i] = static_cast<uint16_t>(T.base_length[i]);
+    st.extra_lbits[i] = static_cast<uint8_t>(kExtraL[i]);
+  }
+  for (int i = 0; i < 30; ++i) {
+    st.base_dist[i] = static_cast<uint16_t>(T.base_dist[i]);
+    st.extra_dbits[i] = static_cast<uint8_t>(kExtraD[i]);
+  }
+  size_t nblocks = static_cast<size_t>(total_syms / BLOCK_SYMS) + 1;
+  if (total_syms > 0 && total_syms % BLOCK_SYMS == 0 && tail_literal) nblocks -= 1;
+  std::vector<uint16_t> lfreq(nblocks * 286), dfreq(nblocks * 30);
+  std::vector<uint32_t> bytes(nblocks), last_len(nblocks);
+  if (!parser.blockStats(st, static_cast<uint32_t>(BLOCK_SYMS), static_cast<uint32_t>(nblocks), lfreq.data(), dfreq.data(),
+                         bytes.data(), last_len.data())) {
+    return false;
+  }
+  lap("stats");
+  std::vector<Block> blocks(nblocks);
+  parallel_for(nblocks, threads, [&](size_t bi) {
+    Block &b = blocks[bi];
+    const uint64_t g0 = static_cast<uint64_t>(bi) * BLOCK_SYMS, g1 = std::min<uint64_t>(total_syms, g0 + BLOCK_SYMS);
+    b.nsyms = static_cast<size_t>(g1 - g0);
+    b.last = (bi + 1 == nblocks);
+    for (int i = 0; i < 286; ++i) b.lt.freq[i] = lfreq[bi * 286 + i];
+    for (int i = 0; i < 30; ++i) b.dt.freq[i] = dfreq[bi * 30 + i];
+    b.bytes = bytes[bi];
+    b.last_sym_len = last_len[bi];
+    plan_trees(b);
+  });
+  lap("trees");
+  uint64_t bit = 0;
+  if (!layout_blocks(blocks, size, &bit)) return false;
+  // codes and headers: a block's header is written on the 32-bit grid of the body, starting at the word its first bit is in
+  std::vector<spz_amd_deflate_block> desc(nblocks);
+  std::vector<spz_amd_deflate_codes> codes(nblocks);
+  std::vector<std::vector<uint8_t>> hdr(nblocks);
+  parallel_for(nblocks, threads, [&](size_t bi) {
+    const Block &b = blocks[bi];
+    BitWriter w;
+    const unsigned lead = static_cast<unsigned>(b.bit_start & 31);
+    for (unsigned i = 0; i < lead / 8; ++i) w.out.push_back(0);
+    w.nbits = static_cast<int>(lead & 7);
+    write_block_header(b, w);
+    spz_amd_deflate_block &d = desc[bi];
+    d.bit_start = b.bit_start;
+    d.header_bits = static_cast<uint32_t>(w.total);
+    if (w.nbits > 0) w.out.push_back(static_cast<uint8_t>(w.acc));
+    while (w.out.size() % 4 != 0) w.out.push_back(0);
+    d.header_words = static_cast<uint32_t>(w.out.size() / 4);
+    d.choice = static_cast<uint32_t>(b.choice);
+    d.input_begin = static_cast<uint32_t>(b.start);
+    d.input_bytes = static_cast<uint32_t>(b.bytes);
+    hdr[bi].swap(w.out);
+    spz_amd_deflate_codes &c = codes[bi];
+    if (b.choice == STATIC) {
+      for (int i = 0; i < 286; ++i) {
+        c.lcode[i] = T.sl_code[i];
+        c.llen[i] = static_cast<uint8_t>(T.sl_len[i]);
+      }
+      for (int i = 0; i < 30; ++i) {
+        c.dcode[i] = T.sd_code[i];
+        c.dlen[i] = 5;
+      }
+    } else {
+      for (int i = 0; i < 286; ++i) {
+        c.lcode[i] = b.lt.code[i];
+        c.llen[i] = static_cast<uint8_t>(b.lt.len[i]);
+      }
+      for (int i = 0; i < 30; ++i) {
+        c.dcode[i] = b.dt.code[i];
+        c.dlen[i] = static_cast<uint8_t>(b.dt.len[i]);
+      }
+    }
+  });
+  uint64_t nwords = 0;
+  for (size_t bi = 0; bi < nblocks; ++bi) {
+    desc[bi].header_word_begin = static_cast<uint32_t>(nwords);
+    nwords += desc[bi].header_words;
+  }
+  if (nwords >= (uint64_t(1) << 32)) return false;
+  std::vector<uint32_t> words(static_cast<size_t>(nwords) + 1);
+  parallel_for(nblocks, threads, [&](size_t bi) {
+    if (!hdr[bi].empty()) std::memcpy(&words[desc[bi].header_word_begin], hdr[bi].data(), hdr[bi].size());
+  });
+  lap("codes");
+  const uint64_t deflate_bytes = bit / 8;
+  out->clear();
+  detail::resizeUninitialized(out, static_cast<size_t>(10 + deflate_bytes + 8));
+  {
+    detail::Prefault pf;
+    pf.add(out->data(), out->size());
+    pf.start();
+    pf.join();
+  }
+  const uint8_t header[10] = {0x1f, 0x8b, 0x08, 0x00, 0, 0, 0, 0, 0x00, 0x03};
+  std::memcpy(out->data(), header, 10);
+  std::vector<uint64_t> symbol_bits(nblocks);
+  if (!parser.encodeBlocks(st, static_cast<uint32_t>(BLOCK_SYMS), static_cast<uint32_t>(nblocks), desc.data(), codes.data(),
+                           words.data(), nwords, deflate_bytes, out->data() + 10, symbol_bits.data())) {
+    return false;
+  }
+  lap("encode");
+  for (size_t bi = 0; bi < nblocks; ++bi) {  // what the encoder wrote against what was planned
+    const Block &b = blocks[bi];
+    uint64_t planned = b.bit_len - desc[bi].header_bits;
+    if (b.last) planned -= (8 - ((b.bit_start + desc[bi].header_bits + symbol_bits[bi]) & 7)) & 7;
+    if (symbol_bits[bi] != planned) return false;
+  }
+  uint8_t *trailer = out->data() + 10 + deflate_bytes;
+  for (int k2 = 0; k2 < 4; ++k2) trailer[k2] = static_cast<uint8_t>(crc >> (8 * k2));
+  for (int k2 = 0; k2 < 4; ++k2) trailer[4 + k2] = static_cast<uint8_t>((size & 0xffffffffu) >> (8 * k2));
+  if (verify_prefix > 0 && !verify_against_zlib(data, size, blocks, *out, verify_prefix)) return false;
+  lap("verify");
   return true;
 }
 
@@ -913,6 +1063,17 @@ bool compressWithHeadParser(const uint8_t *data, size_t size, int threads, HeadP
   }
   lap("head parse");
   if (tail_first > tj.sym_lc.size() || nhead > size) return false;
+  if (parser.canFinish()) {
+    const size_t ntail = tj.sym_lc.size() - tail_first;
+    if (!parser.append(tj.sym_dist.data() + tail_first, tj.sym_lc.data() + tail_first, ntail)) return false;
+    crc_thread.join();
+    uLong crc = crcs[0];
+    for (size_t i = 1; i < ncrc; ++i) {
+      const size_t lo = i * (size_t(4) << 20), hi = std::min(size, lo + (size_t(4) << 20));
+      crc = crc32_combine(crc, crcs[i], static_cast<z_off_t>(hi - lo));
+    }
+    return finish_member_on_parser(parser, data, size, threads, nhead + ntail, tj.tail_literal, crc, out, verify_prefix, lap);
+  }
   std::vector<uint16_t> hd;
   std::vector<uint8_t> hl;
   detail::resizeUninitialized(&hd, static_cast<size_t>(nhead));
@@ -936,7 +1097,9 @@ bool compressWithHeadParser(const uint8_t *data, size_t size, int threads, HeadP
     crc = crc32_combine(crc, crcs[i], static_cast<z_off_t>(hi - lo));
   }
   lap("crc join");
-  return finish_member(data, size, threads, parts, tj.tail_literal, crc, out, verify_prefix, lap);
+  const bool ok = finish_member(data, size, threads, parts, tj.tail_literal, crc, out, verify_prefix, lap);
+  lap("blocks freed");
+  return ok;
 }
 
 }  // namespace exactgz

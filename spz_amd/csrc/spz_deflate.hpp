@@ -6,6 +6,8 @@
 #include <cstdint>
 #include <vector>
 
+#include "spz_amd.h"
+
 namespace spz {
 namespace exactgz {
 
@@ -33,6 +35,19 @@ struct HeadParser {
                      uint64_t *num_symbols, uint32_t *tail_first_symbol) = 0;
   // Copies the head symbols out: distance (0 = literal) and literal byte / match length - 3.
   virtual bool fetch(uint16_t *dist, uint8_t *lc) = 0;
+  // Optional: the Huffman stage where the symbols already are (include/spz_amd.h: spz_amd_zlib_parse_append /
+  // _block_stats / _encode_blocks have the same meaning).  canFinish() false: the caller fetches the symbols and
+  // does all of it on the host.
+  virtual bool canFinish() const { return false; }
+  virtual bool append(const uint16_t *, const uint8_t *, size_t) { return false; }
+  virtual bool blockStats(const spz_amd_deflate_static &, uint32_t, uint32_t, uint16_t *, uint16_t *, uint32_t *,
+                          uint32_t *) {
+    return false;
+  }
+  virtual bool encodeBlocks(const spz_amd_deflate_static &, uint32_t, uint32_t, const spz_amd_deflate_block *,
+                            const spz_amd_deflate_codes *, const uint32_t *, uint64_t, uint64_t, uint8_t *, uint64_t *) {
+    return false;
+  }
 };
 bool compressWithHeadParser(const uint8_t *data, size_t size, int threads, HeadParser &parser,
                             std::vector<uint8_t> *out, size_t verify_prefix = 0);

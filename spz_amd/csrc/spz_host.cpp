@@ -12,6 +12,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -426,6 +427,27 @@ struct DeviceHeadParser final : exactgz::HeadParser {
     status = spz_amd_zlib_parse_fetch(ctx, dist, lc);
     return status == SPZ_AMD_OK;
   }
+  // SPZ_AMD_GZIP_DEVICE_HUFFMAN=0: symbols come back and the host codes them (the parse alone on the device)
+  bool canFinish() const override {
+    const char *e = std::getenv("SPZ_AMD_GZIP_DEVICE_HUFFMAN");
+    return !(e && e[0] == '0');
+  }
+  bool append(const uint16_t *dist, const uint8_t *lc, size_t n) override {
+    status = spz_amd_zlib_parse_append(ctx, dist, lc, n);
+    return status == SPZ_AMD_OK;
+  }
+  bool blockStats(const spz_amd_deflate_static &t, uint32_t block_syms, uint32_t nblocks, uint16_t *lfreq, uint16_t *dfreq,
+                  uint32_t *bytes, uint32_t *last_len) override {
+    status = spz_amd_zlib_block_stats(ctx, &t, block_syms, nblocks, lfreq, dfreq, bytes, last_len);
+    return status == SPZ_AMD_OK;
+  }
+  bool encodeBlocks(const spz_amd_deflate_static &t, uint32_t block_syms, uint32_t nblocks, const spz_amd_deflate_block *blocks,
+                    const spz_amd_deflate_codes *codes, const uint32_t *words, uint64_t nwords, uint64_t body_bytes,
+                    uint8_t *body, uint64_t *symbol_bits) override {
+    status = spz_amd_zlib_encode_blocks(ctx, &t, block_syms, nblocks, blocks, codes, words, nwords, body_bytes, body,
+                                        symbol_bits);
+    return status == SPZ_AMD_OK;
+  }
 };
 
 bool deviceParseWanted(size_t size) {
@@ -453,8 +475,22 @@ bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out
       const size_t verify = std::min<size_t>(size_t(256) << 10, std::max<size_t>(size_t(64) << 10, size / 16));
       const size_t avail = availablePhysicalBytes();
       if (avail == 0 || size / 2 * 9 < avail) {
-        DeviceHeadParser parser;
-        if (exactgz::compressWithHeadParser(data, size, std::max(threads, 1), parser, out, verify)) {
+        static const bool timing = std::getenv("SPZ_AMD_EXACT_GZIP_TIMING") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
+        bool ok;
+        {
+          DeviceHeadParser parser;
+          ok = exactgz::compressWithHeadParser(data, size, std::max(threads, 1), parser, out, verify);
+          if (timing) {
+            std::fprintf(stderr, "[exactgz] writer     %.3f s in all\n",
+                         std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+          }
+        }
+        if (timing) {
+          std::fprintf(stderr, "[exactgz] + release  %.3f s in all\n",
+                       std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        }
+        if (ok) {
           const int level = gzipVerifyLevel();
           if (level == 0 || verifiedExact(data, size, *out, level)) {
             g_device_parses.fetch_add(1);

@@ -16,18 +16,20 @@
 //                     their 96 KiB of links are staged in LDS (144 KiB of the CU's 160), every thread walks the
 //                     chains of 16 positions exactly like longest_match does — all reads are LDS reads — and
 //                     writes the two results per position (chain budget 128 and 32).
-//   lz_parse_kernel   one lane per 64 KiB job: deflate_slow's loop with the table lookup in place of the search
-//                     (each lane keeps the 32 entries around its position in LDS: one HBM latency per 32 positions).
-//                     Pass 0 records each job's lazy state over its first 8192 loop tops, pass 1 emits symbols
-//                     and ends a job where its state equals its successor's record (spz_deflate.cpp's splice).
-//   lz_compact_kernel the jobs' contributed symbol ranges, concatenated.
+//   lz_parse_kernel   one lane per 16 KiB job: deflate_slow's loop with the table lookup in place of the search
+//                     (each lane keeps the 32 entries around its position in LDS: one HBM latency per 32 positions),
+//                     recording the lazy state at every loop top (one word per input position).
+//   lz_stitch_kernel  every job continues into its successor's range until its state equals the recorded one
+//                     (spz_deflate.cpp's splice): a few hundred positions.
+//   lz_compact_kernel the jobs' contributed symbol ranges and stitches, concatenated.
 //
 // The last 64-96 KiB of the input (where zlib's lookahead runs out and its window's stale bytes matter) are
 // parsed by spz_deflate.cpp's serial job on the host; its records arrive here as the last job's successor.
-// HBM per input byte: 1 (input) + 2 (links) + 8 (tables) + 1 (records) + 3.4 (job symbols); the dense symbol
+// HBM per input byte: 1 (input) + 2 (links) + 8 (tables) + 4 (records) + 6 (job and stitch symbols); the dense symbol
 // arrays reuse the tables' memory.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -152,28 +154,28 @@ __global__ __launch_bounds__(1024) void lz_match_kernel(const uint8_t *__restric
 
 // ---- stage 3: lazy state machine -------------------------------------------------------------------------
 struct JobInfo {
-  uint32_t lo, hi, spliced;
+  uint32_t lo;        // first symbol of the job's own parse that it contributes (set by its predecessor's stitch)
+  uint32_t n;         // symbols of its own parse
+  uint32_t extra;     // symbols of its stitch
+  uint32_t spliced;
+  // where its own parse stopped: the first loop top at or past its end, with the lazy state there
+  uint32_t end_s, end_available, end_length, end_byte, end_start;
 };
 
 constexpr uint32_t kParseWindow = 32;  // table entries a lane fetches at a time
 
-__global__ __launch_bounds__(64) void lz_parse_kernel(int pass, const uint32_t *__restrict__ r128,
-                                                      const uint32_t *__restrict__ r32, uint32_t head_end, uint32_t n_jobs,
-                                                      uint2 *__restrict__ rec, uint16_t *__restrict__ sym_dist,
-                                                      uint8_t *__restrict__ sym_lc, JobInfo *__restrict__ info) {
-  // The loop's next position depends on the entry it has just read, so a read from HBM per loop top would be all
-  // latency: each lane keeps the 32 entries around its position in LDS ([entry][lane]: conflict-free) and
-  // refills them with eight 16-byte loads when it leaves them.
-  __shared__ uint32_t s_win[kParseWindow * 64];
-  const uint32_t lane = threadIdx.x;
-  const uint32_t j = blockIdx.x * 64u + lane;
-  if (j >= n_jobs) return;
-  const uint32_t begin = j * kJobBytes;
-  uint32_t win_base = 0xffffffffu;
-  auto e128 = [&](uint32_t pos) {
+// The loop's next position depends on the entry it has just read, so a read from HBM per loop top would be all
+// latency: each lane keeps the 32 entries around its position in LDS ([entry][lane]: conflict-free) and
+// refills them with eight 16-byte loads when it leaves them.
+struct EntryWindow {
+  uint32_t *s_win;
+  const uint32_t *table;
+  uint32_t lane;
+  mutable uint32_t base;
+  __device__ __forceinline__ uint32_t operator()(uint32_t pos) const {
     const uint32_t b = pos & ~(kParseWindow - 1u);
-    if (b != win_base) {
-      const uint4 *src = reinterpret_cast<const uint4 *>(r128 + b);
+    if (b != base) {
+      const uint4 *src = reinterpret_cast<const uint4 *>(table + b);
 #pragma unroll
       for (uint32_t q = 0; q < kParseWindow / 4; ++q) {
         const uint4 v = src[q];
@@ -182,73 +184,284 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(int pass, const uint32_t *
         s_win[(4 * q + 2) * 64 + lane] = v.z;
         s_win[(4 * q + 3) * 64 + lane] = v.w;
       }
-      win_base = b;
+      base = b;
     }
     return s_win[(pos - b) * 64 + lane];
-  };
-  auto e32 = [&](uint32_t pos) { return r32[pos]; };
-  uint32_t s = begin;
-  LazyState<uint32_t> st;
-  uint32_t nsym = 0;
-  if (pass == 0) {
-    if (j == 0) return;  // nobody splices into the first job
-    uint2 *r = rec + (size_t)j * kRecordWindow;
-    auto count = [&](uint32_t, uint32_t) { ++nsym; };
-    while (s - begin < kRecordWindow) {
-      r[s - begin] = make_uint2(pack_state(st, s), nsym);
-      lazy_step(s, st, e128, e32, count);
-    }
-    return;
   }
-  const uint32_t next = (begin + kJobBytes < head_end) ? begin + kJobBytes : head_end;
-  const uint2 *succ = rec + (size_t)(j + 1) * kRecordWindow;
+};
+
+__global__ __launch_bounds__(64) void lz_parse_kernel(const uint32_t *__restrict__ r128, const uint32_t *__restrict__ r32,
+                                                      uint32_t n_jobs, uint32_t *__restrict__ rec,
+                                                      uint16_t *__restrict__ sym_dist, uint8_t *__restrict__ sym_lc,
+                                                      JobInfo *__restrict__ info) {
+  __shared__ uint32_t s_win[kParseWindow * 64];
+  const uint32_t lane = threadIdx.x;
+  const uint32_t j = blockIdx.x * 64u + lane;
+  if (j >= n_jobs) return;
+  const uint32_t begin = j * kJobBytes, next = begin + kJobBytes;
+  EntryWindow e128 = {s_win, r128, lane, 0xffffffffu};
+  auto e32 = [&](uint32_t pos) { return r32[pos]; };
   uint16_t *od = sym_dist + (size_t)j * kJobSymbolStride;
   uint8_t *ol = sym_lc + (size_t)j * kJobSymbolStride;
+  uint32_t s = begin, nsym = 0;
+  LazyState<uint32_t> st;
   auto emit = [&](uint32_t dist, uint32_t lc) {
     od[nsym] = (uint16_t)dist;
     ol[nsym] = (uint8_t)lc;
     ++nsym;
   };
-  uint32_t spliced = 0;
-  for (;;) {
-    if (s >= next) {
-      if (s - next >= kRecordWindow) break;
-      const uint2 r = succ[s - next];
-      if (r.x == pack_state(st, s)) {
-        info[j].hi = nsym;
-        info[j + 1].lo = r.y;
-        spliced = 1;
-        break;
-      }
-    }
-    if (nsym + 1 >= kJobSymbolStride) break;
+  while (s < next) {
+    rec[s] = pack_state(st, s);
     lazy_step(s, st, e128, e32, emit);
   }
+  JobInfo &o = info[j];
+  o.n = nsym;
+  o.end_s = s;
+  o.end_available = st.match_available;
+  o.end_length = st.match_length;
+  o.end_byte = st.byte_before;
+  o.end_start = st.match_start;
+}
+
+__global__ __launch_bounds__(64) void lz_stitch_kernel(const uint32_t *__restrict__ r128, const uint32_t *__restrict__ r32,
+                                                       uint32_t n_jobs, const uint32_t *__restrict__ rec,
+                                                       uint16_t *__restrict__ x_dist, uint8_t *__restrict__ x_lc,
+                                                       JobInfo *__restrict__ info) {
+  const uint32_t j = blockIdx.x * 64u + threadIdx.x;
+  if (j >= n_jobs) return;
+  const uint32_t next = (j + 1) * kJobBytes;
+  auto e128 = [&](uint32_t pos) { return r128[pos]; };
+  auto e32 = [&](uint32_t pos) { return r32[pos]; };
+  uint16_t *od = x_dist + (size_t)j * kStitchSymbolStride;
+  uint8_t *ol = x_lc + (size_t)j * kStitchSymbolStride;
+  uint32_t s = info[j].end_s, nsym = 0, spliced = 0;
+  LazyState<uint32_t> st;
+  st.match_available = info[j].end_available;
+  st.match_length = info[j].end_length;
+  st.byte_before = info[j].end_byte;
+  st.match_start = info[j].end_start;
+  auto emit = [&](uint32_t dist, uint32_t lc) {
+    od[nsym] = (uint16_t)dist;
+    ol[nsym] = (uint8_t)lc;
+    ++nsym;
+  };
+  while (s - next < kRecordWindow) {
+    if (rec[s] == pack_state(st, s)) {
+      // symbols the successor's own parse had emitted before this loop top
+      uint32_t s2 = next, cnt = 0;
+      LazyState<uint32_t> st2;
+      auto count = [&](uint32_t, uint32_t) { ++cnt; };
+      while (s2 < s) lazy_step(s2, st2, e128, e32, count);
+      if (s2 == s) {
+        info[j + 1].lo = cnt;
+        info[j].end_s = s;  // the meeting point
+        spliced = 1;
+      }
+      break;
+    }
+    lazy_step(s, st, e128, e32, emit);
+  }
+  info[j].extra = nsym;
   info[j].spliced = spliced;
 }
 
 // ---- stage 4: the contributed ranges, concatenated ---------------------------------------------------------
 __global__ __launch_bounds__(256) void lz_compact_kernel(const uint16_t *__restrict__ sym_dist,
                                                          const uint8_t *__restrict__ sym_lc,
+                                                         const uint16_t *__restrict__ x_dist, const uint8_t *__restrict__ x_lc,
                                                          const JobInfo *__restrict__ info,
                                                          const unsigned long long *__restrict__ goff,
                                                          uint16_t *__restrict__ dense_dist, uint8_t *__restrict__ dense_lc) {
   const uint32_t j = blockIdx.x;
-  const uint32_t lo = info[j].lo, n = info[j].hi - lo;
-  const size_t src = (size_t)j * kJobSymbolStride + lo;
+  const uint32_t lo = info[j].lo, n = info[j].n - lo, x = info[j].extra;
+  const size_t src = (size_t)j * kJobSymbolStride + lo, xsrc = (size_t)j * kStitchSymbolStride;
   const unsigned long long dst = goff[j];
   for (uint32_t i = threadIdx.x; i < n; i += 256) {
     dense_dist[dst + i] = sym_dist[src + i];
     dense_lc[dst + i] = sym_lc[src + i];
   }
+  for (uint32_t i = threadIdx.x; i < x; i += 256) {
+    dense_dist[dst + n + i] = x_dist[xsrc + i];
+    dense_lc[dst + n + i] = x_lc[xsrc + i];
+  }
+}
+
+// ---- Huffman stage (trees.c's tally and compress_block; the trees themselves are built on the host) ----------
+// Block b is symbols [b * block_syms, ...) of the dense stream.  Stats: the literal/length and distance
+// frequencies (what _tr_tally counts), the input bytes the block covers and the length of its last symbol.
+__device__ __forceinline__ uint32_t d_code_of(const spz_amd_deflate_static *t, uint32_t dist_minus_1) {
+  return dist_minus_1 < 256u ? t->dist_code[dist_minus_1] : t->dist_code[256u + (dist_minus_1 >> 7)];
+}
+
+__global__ __launch_bounds__(256) void lz_block_stats_kernel(const uint16_t *__restrict__ dist, const uint8_t *__restrict__ lc,
+                                                             unsigned long long total, uint32_t block_syms,
+                                                             const spz_amd_deflate_static *__restrict__ tables,
+                                                             uint16_t *__restrict__ lfreq, uint16_t *__restrict__ dfreq,
+                                                             uint32_t *__restrict__ bytes, uint32_t *__restrict__ last_len) {
+  __shared__ uint32_t hl[288], hd[32], s_bytes;
+  const uint32_t tid = threadIdx.x, b = blockIdx.x;
+  for (uint32_t i = tid; i < 288; i += 256) hl[i] = 0;
+  if (tid < 32) hd[tid] = 0;
+  if (tid == 0) s_bytes = 0;
+  __syncthreads();
+  const unsigned long long g0 = (unsigned long long)b * block_syms;
+  const unsigned long long g1 = (g0 + block_syms < total) ? g0 + block_syms : total;
+  uint32_t mine = 0;
+  for (unsigned long long i = g0 + tid; i < g1; i += 256) {
+    const uint32_t d = dist[i], l = lc[i];
+    uint32_t len = 1;
+    if (d == 0) {
+      atomicAdd(&hl[l], 1u);
+    } else {
+      atomicAdd(&hl[tables->length_code[l] + 257u], 1u);
+      atomicAdd(&hd[d_code_of(tables, d - 1u)], 1u);
+      len = l + MIN_MATCH;
+    }
+    mine += len;
+    if (i + 1 == g1) last_len[b] = len;
+  }
+  atomicAdd(&s_bytes, mine);
+  __syncthreads();
+  for (uint32_t i = tid; i < 286; i += 256) lfreq[(size_t)b * 286 + i] = (uint16_t)hl[i];
+  if (tid < 30) dfreq[(size_t)b * 30 + tid] = (uint16_t)hd[tid];
+  if (tid == 0) {
+    bytes[b] = s_bytes;
+    if (g1 == g0) last_len[b] = 0;
+  }
+}
+
+// Encode: a thread owns a contiguous run of its block's symbols; the runs' bit offsets come from a scan of their
+// lengths.  Words inside a run are the thread's own (plain stores); the first and the last word of a run may be
+// shared with the neighbours and are OR-ed into the zero-filled body.
+struct BitSink {
+  uint32_t *body;            // the deflate body as little-endian words, zero-filled
+  unsigned long long word;   // index of the word `acc` starts in
+  unsigned long long acc;    // pending bits, bit 0 = bit `lead` ... of that word
+  uint32_t fill;             // bits in acc (including the lead-in)
+  bool first;                // the word about to be written is the run's first (shared with the previous run)
+  __device__ __forceinline__ void put(uint32_t value, uint32_t nbits) {
+    acc |= (unsigned long long)value << fill;
+    fill += nbits;
+    if (fill >= 32u) {
+      const uint32_t w = (uint32_t)acc;
+      if (first) atomicOr(&body[word], w);
+      else body[word] = w;
+      first = false;
+      ++word;
+      acc >>= 32;
+      fill -= 32u;
+    }
+  }
+  __device__ __forceinline__ void finish() {
+    if (fill > 0u) atomicOr(&body[word], (uint32_t)acc);
+  }
+};
+
+constexpr uint32_t kEncodeThreads = 256;
+
+__global__ __launch_bounds__(256) void lz_encode_kernel(const uint16_t *__restrict__ dist, const uint8_t *__restrict__ lc,
+                                                        unsigned long long total, uint32_t block_syms,
+                                                        const uint8_t *__restrict__ input,
+                                                        const spz_amd_deflate_static *__restrict__ tables,
+                                                        const spz_amd_deflate_block *__restrict__ blocks,
+                                                        const spz_amd_deflate_codes *__restrict__ codes,
+                                                        const uint32_t *__restrict__ header_words, uint32_t *__restrict__ body,
+                                                        unsigned long long *__restrict__ symbol_bits) {
+  __shared__ spz_amd_deflate_codes cd;
+  __shared__ spz_amd_deflate_static tb;
+  __shared__ uint32_t s_scan[kEncodeThreads];
+  const uint32_t tid = threadIdx.x, b = blockIdx.x;
+  const spz_amd_deflate_block blk = blocks[b];
+  // the block's header (type bits, trees, or the stored block's length words): placed by the host on the word grid
+  for (uint32_t i = tid; i < blk.header_words; i += kEncodeThreads) {
+    const uint32_t w = header_words[blk.header_word_begin + i];
+    if (w != 0u) atomicOr(&body[(blk.bit_start >> 5) + i], w);
+  }
+  if (blk.choice == 0u) {  // stored: the input bytes themselves, byte-aligned after the header
+    uint8_t *out = reinterpret_cast<uint8_t *>(body) + ((blk.bit_start + blk.header_bits) >> 3);
+    for (uint32_t i = tid; i < blk.input_bytes; i += kEncodeThreads) out[i] = input[(size_t)blk.input_begin + i];
+    if (tid == 0) symbol_bits[b] = 8ull * blk.input_bytes;
+    return;
+  }
+  {
+    const uint32_t *src = reinterpret_cast<const uint32_t *>(codes + b);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&cd);
+    for (uint32_t i = tid; i < sizeof(spz_amd_deflate_codes) / 4; i += kEncodeThreads) dst[i] = src[i];
+    const uint32_t *ts = reinterpret_cast<const uint32_t *>(tables);
+    uint32_t *td = reinterpret_cast<uint32_t *>(&tb);
+    for (uint32_t i = tid; i < sizeof(spz_amd_deflate_static) / 4; i += kEncodeThreads) td[i] = ts[i];
+  }
+  __syncthreads();
+  const unsigned long long g0 = (unsigned long long)b * block_syms;
+  const unsigned long long g1 = (g0 + block_syms < total) ? g0 + block_syms : total;
+  const uint32_t n = (uint32_t)(g1 - g0) + 1u;  // the block's symbols and its END_BLOCK
+  const uint32_t per = (n + kEncodeThreads - 1u) / kEncodeThreads;
+  const uint32_t i0 = tid * per < n ? tid * per : n, i1 = i0 + per < n ? i0 + per : n;
+  // what one symbol puts into the stream: the length part and the distance part (each at most 28 bits)
+  auto symbol = [&](uint32_t i, uint32_t *v0, uint32_t *n0, uint32_t *v1, uint32_t *n1) {
+    *v1 = 0;
+    *n1 = 0;
+    if (i + 1u == n) {  // END_BLOCK
+      *v0 = cd.lcode[256];
+      *n0 = cd.llen[256];
+      return;
+    }
+    const uint32_t d = dist[g0 + i], l = lc[g0 + i];
+    if (d == 0u) {
+      *v0 = cd.lcode[l];
+      *n0 = cd.llen[l];
+      return;
+    }
+    const uint32_t code = tb.length_code[l];
+    const uint32_t el = tb.extra_lbits[code];
+    *v0 = cd.lcode[code + 257u] | (((l - tb.base_length[code]) & ((1u << el) - 1u)) << cd.llen[code + 257u]);  // 258: no extra bits
+    *n0 = cd.llen[code + 257u] + el;
+    const uint32_t dm = d - 1u;
+    const uint32_t dc = dm < 256u ? tb.dist_code[dm] : tb.dist_code[256u + (dm >> 7)];
+    const uint32_t ed = tb.extra_dbits[dc];
+    *v1 = cd.dcode[dc] | (((dm - tb.base_dist[dc]) & ((1u << ed) - 1u)) << cd.dlen[dc]);
+    *n1 = cd.dlen[dc] + ed;
+  };
+  uint32_t bits = 0;
+  for (uint32_t i = i0; i < i1; ++i) {
+    uint32_t v0, n0, v1, n1;
+    symbol(i, &v0, &n0, &v1, &n1);
+    bits += n0 + n1;
+  }
+  // exclusive scan of the runs' bit counts (a block's symbols take at most 32768 * 48 bits)
+  s_scan[tid] = bits;
+  __syncthreads();
+  for (uint32_t off = 1; off < kEncodeThreads; off <<= 1) {
+    const uint32_t v = tid >= off ? s_scan[tid - off] : 0u;
+    __syncthreads();
+    s_scan[tid] += v;
+    __syncthreads();
+  }
+  const uint32_t before = s_scan[tid] - bits;
+  if (tid == kEncodeThreads - 1) symbol_bits[b] = s_scan[tid];
+  if (i0 >= i1) return;
+  const unsigned long long at = blk.bit_start + blk.header_bits + before;
+  BitSink sink = {body, at >> 5, 0ull, (uint32_t)(at & 31ull), true};
+  for (uint32_t i = i0; i < i1; ++i) {
+    uint32_t v0, n0, v1, n1;
+    symbol(i, &v0, &n0, &v1, &n1);
+    sink.put(v0, n0);
+    if (n1) sink.put(v1, n1);
+  }
+  sink.finish();
 }
 
 struct LzContext {
   int device = 0;
   void *block = nullptr;
-  const uint16_t *dense_dist = nullptr;
-  const uint8_t *dense_lc = nullptr;
-  uint64_t num_symbols = 0;
+  uint16_t *dense_dist = nullptr;
+  uint8_t *dense_lc = nullptr;
+  uint64_t num_symbols = 0, capacity = 0;   // symbols in / that fit into the dense arrays
+  const uint8_t *data = nullptr;            // the whole input
+  uint64_t size = 0;
+  // memory of the parse that the Huffman stage reuses
+  char *scratch_a = nullptr, *scratch_b = nullptr, *scratch_c = nullptr;
+  size_t scratch_a_bytes = 0, scratch_b_bytes = 0, scratch_c_bytes = 0;
 };
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -285,7 +498,7 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
     t_prev = now;
   };
 
-  const uint32_t n_jobs = (uint32_t)((tail_begin + kJobBytes - 1) / kJobBytes);
+  const uint32_t n_jobs = (uint32_t)(tail_begin / kJobBytes);  // tail_begin is a multiple of W = 2 jobs
   const uint32_t n_tiles = (uint32_t)((n_pos + kMatchTile - 1) / kMatchTile);
   const size_t pos_padded = (size_t)n_tiles * kMatchTile;
   // carve one allocation
@@ -295,14 +508,16 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
     off += round_up(bytes, 256);
     return at;
   };
-  const size_t data_bytes = pos_padded + kReadAhead + 64;  // what the last tile stages
+  const size_t data_bytes = std::max<size_t>(pos_padded + kReadAhead + 64, round_up(size, 4) + 64);  // what the last tile stages; the whole input
   const size_t o_data = carve(data_bytes);
   const size_t o_link = carve(pos_padded * sizeof(uint16_t));
   const size_t o_r128 = carve(pos_padded * sizeof(uint32_t));
   const size_t o_r32 = carve(pos_padded * sizeof(uint32_t));
-  const size_t o_rec = carve((size_t)(n_jobs + 1) * kRecordWindow * sizeof(uint2));
+  const size_t o_rec = carve(((size_t)n_jobs * kJobBytes + kRecordWindow) * sizeof(uint32_t));
   const size_t o_sd = carve((size_t)n_jobs * kJobSymbolStride * sizeof(uint16_t));
   const size_t o_sl = carve((size_t)n_jobs * kJobSymbolStride);
+  const size_t o_xd = carve((size_t)n_jobs * kStitchSymbolStride * sizeof(uint16_t));
+  const size_t o_xl = carve((size_t)n_jobs * kStitchSymbolStride);
   const size_t o_info = carve((size_t)(n_jobs + 1) * sizeof(JobInfo));
   const size_t o_goff = carve((size_t)n_jobs * sizeof(unsigned long long));
   const size_t total = off;
@@ -321,9 +536,11 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
   uint16_t *d_link = reinterpret_cast<uint16_t *>(block + o_link);
   uint32_t *d_r128 = reinterpret_cast<uint32_t *>(block + o_r128);
   uint32_t *d_r32 = reinterpret_cast<uint32_t *>(block + o_r32);
-  uint2 *d_rec = reinterpret_cast<uint2 *>(block + o_rec);
+  uint32_t *d_rec = reinterpret_cast<uint32_t *>(block + o_rec);
   uint16_t *d_sd = reinterpret_cast<uint16_t *>(block + o_sd);
   uint8_t *d_sl = reinterpret_cast<uint8_t *>(block + o_sl);
+  uint16_t *d_xd = reinterpret_cast<uint16_t *>(block + o_xd);
+  uint8_t *d_xl = reinterpret_cast<uint8_t *>(block + o_xl);
   JobInfo *d_info = reinterpret_cast<JobInfo *>(block + o_info);
   unsigned long long *d_goff = reinterpret_cast<unsigned long long *>(block + o_goff);
 
@@ -332,9 +549,11 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
   SPZ_HIP_TRY(hipMemcpyAsync(d_data, h_data, upload, hipMemcpyHostToDevice, st));
   if (upload < data_bytes) SPZ_HIP_TRY(hipMemsetAsync(d_data + upload, 0, data_bytes - upload, st));
   SPZ_HIP_TRY(hipMemsetAsync(d_link, 0, pos_padded * sizeof(uint16_t), st));
-  SPZ_HIP_TRY(hipMemsetAsync(d_rec, 0, (size_t)(n_jobs + 1) * kRecordWindow * sizeof(uint2), st));
+  SPZ_HIP_TRY(hipMemsetAsync(d_rec, 0, ((size_t)n_jobs * kJobBytes + kRecordWindow) * sizeof(uint32_t), st));
   SPZ_HIP_TRY(hipMemsetAsync(d_info, 0, (size_t)(n_jobs + 1) * sizeof(JobInfo), st));
-  SPZ_HIP_TRY(hipMemcpyAsync(d_rec + (size_t)n_jobs * kRecordWindow, h_tail_rec, (size_t)kRecordWindow * sizeof(uint2),
+  std::vector<uint32_t> tail_states(kRecordWindow);
+  for (uint32_t k = 0; k < kRecordWindow; ++k) tail_states[k] = h_tail_rec[2 * k];
+  SPZ_HIP_TRY(hipMemcpyAsync(d_rec + (size_t)n_jobs * kJobBytes, tail_states.data(), (size_t)kRecordWindow * sizeof(uint32_t),
                              hipMemcpyHostToDevice, st));
   lap("upload");
   const uint32_t n_seg = (uint32_t)((n_pos + kLinkSegment - 1) / kLinkSegment);
@@ -345,30 +564,34 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
   SPZ_HIP_TRY(hipGetLastError());
   lap("matches");
   const uint32_t parse_blocks = (n_jobs + 63u) / 64u;
-  hipLaunchKernelGGL(lz_parse_kernel, dim3(parse_blocks), dim3(64), 0, st, 0, d_r128, d_r32, (uint32_t)tail_begin, n_jobs, d_rec,
-                     d_sd, d_sl, d_info);
+  hipLaunchKernelGGL(lz_parse_kernel, dim3(parse_blocks), dim3(64), 0, st, d_r128, d_r32, n_jobs, d_rec, d_sd,
+                     d_sl, d_info);
   SPZ_HIP_TRY(hipGetLastError());
-  lap("records");
-  hipLaunchKernelGGL(lz_parse_kernel, dim3(parse_blocks), dim3(64), 0, st, 1, d_r128, d_r32, (uint32_t)tail_begin, n_jobs, d_rec,
-                     d_sd, d_sl, d_info);
+  lap("parse");
+  hipLaunchKernelGGL(lz_stitch_kernel, dim3(parse_blocks), dim3(64), 0, st, d_r128, d_r32, n_jobs, d_rec, d_xd,
+                     d_xl, d_info);
   SPZ_HIP_TRY(hipGetLastError());
   std::vector<JobInfo> info(n_jobs + 1);
   SPZ_HIP_TRY(hipMemcpyAsync(info.data(), d_info, info.size() * sizeof(JobInfo), hipMemcpyDeviceToHost, st));
   SPZ_HIP_TRY(hipStreamSynchronize(st));
-  lap("parse");
+  lap("stitch");
   std::vector<unsigned long long> goff(n_jobs);
   unsigned long long total_syms = 0;
   for (uint32_t j = 0; j < n_jobs; ++j) {
-    if (!info[j].spliced || info[j].hi < info[j].lo) return SPZ_AMD_ERR_UNSUPPORTED;  // no meeting point: host parse
+    if (!info[j].spliced || info[j].n < info[j].lo) return SPZ_AMD_ERR_UNSUPPORTED;  // no meeting point: host parse
     goff[j] = total_syms;
-    total_syms += info[j].hi - info[j].lo;
+    total_syms += info[j].n - info[j].lo + info[j].extra;
   }
   if (total_syms > n_pos) return SPZ_AMD_ERR_UNSUPPORTED;
+  {  // the last job met the host's tail parse: the host's own symbol count at that loop top must be the one counted here
+    const uint32_t k = info[n_jobs - 1].end_s - (uint32_t)tail_begin;
+    if (k >= kRecordWindow || h_tail_rec[2 * k + 1] != info[n_jobs].lo) return SPZ_AMD_ERR_UNSUPPORTED;
+  }
   SPZ_HIP_TRY(hipMemcpyAsync(d_goff, goff.data(), goff.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
   // the tables are done with: their memory takes the dense arrays (2 B and 1 B per symbol, at most one symbol per position)
   uint16_t *dense_dist = reinterpret_cast<uint16_t *>(d_r128);
   uint8_t *dense_lc = reinterpret_cast<uint8_t *>(d_r32);
-  hipLaunchKernelGGL(lz_compact_kernel, dim3(n_jobs), dim3(256), 0, st, d_sd, d_sl, d_info, d_goff, dense_dist, dense_lc);
+  hipLaunchKernelGGL(lz_compact_kernel, dim3(n_jobs), dim3(256), 0, st, d_sd, d_sl, d_xd, d_xl, d_info, d_goff, dense_dist, dense_lc);
   SPZ_HIP_TRY(hipGetLastError());
   SPZ_HIP_TRY(hipStreamSynchronize(st));
   lap("compact");
@@ -380,6 +603,15 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
   c->dense_dist = dense_dist;
   c->dense_lc = dense_lc;
   c->num_symbols = total_syms;
+  c->capacity = std::min<uint64_t>(pos_padded * sizeof(uint32_t) / sizeof(uint16_t), pos_padded * sizeof(uint32_t));
+  c->data = d_data;
+  c->size = size;
+  c->scratch_a = block + o_rec;   // the deflate body
+  c->scratch_a_bytes = ((size_t)n_jobs * kJobBytes + kRecordWindow) * sizeof(uint32_t);
+  c->scratch_b = block + o_sd;    // codes, block descriptors, header words
+  c->scratch_b_bytes = o_xd - o_sd;
+  c->scratch_c = block + o_xd;    // frequencies, per-block counters, static tables
+  c->scratch_c_bytes = o_info - o_xd;
   *ctx = c;
   *num_symbols = total_syms;
   *tail_first_symbol = info[n_jobs].lo;
@@ -405,6 +637,120 @@ void spz_amd_zlib_parse_close(void *ctx) {
   DeviceGuard guard;
   if (guard.enter(c->device) == SPZ_AMD_OK && c->block) (void)hipFree(c->block);
   delete c;
+}
+
+int spz_amd_zlib_parse_append(void *ctx, const uint16_t *h_dist, const uint8_t *h_lc, uint64_t n) {
+  LzContext *c = static_cast<LzContext *>(ctx);
+  if (c == nullptr || (n > 0 && (h_dist == nullptr || h_lc == nullptr))) return SPZ_AMD_ERR_INVALID_ARG;
+  if (c->num_symbols + n > c->capacity) return SPZ_AMD_ERR_CAPACITY;
+  if (n == 0) return SPZ_AMD_OK;
+  DeviceGuard guard;
+  int rc = guard.enter(c->device);
+  if (rc != SPZ_AMD_OK) return rc;
+  SPZ_HIP_TRY(hipMemcpyAsync(c->dense_dist + c->num_symbols, h_dist, n * sizeof(uint16_t), hipMemcpyHostToDevice, nullptr));
+  SPZ_HIP_TRY(hipMemcpyAsync(c->dense_lc + c->num_symbols, h_lc, n, hipMemcpyHostToDevice, nullptr));
+  SPZ_HIP_TRY(hipStreamSynchronize(nullptr));
+  c->num_symbols += n;
+  return SPZ_AMD_OK;
+}
+
+int spz_amd_zlib_block_stats(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols, uint32_t num_blocks,
+                             uint16_t *h_lfreq, uint16_t *h_dfreq, uint32_t *h_bytes, uint32_t *h_last_len) {
+  LzContext *c = static_cast<LzContext *>(ctx);
+  if (c == nullptr || tables == nullptr || block_symbols == 0 || num_blocks == 0 || h_lfreq == nullptr ||
+      h_dfreq == nullptr || h_bytes == nullptr || h_last_len == nullptr) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  if ((uint64_t)num_blocks * block_symbols < c->num_symbols) return SPZ_AMD_ERR_INVALID_ARG;
+  DeviceGuard guard;
+  int rc = guard.enter(c->device);
+  if (rc != SPZ_AMD_OK) return rc;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    const size_t at = off;
+    off += round_up(bytes, 256);
+    return c->scratch_c + at;
+  };
+  spz_amd_deflate_static *d_tables = reinterpret_cast<spz_amd_deflate_static *>(carve(sizeof(spz_amd_deflate_static)));
+  uint16_t *d_lfreq = reinterpret_cast<uint16_t *>(carve((size_t)num_blocks * 286 * sizeof(uint16_t)));
+  uint16_t *d_dfreq = reinterpret_cast<uint16_t *>(carve((size_t)num_blocks * 30 * sizeof(uint16_t)));
+  uint32_t *d_bytes = reinterpret_cast<uint32_t *>(carve((size_t)num_blocks * sizeof(uint32_t)));
+  uint32_t *d_last = reinterpret_cast<uint32_t *>(carve((size_t)num_blocks * sizeof(uint32_t)));
+  if (off > c->scratch_c_bytes) return SPZ_AMD_ERR_CAPACITY;
+  hipStream_t st = nullptr;
+  SPZ_HIP_TRY(hipMemcpyAsync(d_tables, tables, sizeof(*tables), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(lz_block_stats_kernel, dim3(num_blocks), dim3(256), 0, st, c->dense_dist, c->dense_lc,
+                     (unsigned long long)c->num_symbols, block_symbols, d_tables, d_lfreq, d_dfreq, d_bytes, d_last);
+  SPZ_HIP_TRY(hipGetLastError());
+  SPZ_HIP_TRY(hipMemcpyAsync(h_lfreq, d_lfreq, (size_t)num_blocks * 286 * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
+  SPZ_HIP_TRY(hipMemcpyAsync(h_dfreq, d_dfreq, (size_t)num_blocks * 30 * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
+  SPZ_HIP_TRY(hipMemcpyAsync(h_bytes, d_bytes, (size_t)num_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  SPZ_HIP_TRY(hipMemcpyAsync(h_last_len, d_last, (size_t)num_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  SPZ_HIP_TRY(hipStreamSynchronize(st));
+  return SPZ_AMD_OK;
+}
+
+int spz_amd_zlib_encode_blocks(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols, uint32_t num_blocks,
+                               const spz_amd_deflate_block *h_blocks, const spz_amd_deflate_codes *h_codes,
+                               const uint32_t *h_header_words, uint64_t num_header_words, uint64_t body_bytes,
+                               uint8_t *h_body, uint64_t *h_symbol_bits) {
+  LzContext *c = static_cast<LzContext *>(ctx);
+  if (c == nullptr || tables == nullptr || block_symbols == 0 || num_blocks == 0 || h_blocks == nullptr ||
+      h_codes == nullptr || (num_header_words > 0 && h_header_words == nullptr) || h_body == nullptr ||
+      h_symbol_bits == nullptr) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  if ((uint64_t)num_blocks * block_symbols < c->num_symbols) return SPZ_AMD_ERR_INVALID_ARG;
+  const size_t body_words = (size_t)((body_bytes + 3) / 4) + 2;
+  if (body_words * 4 > c->scratch_a_bytes) return SPZ_AMD_ERR_CAPACITY;
+  for (uint32_t b = 0; b < num_blocks; ++b) {  // nothing the kernel writes may leave the body
+    const spz_amd_deflate_block &k = h_blocks[b];
+    if ((uint64_t)k.header_word_begin + k.header_words > num_header_words || (k.bit_start >> 5) + k.header_words > body_words ||
+        (k.choice == 0 && (((k.bit_start + k.header_bits) & 7) != 0 || ((k.bit_start + k.header_bits) >> 3) + k.input_bytes > body_bytes ||
+                           (uint64_t)k.input_begin + k.input_bytes > c->size))) {
+      return SPZ_AMD_ERR_INVALID_ARG;
+    }
+  }
+  DeviceGuard guard;
+  int rc = guard.enter(c->device);
+  if (rc != SPZ_AMD_OK) return rc;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    const size_t at = off;
+    off += round_up(bytes, 256);
+    return c->scratch_b + at;
+  };
+  spz_amd_deflate_static *d_tables = reinterpret_cast<spz_amd_deflate_static *>(carve(sizeof(spz_amd_deflate_static)));
+  spz_amd_deflate_block *d_blocks = reinterpret_cast<spz_amd_deflate_block *>(carve((size_t)num_blocks * sizeof(spz_amd_deflate_block)));
+  spz_amd_deflate_codes *d_codes = reinterpret_cast<spz_amd_deflate_codes *>(carve((size_t)num_blocks * sizeof(spz_amd_deflate_codes)));
+  uint32_t *d_header = reinterpret_cast<uint32_t *>(carve((size_t)(num_header_words + 1) * sizeof(uint32_t)));
+  unsigned long long *d_bits = reinterpret_cast<unsigned long long *>(carve((size_t)num_blocks * sizeof(unsigned long long)));
+  if (off > c->scratch_b_bytes) return SPZ_AMD_ERR_CAPACITY;
+  uint32_t *d_body = reinterpret_cast<uint32_t *>(c->scratch_a);
+  hipStream_t st = nullptr;
+  static const bool timing = std::getenv("SPZ_AMD_LZ_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  SPZ_HIP_TRY(hipMemsetAsync(d_body, 0, body_words * 4, st));
+  SPZ_HIP_TRY(hipMemcpyAsync(d_tables, tables, sizeof(*tables), hipMemcpyHostToDevice, st));
+  SPZ_HIP_TRY(hipMemcpyAsync(d_blocks, h_blocks, (size_t)num_blocks * sizeof(spz_amd_deflate_block), hipMemcpyHostToDevice, st));
+  SPZ_HIP_TRY(hipMemcpyAsync(d_codes, h_codes, (size_t)num_blocks * sizeof(spz_amd_deflate_codes), hipMemcpyHostToDevice, st));
+  if (num_header_words) {
+    SPZ_HIP_TRY(hipMemcpyAsync(d_header, h_header_words, (size_t)num_header_words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  }
+  hipLaunchKernelGGL(lz_encode_kernel, dim3(num_blocks), dim3(kEncodeThreads), 0, st, c->dense_dist, c->dense_lc,
+                     (unsigned long long)c->num_symbols, block_symbols, c->data, d_tables, d_blocks, d_codes, d_header, d_body, d_bits);
+  SPZ_HIP_TRY(hipGetLastError());
+  if (timing) {
+    (void)hipStreamSynchronize(st);
+    std::fprintf(stderr, "[lz77] encode     %.4f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  }
+  SPZ_HIP_TRY(hipMemcpyAsync(h_body, d_body, body_bytes, hipMemcpyDeviceToHost, st));
+  SPZ_HIP_TRY(hipMemcpyAsync(h_symbol_bits, d_bits, (size_t)num_blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  SPZ_HIP_TRY(hipStreamSynchronize(st));
+  if (timing) {
+    std::fprintf(stderr, "[lz77] + download %.4f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  }
+  return SPZ_AMD_OK;
 }
 
 }  // extern "C"

@@ -37,15 +37,20 @@ constexpr uint32_t MIN_MATCH = 3, MAX_MATCH = 258, MIN_LOOKAHEAD = MAX_MATCH + M
 constexpr uint32_t MAX_DIST = W - MIN_LOOKAHEAD, TOO_FAR = 4096;
 constexpr uint32_t GOOD_MATCH = 8, MAX_LAZY = 16, NICE_MATCH = 128, MAX_CHAIN = 128, SHORT_CHAIN = MAX_CHAIN >> 2;
 
-// Geometry of the data-parallel parse.  A job is kJobBytes of input; job j+1 first parses its first
-// kRecordWindow positions and records its lazy state at every loop top, job j then runs until its own state at a
-// position inside that window equals the recorded one (declined when that does not happen: the caller parses
-// on the host instead).
-constexpr uint32_t kJobBytes = 2 * W;
-constexpr uint32_t kRecordWindow = 8192;
-constexpr uint32_t kJobSymbolStride = kJobBytes + kRecordWindow + MAX_MATCH + 6;  // symbols a job can emit, rounded up
+// Geometry of the data-parallel parse.  A job is kJobBytes of input: it runs deflate_slow's loop from its first
+// position (lazy state reset) to the first loop top at or past its end, and records its lazy state at every
+// loop top (one word per input position).  A second, short step continues each job into its successor's range
+// until its state at a loop top equals the one the successor recorded there — from that position on the two
+// parses are the same parse, so the successor's symbols take over (spz_deflate.cpp's splice; how many symbols
+// the successor had emitted by then is counted by running its parse up to that position once more).  The
+// meeting point is usually a few positions in, a few thousand after long runs; none inside the successor's
+// range: declined, the caller parses on the host instead.
+constexpr uint32_t kJobBytes = W / 2;
+constexpr uint32_t kRecordWindow = kJobBytes;
+constexpr uint32_t kJobSymbolStride = kJobBytes + 8;        // at most one symbol per position
+constexpr uint32_t kStitchSymbolStride = kRecordWindow + 8;
 // Positions past the last job's end that the tables must cover (loop tops of that job inside its successor's
-// record window, plus one match), and the bytes past a position that a match compare may read.
+// range, plus one match), and the bytes past a position that a match compare may read.
 constexpr uint32_t kTableSlack = kRecordWindow + MAX_MATCH + 6;
 constexpr uint32_t kReadAhead = MAX_MATCH + 4;
 

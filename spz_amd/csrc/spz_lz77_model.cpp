@@ -3,6 +3,8 @@
 // suite prove that links -> match tables -> lazy state machine -> record-window splice reproduces zlib's
 // symbols before a GPU is involved (tests/test_exact_gzip.py); nothing in the product path calls it.
 #include <algorithm>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <vector>
 
@@ -49,59 +51,69 @@ struct ModelParser final : HeadParser {
     for (uint64_t p = 0; p < n_pos; ++p) {
       find_matches<int64_t>(dacc, lacc, static_cast<int64_t>(p), static_cast<int64_t>(base_at(p, size)), &r128[p], &r32[p]);
     }
-    // ---- stage 3: jobs; pass 0 records the first kRecordWindow loop tops of every job but the first
-    const uint64_t njobs = (tail_begin + kJobBytes - 1) / kJobBytes;
-    std::vector<uint32_t> rec((njobs + 1) * size_t(kRecordWindow) * 2, 0);  // {state, symcount}
-    std::memcpy(&rec[njobs * size_t(kRecordWindow) * 2], tail_rec, size_t(kRecordWindow) * 8);
+    // ---- stage 3: every job parses its own range and records its lazy state at every loop top
+    const uint64_t njobs = tail_begin / kJobBytes;  // tail_begin is a multiple of W = 2 jobs
+    std::vector<uint32_t> rec(tail_begin + kRecordWindow, 0);  // per position; the tail job's first loop tops at the end
+    for (uint32_t k = 0; k < kRecordWindow; ++k) rec[tail_begin + k] = tail_rec[2 * k];
     auto a128 = [&](uint64_t pos) { return r128[pos]; };
     auto a32 = [&](uint64_t pos) { return r32[pos]; };
-    for (uint64_t j = 1; j < njobs; ++j) {
-      const uint64_t begin = j * kJobBytes;
-      uint64_t s = begin;
-      LazyState<uint64_t> st;
-      uint32_t nsym = 0;
-      auto count = [&](uint32_t, uint32_t) { ++nsym; };
-      while (s - begin < kRecordWindow) {
-        uint32_t *r = &rec[(j * size_t(kRecordWindow) + (s - begin)) * 2];
-        r[0] = pack_state(st, s);
-        r[1] = nsym;
-        lazy_step(s, st, a128, a32, count);
-      }
-    }
-    // pass 1: every job emits until it meets its successor's record
-    std::vector<std::vector<uint16_t>> jd(njobs);
-    std::vector<std::vector<uint8_t>> jl(njobs);
-    std::vector<uint32_t> lo(njobs + 1, 0), hi(njobs, 0);
+    std::vector<std::vector<uint16_t>> jd(njobs), xd(njobs);
+    std::vector<std::vector<uint8_t>> jl(njobs), xl(njobs);
+    std::vector<uint64_t> end_s(njobs);
+    std::vector<LazyState<uint64_t>> end_st(njobs);
     for (uint64_t j = 0; j < njobs; ++j) {
-      const uint64_t begin = j * kJobBytes, next = std::min<uint64_t>(begin + kJobBytes, tail_begin);
+      const uint64_t begin = j * kJobBytes, next = begin + kJobBytes;
       uint64_t s = begin;
       LazyState<uint64_t> st;
       auto emit = [&](uint32_t d, uint32_t l) {
         jd[j].push_back(static_cast<uint16_t>(d));
         jl[j].push_back(static_cast<uint8_t>(l));
       };
+      while (s < next) {
+        rec[s] = pack_state(st, s);
+        lazy_step(s, st, a128, a32, emit);
+      }
+      if (jl[j].size() > kJobSymbolStride) return false;
+      end_s[j] = s;
+      end_st[j] = st;
+    }
+    // ---- stitch: every job continues into its successor's range until the states agree
+    std::vector<uint32_t> lo(njobs + 1, 0);
+    for (uint64_t j = 0; j < njobs; ++j) {
+      const uint64_t next = (j + 1) * kJobBytes;
+      uint64_t s = end_s[j];
+      LazyState<uint64_t> st = end_st[j];
+      auto emit = [&](uint32_t d, uint32_t l) {
+        xd[j].push_back(static_cast<uint16_t>(d));
+        xl[j].push_back(static_cast<uint8_t>(l));
+      };
       bool spliced = false;
-      for (;;) {
-        if (s >= next) {
-          if (s - next >= kRecordWindow) break;
-          const uint32_t *r = &rec[((j + 1) * size_t(kRecordWindow) + (s - next)) * 2];
-          if (r[0] == pack_state(st, s)) {
-            hi[j] = static_cast<uint32_t>(jl[j].size());
-            lo[j + 1] = r[1];
-            spliced = true;
-            break;
-          }
+      while (s - next < kRecordWindow) {
+        if (rec[s] == pack_state(st, s)) {
+          // symbols the successor's own parse had emitted before this loop top
+          uint64_t s2 = next;
+          LazyState<uint64_t> st2;
+          uint32_t cnt = 0;
+          auto count = [&](uint32_t, uint32_t) { ++cnt; };
+          while (s2 < s) lazy_step(s2, st2, a128, a32, count);
+          if (s2 != s) return false;
+          lo[j + 1] = cnt;
+          spliced = true;
+          break;
         }
         lazy_step(s, st, a128, a32, emit);
-        if (jl[j].size() > kJobSymbolStride) return false;
       }
-      if (!spliced || hi[j] < lo[j]) return false;
+      if (!spliced) return false;
+      if (j + 1 == njobs && tail_rec[2 * (s - next) + 1] != lo[njobs]) return false;  // the host's own count
     }
     dist.clear();
     lc.clear();
     for (uint64_t j = 0; j < njobs; ++j) {
-      dist.insert(dist.end(), jd[j].begin() + lo[j], jd[j].begin() + hi[j]);
-      lc.insert(lc.end(), jl[j].begin() + lo[j], jl[j].begin() + hi[j]);
+      if (lo[j] > jl[j].size()) return false;
+      dist.insert(dist.end(), jd[j].begin() + lo[j], jd[j].end());
+      lc.insert(lc.end(), jl[j].begin() + lo[j], jl[j].end());
+      dist.insert(dist.end(), xd[j].begin(), xd[j].end());
+      lc.insert(lc.end(), xl[j].begin(), xl[j].end());
     }
     *num_symbols = lc.size();
     *tail_first_symbol = lo[njobs];

@@ -20,15 +20,20 @@ def force_device_parse():
     old = os.environ.get("SPZ_AMD_GZIP_DEVICE")
     os.environ["SPZ_AMD_GZIP_DEVICE"] = "1"
     yield
+    os.environ.pop("SPZ_AMD_GZIP_DEVICE_HUFFMAN", None)
     if old is None:
         os.environ.pop("SPZ_AMD_GZIP_DEVICE", None)
     else:
         os.environ["SPZ_AMD_GZIP_DEVICE"] = old
 
 
+@pytest.mark.parametrize("huffman", ["1", "0"])
 @pytest.mark.parametrize("kind", ["nibbles", "bytes", "words", "runs", "sh_like"])
-def test_device_parse_bytes_equal_zlib(kind):
-    """Sizes around the job (64 KiB), tile (16 KiB) and link-segment (512 KiB) boundaries of the kernels."""
+def test_device_parse_bytes_equal_zlib(kind, huffman):
+    """Sizes around the job (16 KiB), tile (16 KiB), block (32767 symbols) and link-segment (512 KiB) boundaries
+    of the kernels; with the Huffman stage on the device too (stored blocks: "bytes"; static and dynamic: the
+    rest) and with only the parse there."""
+    os.environ["SPZ_AMD_GZIP_DEVICE_HUFFMAN"] = huffman
     rng = np.random.default_rng(sum(kind.encode()) + 1)
     for n in ((1 << 20), (1 << 20) + 1, 1_300_001, (1 << 21) + 32768, 3_000_017):
         data = make(kind, n, rng)

@@ -28,10 +28,11 @@ def main():
     out = {"points": n, "stream_bytes": len(raw), "usable_cpus": spz._effective_cpu_count()}
     os.environ["SPZ_AMD_LZ_TIMING"] = "1"
     os.environ["SPZ_AMD_EXACT_GZIP_TIMING"] = "1"
-    for mode in ("1", "0"):
-        os.environ["SPZ_AMD_GZIP_DEVICE"] = mode
+    for mode in ("1", "parse_only", "0"):
+        os.environ["SPZ_AMD_GZIP_DEVICE"] = "0" if mode == "0" else "1"
+        os.environ["SPZ_AMD_GZIP_DEVICE_HUFFMAN"] = "0" if mode == "parse_only" else "1"
         best = None
-        for r in range(reps if mode == "1" else 1):
+        for r in range(reps if mode != "0" else 1):
             before = spz._device_gzip_parse_count()
             t = time.perf_counter()
             m = spz._compress_gzipped(raw)
@@ -39,13 +40,14 @@ def main():
             best = dt if best is None else min(best, dt)
             used = spz._device_gzip_parse_count() - before
             print(f"[bench] device={mode} run {r}: {dt:.3f} s, device parses {used}", file=sys.stderr, flush=True)
-        key = "device_parse" if mode == "1" else "host_threads"
+        key = {"1": "device_parse_and_huffman", "parse_only": "device_parse", "0": "host_threads"}[mode]
         out[key + "_s"] = round(best, 4)
         out[key + "_member_sha256_16"] = hashlib.sha256(m).hexdigest()[:16]
         out[key + "_member_bytes"] = len(m)
         if mode == "1":
             out["device_parse_used"] = bool(used)
-    out["members_identical"] = out["device_parse_member_sha256_16"] == out["host_threads_member_sha256_16"]
+    out["members_identical"] = (out["device_parse_member_sha256_16"] == out["host_threads_member_sha256_16"] ==
+                                out["device_parse_and_huffman_member_sha256_16"])
     print(json.dumps(out))
 
 
