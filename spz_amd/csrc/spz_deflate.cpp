@@ -1056,7 +1056,7 @@ bool compressWithHeadParser(const uint8_t *data, size_t size, int threads, HeadP
 
   uint64_t nhead = 0;
   uint32_t tail_first = 0;
-  const uint32_t n_rec = static_cast<uint32_t>(std::min<size_t>(tj.rec_succ.size(), spz_lz::kRecordWindow));
+  const uint32_t n_rec = static_cast<uint32_t>(std::min<size_t>(tj.rec_succ.size(), spz_lz::kTailWindow));
   if (!parser.parse(data, size, tail_begin, reinterpret_cast<const uint32_t *>(tj.rec_succ.data()), n_rec, &nhead,
                     &tail_first)) {
     return false;

@@ -7,15 +7,13 @@
 // the parse state only through a threshold, and the lazy state machine over the resulting tables is O(1) per
 // position.  One kernel per stage:
 //
-//   lz_links_kernel   one workgroup per 512 KiB of input (+32 KiB warm-up): zlib's head[] as 65536 16-bit
-//                     entries in LDS (128 KiB), 512 positions per round; each wave finds the equal hashes among its
-//                     64 positions with a readlane/ballot loop, then the eight waves take the table in position order.
-//                     Entries older than 32 KiB are retired by a sweep every 8192 positions, which is what keeps
-//                     16-bit positions unambiguous.  Output: link[p], 2 B per input byte.
-//   lz_match_kernel   one workgroup per 16 KiB of positions: the 48 KiB of input those positions can reach and
-//                     their 96 KiB of links are staged in LDS (144 KiB of the CU's 160), every thread walks the
-//                     chains of 16 positions exactly like longest_match does — all reads are LDS reads — and
-//                     writes the two results per position (chain budget 128 and 32).
+//   lz_table_kernel   (twice) one workgroup per 512 KiB of input: a 65536-entry table in LDS gives every position the
+//                     distance to the previous position with the same well-mixed hash of its three bytes (link[])
+//                     and its running count among the positions with the same zlib hash (rank[]).
+//   lz_match_kernel   one workgroup per 4 KiB of positions, their reach of links and ranks in LDS (144 KiB): every
+//                     thread walks link[] — positions with the same three bytes, where zlib's own chain of 128 is
+//                     mostly strangers for .spz data — and knows from two ranks how far along zlib's chain a
+//                     candidate is; it writes the two results per position (chain budget 128 and 32).
 //   lz_parse_kernel   one lane per 16 KiB job: deflate_slow's loop with the table lookup in place of the search
 //                     (each lane keeps the 32 entries around its position in LDS: one HBM latency per 32 positions),
 //                     recording the lazy state at every loop top (one word per input position).
@@ -25,7 +23,7 @@
 //
 // The last 64-96 KiB of the input (where zlib's lookahead runs out and its window's stale bytes matter) are
 // parsed by spz_deflate.cpp's serial job on the host; its records arrive here as the last job's successor.
-// HBM per input byte: 1 (input) + 2 (links) + 8 (tables) + 4 (records) + 6 (job and stitch symbols); the dense symbol
+// HBM per input byte: 1 (input) + 4.1 (links, ranks) + 8 (tables) + 4 (records) + 6 (job and stitch symbols); the dense symbol
 // arrays reuse the tables' memory.
 #include <hip/hip_runtime.h>
 
@@ -46,32 +44,45 @@ namespace {
 
 using namespace spz_lz;
 
-// ---- stage 1: links ------------------------------------------------------------------------------------
+// ---- stage 1: chains -------------------------------------------------------------------------------------
+// One table of 65536 16-bit entries in LDS (128 KiB), one workgroup per 512 KiB of input (+32 KiB warm-up), 512
+// positions per round: each wave finds the equal keys among its 64 positions with a readlane/ballot loop, then
+// the eight waves take the table in position order.
+//   LINK: key = hash2, entry = low 16 bits of the newest position; out = distance to it (0: none within 32 KiB).
+//         Entries older than 32 KiB are retired by a sweep every 8192 positions, which keeps 16-bit positions
+//         unambiguous.
+//   RANK: key = zlib's hash, entry = positions seen so far (mod 2^16); out = that count, into the segment's own
+//         slab [s0 - 32 KiB, s1): ranks are compared only along one walk, which never leaves such a range.
 constexpr uint32_t kLinkThreads = 512, kLinkSegment = 1u << 19, kSweepEvery = 8192, kRetiredAge = 40000;
+constexpr uint32_t kRankSlab = W + kLinkSegment;
+enum TableMode { TABLE_LINK = 0, TABLE_RANK = 1 };
 
-__global__ __launch_bounds__(512) void lz_links_kernel(const uint8_t *__restrict__ d, uint64_t n_pos,
-                                                       uint16_t *__restrict__ link) {
-  __shared__ uint16_t head[HASH_MASK + 1];  // low 16 bits of the newest position per hash
+template <int MODE>
+__global__ __launch_bounds__(512) void lz_table_kernel(const uint8_t *__restrict__ d, uint64_t n_pos,
+                                                       uint16_t *__restrict__ out) {
+  __shared__ uint16_t table[HASH_MASK + 1];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint64_t s0 = (uint64_t)blockIdx.x * kLinkSegment;
   const uint64_t s1 = (s0 + kLinkSegment < n_pos) ? s0 + kLinkSegment : n_pos;
-  const uint64_t start = s0 >= W ? s0 - W : 0;  // the chains of the first positions reach 32 KiB back
-  for (uint32_t i = tid; i <= HASH_MASK; i += kLinkThreads) head[i] = (uint16_t)((uint32_t)start - kRetiredAge);
+  const uint64_t start = s0 >= W ? s0 - W : 0;  // the walks of the first positions reach 32 KiB back
+  const uint16_t fresh = MODE == TABLE_LINK ? (uint16_t)((uint32_t)start - kRetiredAge) : (uint16_t)0;
+  for (uint32_t i = tid; i <= HASH_MASK; i += kLinkThreads) table[i] = fresh;
   __syncthreads();
+  uint16_t *slab = out + (size_t)blockIdx.x * kRankSlab;  // RANK: entry i is position s0 - W + i
   for (uint64_t P = start; P < s1; P += kLinkThreads) {
-    if (P != start && ((P - start) & (kSweepEvery - 1)) == 0) {
+    if (MODE == TABLE_LINK && P != start && ((P - start) & (kSweepEvery - 1)) == 0) {
       // retire what no later position can reach: an entry never gets 65536 positions old
       for (uint32_t i = tid; i <= HASH_MASK; i += kLinkThreads) {
-        const uint16_t age = (uint16_t)((uint32_t)P - head[i]);
-        if (age >= W) head[i] = (uint16_t)((uint32_t)P - kRetiredAge);
+        const uint16_t age = (uint16_t)((uint32_t)P - table[i]);
+        if (age >= W) table[i] = (uint16_t)((uint32_t)P - kRetiredAge);
       }
       __syncthreads();
     }
     const uint64_t p = P + tid;
     const bool valid = p < s1;
-    uint32_t h = 0x10000u + lane;  // a hash of its own: equal to nobody's
-    if (valid) h = hash3(d[p], d[p + 1], d[p + 2]);
-    // lanes of this wave with the same hash
+    uint32_t h = 0x10000u + lane;  // a key of its own: equal to nobody's
+    if (valid) h = MODE == TABLE_LINK ? hash2(d[p], d[p + 1], d[p + 2]) : hash3(d[p], d[p + 1], d[p + 2]);
+    // lanes of this wave with the same key
     unsigned long long cls = 0;
 #pragma unroll
     for (int j = 0; j < 64; ++j) {
@@ -84,15 +95,21 @@ __global__ __launch_bounds__(512) void lz_links_kernel(const uint8_t *__restrict
     const bool newest = (cls >> lane) == 1ull;
     for (uint32_t turn = 0; turn < kLinkThreads / 64; ++turn) {
       if (wave == turn && valid) {
-        uint32_t g;
-        if (below != 0ull) {
-          g = lane - (63u - (uint32_t)__clzll((long long)below));
+        if (MODE == TABLE_LINK) {
+          uint32_t g;
+          if (below != 0ull) {
+            g = lane - (63u - (uint32_t)__clzll((long long)below));
+          } else {
+            const uint16_t age = (uint16_t)((uint32_t)p - table[h]);
+            g = age < W ? age : 0u;
+          }
+          if (newest) table[h] = (uint16_t)p;
+          if (p >= s0) out[p] = (uint16_t)g;
         } else {
-          const uint16_t age = (uint16_t)((uint32_t)p - head[h]);
-          g = age < W ? age : 0u;
+          const uint32_t r = (uint32_t)table[h] + (uint32_t)__popcll(below);
+          if (newest) table[h] = (uint16_t)(r + 1u);
+          slab[p + W - s0] = (uint16_t)r;
         }
-        if (newest) head[h] = (uint16_t)p;
-        if (p >= s0) link[p] = (uint16_t)g;
       }
       __syncthreads();
     }
@@ -100,44 +117,48 @@ __global__ __launch_bounds__(512) void lz_links_kernel(const uint8_t *__restrict
 }
 
 // ---- stage 2: match tables -----------------------------------------------------------------------------
-constexpr uint32_t kMatchTile = 16384, kMatchThreads = 1024;
-constexpr uint32_t kMatchDataDwords = (W + kMatchTile + kReadAhead + 3) / 4 + 2;
-constexpr uint32_t kMatchLinkDwords = (W + kMatchTile) / 2;
+// One workgroup per 4 KiB of positions: the links and ranks of the 36 KiB of positions those can reach are staged
+// in LDS (144 KiB of the CU's 160); the input bytes themselves are read through the vector cache (a walk looks
+// at them only where it stops).  (Input bytes in LDS instead of the ranks, with the ranks reduced to one byte of
+// chain steps per link, measured 10 % slower all told: profiles/r02_gzip_device_laps.txt.)
+constexpr uint32_t kMatchTile = 4096, kMatchThreads = 1024;
+constexpr uint32_t kMatchWindowDwords = (W + kMatchTile) / 2;
 
-struct LdsData {
-  const uint32_t *s;
-  __device__ __forceinline__ uint32_t load4(int32_t pos) const {  // pos: bytes from the window's origin
-    const uint32_t off = (uint32_t)pos;
-    const uint32_t a = s[off >> 2], b = s[(off >> 2) + 1];
-    return __builtin_amdgcn_alignbyte(b, a, off & 3u);
+struct WindowData {
+  const uint8_t *d;   // the input
+  long long origin;   // absolute position of window position 0
+  __device__ __forceinline__ uint32_t load4(int32_t pos) const {
+    uint32_t v;
+    __builtin_memcpy(&v, d + (origin + pos), 4);  // one unaligned dword load
+    return v;
   }
 };
-struct LdsLink {
+struct WindowU16 {
   const uint16_t *s;
   __device__ __forceinline__ uint32_t operator()(int32_t pos) const { return s[(uint32_t)pos]; }
 };
 
 __global__ __launch_bounds__(1024) void lz_match_kernel(const uint8_t *__restrict__ d, const uint16_t *__restrict__ link,
-                                                        uint64_t n_pos, uint64_t size, uint32_t *__restrict__ r128,
-                                                        uint32_t *__restrict__ r32) {
-  __shared__ uint32_t s_data[kMatchDataDwords];
-  __shared__ uint32_t s_link[kMatchLinkDwords];
+                                                        const uint16_t *__restrict__ rank_slabs, uint64_t n_pos, uint64_t size,
+                                                        uint32_t *__restrict__ r128, uint32_t *__restrict__ r32) {
+  __shared__ uint32_t s_link[kMatchWindowDwords];
+  __shared__ uint32_t s_rank[kMatchWindowDwords];
   const uint32_t tid = threadIdx.x;
   const uint64_t t0 = (uint64_t)blockIdx.x * kMatchTile;
-  const long long origin = (long long)t0 - (long long)W;  // a multiple of 16 KiB; window position 0
-  const uint32_t *d32 = reinterpret_cast<const uint32_t *>(d);
+  const long long origin = (long long)t0 - (long long)W;  // window position 0; a multiple of 4 KiB
+  const uint64_t seg = t0 / kLinkSegment;
   const uint32_t *l32 = reinterpret_cast<const uint32_t *>(link);
-  for (uint32_t i = tid; i < kMatchDataDwords; i += kMatchThreads) {
-    const long long pos = origin + 4ll * i;
-    s_data[i] = pos >= 0 ? d32[pos >> 2] : 0u;
-  }
-  for (uint32_t i = tid; i < kMatchLinkDwords; i += kMatchThreads) {
+  // the segment's slab starts at position seg * kLinkSegment - W: the window starts (t0 - seg * kLinkSegment) entries in
+  const uint32_t *k32 = reinterpret_cast<const uint32_t *>(rank_slabs + seg * kRankSlab + (t0 - seg * kLinkSegment));
+  for (uint32_t i = tid; i < kMatchWindowDwords; i += kMatchThreads) {
     const long long pos = origin + 2ll * i;
     s_link[i] = pos >= 0 ? l32[pos >> 1] : 0u;
+    s_rank[i] = k32[i];
   }
   __syncthreads();
-  const LdsData data = {s_data};
-  const LdsLink lk = {reinterpret_cast<const uint16_t *>(s_link)};
+  const WindowData data = {d, origin};
+  const WindowU16 lk = {reinterpret_cast<const uint16_t *>(s_link)};
+  const WindowU16 rk = {reinterpret_cast<const uint16_t *>(s_rank)};
   for (uint32_t it = 0; it < kMatchTile / kMatchThreads; ++it) {
     const uint32_t local = it * kMatchThreads + tid;
     const uint64_t p = t0 + local;
@@ -145,7 +166,7 @@ __global__ __launch_bounds__(1024) void lz_match_kernel(const uint8_t *__restric
       // the window base in window coordinates; a base below the window is out of every candidate's reach
       const long long b = (long long)base_at(p, size) - origin;
       uint32_t e128, e32;
-      find_matches<int32_t>(data, lk, (int32_t)(W + local), (int32_t)(b > 0 ? b : 0), &e128, &e32);
+      find_matches<int32_t>(data, lk, rk, (int32_t)(W + local), (int32_t)(b > 0 ? b : 0), &e128, &e32);
       r128[p] = e128;
       r32[p] = e32;
     }
@@ -191,18 +212,18 @@ struct EntryWindow {
 };
 
 __global__ __launch_bounds__(64) void lz_parse_kernel(const uint32_t *__restrict__ r128, const uint32_t *__restrict__ r32,
-                                                      uint32_t n_jobs, uint32_t *__restrict__ rec,
-                                                      uint16_t *__restrict__ sym_dist, uint8_t *__restrict__ sym_lc,
-                                                      JobInfo *__restrict__ info) {
+                                                      uint32_t job_bytes, uint32_t head_end, uint32_t n_jobs,
+                                                      uint32_t *__restrict__ rec, uint16_t *__restrict__ sym_dist,
+                                                      uint8_t *__restrict__ sym_lc, JobInfo *__restrict__ info) {
   __shared__ uint32_t s_win[kParseWindow * 64];
   const uint32_t lane = threadIdx.x;
   const uint32_t j = blockIdx.x * 64u + lane;
   if (j >= n_jobs) return;
-  const uint32_t begin = j * kJobBytes, next = begin + kJobBytes;
+  const uint32_t begin = j * job_bytes, next = begin + job_bytes < head_end ? begin + job_bytes : head_end;
   EntryWindow e128 = {s_win, r128, lane, 0xffffffffu};
   auto e32 = [&](uint32_t pos) { return r32[pos]; };
-  uint16_t *od = sym_dist + (size_t)j * kJobSymbolStride;
-  uint8_t *ol = sym_lc + (size_t)j * kJobSymbolStride;
+  uint16_t *od = sym_dist + (size_t)j * job_symbol_stride(job_bytes);
+  uint8_t *ol = sym_lc + (size_t)j * job_symbol_stride(job_bytes);
   uint32_t s = begin, nsym = 0;
   LazyState<uint32_t> st;
   auto emit = [&](uint32_t dist, uint32_t lc) {
@@ -224,16 +245,17 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint32_t *__restrict
 }
 
 __global__ __launch_bounds__(64) void lz_stitch_kernel(const uint32_t *__restrict__ r128, const uint32_t *__restrict__ r32,
-                                                       uint32_t n_jobs, const uint32_t *__restrict__ rec,
-                                                       uint16_t *__restrict__ x_dist, uint8_t *__restrict__ x_lc,
-                                                       JobInfo *__restrict__ info) {
+                                                       uint32_t job_bytes, uint32_t head_end, uint32_t n_jobs,
+                                                       const uint32_t *__restrict__ rec, uint16_t *__restrict__ x_dist,
+                                                       uint8_t *__restrict__ x_lc, JobInfo *__restrict__ info) {
   const uint32_t j = blockIdx.x * 64u + threadIdx.x;
   if (j >= n_jobs) return;
-  const uint32_t next = (j + 1) * kJobBytes;
+  const uint32_t next = (j + 1) * job_bytes < head_end ? (j + 1) * job_bytes : head_end;
+  const uint32_t stop = (uint32_t)stitch_end(j, n_jobs, job_bytes, head_end);
   auto e128 = [&](uint32_t pos) { return r128[pos]; };
   auto e32 = [&](uint32_t pos) { return r32[pos]; };
-  uint16_t *od = x_dist + (size_t)j * kStitchSymbolStride;
-  uint8_t *ol = x_lc + (size_t)j * kStitchSymbolStride;
+  uint16_t *od = x_dist + (size_t)j * job_symbol_stride(job_bytes);
+  uint8_t *ol = x_lc + (size_t)j * job_symbol_stride(job_bytes);
   uint32_t s = info[j].end_s, nsym = 0, spliced = 0;
   LazyState<uint32_t> st;
   st.match_available = info[j].end_available;
@@ -245,7 +267,7 @@ __global__ __launch_bounds__(64) void lz_stitch_kernel(const uint32_t *__restric
     ol[nsym] = (uint8_t)lc;
     ++nsym;
   };
-  while (s - next < kRecordWindow) {
+  while (s < stop) {
     if (rec[s] == pack_state(st, s)) {
       // symbols the successor's own parse had emitted before this loop top
       uint32_t s2 = next, cnt = 0;
@@ -269,12 +291,12 @@ __global__ __launch_bounds__(64) void lz_stitch_kernel(const uint32_t *__restric
 __global__ __launch_bounds__(256) void lz_compact_kernel(const uint16_t *__restrict__ sym_dist,
                                                          const uint8_t *__restrict__ sym_lc,
                                                          const uint16_t *__restrict__ x_dist, const uint8_t *__restrict__ x_lc,
-                                                         const JobInfo *__restrict__ info,
+                                                         const JobInfo *__restrict__ info, uint32_t job_bytes,
                                                          const unsigned long long *__restrict__ goff,
                                                          uint16_t *__restrict__ dense_dist, uint8_t *__restrict__ dense_lc) {
   const uint32_t j = blockIdx.x;
   const uint32_t lo = info[j].lo, n = info[j].n - lo, x = info[j].extra;
-  const size_t src = (size_t)j * kJobSymbolStride + lo, xsrc = (size_t)j * kStitchSymbolStride;
+  const size_t src = (size_t)j * job_symbol_stride(job_bytes) + lo, xsrc = (size_t)j * job_symbol_stride(job_bytes);
   const unsigned long long dst = goff[j];
   for (uint32_t i = threadIdx.x; i < n; i += 256) {
     dense_dist[dst + i] = sym_dist[src + i];
@@ -481,7 +503,7 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
     return SPZ_AMD_ERR_INVALID_ARG;
   }
   *ctx = nullptr;
-  if (tail_begin == 0 || tail_begin % W != 0 || n_rec < kRecordWindow || size >= (1ull << 32)) return SPZ_AMD_ERR_INVALID_ARG;
+  if (tail_begin == 0 || tail_begin % W != 0 || n_rec < kTailWindow || size >= (1ull << 32)) return SPZ_AMD_ERR_INVALID_ARG;
   const uint64_t n_pos = tail_begin + kTableSlack;  // positions the tables cover
   if (n_pos + kReadAhead + MIN_LOOKAHEAD > size) return SPZ_AMD_ERR_INVALID_ARG;
   DeviceGuard guard;
@@ -498,7 +520,7 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
     t_prev = now;
   };
 
-  const uint32_t n_jobs = (uint32_t)(tail_begin / kJobBytes);  // tail_begin is a multiple of W = 2 jobs
+  const uint32_t max_jobs = (uint32_t)(tail_begin / kSmallestJob);  // tail_begin is a multiple of W = 2 of them
   const uint32_t n_tiles = (uint32_t)((n_pos + kMatchTile - 1) / kMatchTile);
   const size_t pos_padded = (size_t)n_tiles * kMatchTile;
   // carve one allocation
@@ -510,16 +532,20 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
   };
   const size_t data_bytes = std::max<size_t>(pos_padded + kReadAhead + 64, round_up(size, 4) + 64);  // what the last tile stages; the whole input
   const size_t o_data = carve(data_bytes);
+  const uint32_t n_seg = (uint32_t)((n_pos + kLinkSegment - 1) / kLinkSegment);
   const size_t o_link = carve(pos_padded * sizeof(uint16_t));
+  const size_t o_rank = carve((size_t)n_seg * kRankSlab * sizeof(uint16_t));
   const size_t o_r128 = carve(pos_padded * sizeof(uint32_t));
   const size_t o_r32 = carve(pos_padded * sizeof(uint32_t));
-  const size_t o_rec = carve(((size_t)n_jobs * kJobBytes + kRecordWindow) * sizeof(uint32_t));
-  const size_t o_sd = carve((size_t)n_jobs * kJobSymbolStride * sizeof(uint16_t));
-  const size_t o_sl = carve((size_t)n_jobs * kJobSymbolStride);
-  const size_t o_xd = carve((size_t)n_jobs * kStitchSymbolStride * sizeof(uint16_t));
-  const size_t o_xl = carve((size_t)n_jobs * kStitchSymbolStride);
-  const size_t o_info = carve((size_t)(n_jobs + 1) * sizeof(JobInfo));
-  const size_t o_goff = carve((size_t)n_jobs * sizeof(unsigned long long));
+  const size_t rec_words = (size_t)tail_begin + kTailWindow;
+  const size_t o_rec = carve(rec_words * sizeof(uint32_t));
+  const size_t sym_entries = (size_t)max_jobs * job_symbol_stride(kSmallestJob);  // larger jobs need fewer
+  const size_t o_sd = carve(sym_entries * sizeof(uint16_t));
+  const size_t o_sl = carve(sym_entries);
+  const size_t o_xd = carve(sym_entries * sizeof(uint16_t));
+  const size_t o_xl = carve(sym_entries);
+  const size_t o_info = carve((size_t)(max_jobs + 1) * sizeof(JobInfo));
+  const size_t o_goff = carve((size_t)max_jobs * sizeof(unsigned long long));
   const size_t total = off;
   size_t free_b = 0, total_b = 0;
   SPZ_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -534,6 +560,7 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
   } holder{block};
   uint8_t *d_data = reinterpret_cast<uint8_t *>(block + o_data);
   uint16_t *d_link = reinterpret_cast<uint16_t *>(block + o_link);
+  uint16_t *d_rank = reinterpret_cast<uint16_t *>(block + o_rank);
   uint32_t *d_r128 = reinterpret_cast<uint32_t *>(block + o_r128);
   uint32_t *d_r32 = reinterpret_cast<uint32_t *>(block + o_r32);
   uint32_t *d_rec = reinterpret_cast<uint32_t *>(block + o_rec);
@@ -549,49 +576,67 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
   SPZ_HIP_TRY(hipMemcpyAsync(d_data, h_data, upload, hipMemcpyHostToDevice, st));
   if (upload < data_bytes) SPZ_HIP_TRY(hipMemsetAsync(d_data + upload, 0, data_bytes - upload, st));
   SPZ_HIP_TRY(hipMemsetAsync(d_link, 0, pos_padded * sizeof(uint16_t), st));
-  SPZ_HIP_TRY(hipMemsetAsync(d_rec, 0, ((size_t)n_jobs * kJobBytes + kRecordWindow) * sizeof(uint32_t), st));
-  SPZ_HIP_TRY(hipMemsetAsync(d_info, 0, (size_t)(n_jobs + 1) * sizeof(JobInfo), st));
-  std::vector<uint32_t> tail_states(kRecordWindow);
-  for (uint32_t k = 0; k < kRecordWindow; ++k) tail_states[k] = h_tail_rec[2 * k];
-  SPZ_HIP_TRY(hipMemcpyAsync(d_rec + (size_t)n_jobs * kJobBytes, tail_states.data(), (size_t)kRecordWindow * sizeof(uint32_t),
-                             hipMemcpyHostToDevice, st));
+  std::vector<uint32_t> tail_states(kTailWindow);
+  for (uint32_t k = 0; k < kTailWindow; ++k) tail_states[k] = h_tail_rec[2 * k];
   lap("upload");
-  const uint32_t n_seg = (uint32_t)((n_pos + kLinkSegment - 1) / kLinkSegment);
-  hipLaunchKernelGGL(lz_links_kernel, dim3(n_seg), dim3(kLinkThreads), 0, st, d_data, n_pos, d_link);
+  hipLaunchKernelGGL(lz_table_kernel<TABLE_LINK>, dim3(n_seg), dim3(kLinkThreads), 0, st, d_data, n_pos, d_link);
   SPZ_HIP_TRY(hipGetLastError());
   lap("links");
-  hipLaunchKernelGGL(lz_match_kernel, dim3(n_tiles), dim3(kMatchThreads), 0, st, d_data, d_link, n_pos, size, d_r128, d_r32);
+  hipLaunchKernelGGL(lz_table_kernel<TABLE_RANK>, dim3(n_seg), dim3(kLinkThreads), 0, st, d_data, n_pos, d_rank);
+  SPZ_HIP_TRY(hipGetLastError());
+  lap("ranks");
+  hipLaunchKernelGGL(lz_match_kernel, dim3(n_tiles), dim3(kMatchThreads), 0, st, d_data, d_link, d_rank, n_pos, size, d_r128, d_r32);
   SPZ_HIP_TRY(hipGetLastError());
   lap("matches");
-  const uint32_t parse_blocks = (n_jobs + 63u) / 64u;
-  hipLaunchKernelGGL(lz_parse_kernel, dim3(parse_blocks), dim3(64), 0, st, d_r128, d_r32, n_jobs, d_rec, d_sd,
-                     d_sl, d_info);
-  SPZ_HIP_TRY(hipGetLastError());
-  lap("parse");
-  hipLaunchKernelGGL(lz_stitch_kernel, dim3(parse_blocks), dim3(64), 0, st, d_r128, d_r32, n_jobs, d_rec, d_xd,
-                     d_xl, d_info);
-  SPZ_HIP_TRY(hipGetLastError());
-  std::vector<JobInfo> info(n_jobs + 1);
-  SPZ_HIP_TRY(hipMemcpyAsync(info.data(), d_info, info.size() * sizeof(JobInfo), hipMemcpyDeviceToHost, st));
-  SPZ_HIP_TRY(hipStreamSynchronize(st));
-  lap("stitch");
-  std::vector<unsigned long long> goff(n_jobs);
+  // stage 3, with larger jobs if two neighbours do not meet (the tables do not depend on the jobs)
+  uint32_t n_jobs = 0, job_bytes = 0;
+  std::vector<JobInfo> info;
+  std::vector<unsigned long long> goff;
   unsigned long long total_syms = 0;
-  for (uint32_t j = 0; j < n_jobs; ++j) {
-    if (!info[j].spliced || info[j].n < info[j].lo) return SPZ_AMD_ERR_UNSUPPORTED;  // no meeting point: host parse
-    goff[j] = total_syms;
-    total_syms += info[j].n - info[j].lo + info[j].extra;
+  bool met = false;
+  for (uint32_t attempt = 0; attempt < sizeof(kJobSizes) / sizeof(kJobSizes[0]) && !met; ++attempt) {
+    job_bytes = kJobSizes[attempt];
+    n_jobs = (uint32_t)((tail_begin + job_bytes - 1) / job_bytes);
+    SPZ_HIP_TRY(hipMemsetAsync(d_rec, 0, rec_words * sizeof(uint32_t), st));
+    SPZ_HIP_TRY(hipMemcpyAsync(d_rec + tail_begin, tail_states.data(), (size_t)kTailWindow * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    SPZ_HIP_TRY(hipMemsetAsync(d_info, 0, (size_t)(n_jobs + 1) * sizeof(JobInfo), st));
+    const uint32_t parse_blocks = (n_jobs + 63u) / 64u;
+    hipLaunchKernelGGL(lz_parse_kernel, dim3(parse_blocks), dim3(64), 0, st, d_r128, d_r32, job_bytes, (uint32_t)tail_begin, n_jobs, d_rec,
+                       d_sd, d_sl, d_info);
+    SPZ_HIP_TRY(hipGetLastError());
+    lap("parse");
+    hipLaunchKernelGGL(lz_stitch_kernel, dim3(parse_blocks), dim3(64), 0, st, d_r128, d_r32, job_bytes, (uint32_t)tail_begin, n_jobs,
+                       d_rec, d_xd, d_xl, d_info);
+    SPZ_HIP_TRY(hipGetLastError());
+    info.resize(n_jobs + 1);
+    SPZ_HIP_TRY(hipMemcpyAsync(info.data(), d_info, info.size() * sizeof(JobInfo), hipMemcpyDeviceToHost, st));
+    SPZ_HIP_TRY(hipStreamSynchronize(st));
+    lap("stitch");
+    met = true;
+    goff.assign(n_jobs, 0);
+    total_syms = 0;
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+      if (!info[j].spliced || info[j].n < info[j].lo) {
+        met = false;
+        break;
+      }
+      goff[j] = total_syms;
+      total_syms += info[j].n - info[j].lo + info[j].extra;
+    }
+    if (timing && !met) std::fprintf(stderr, "[lz77] jobs of %u bytes: two neighbours did not meet\n", job_bytes);
   }
+  if (!met) return SPZ_AMD_ERR_UNSUPPORTED;  // no meeting point even between the largest jobs: host parse
   if (total_syms > n_pos) return SPZ_AMD_ERR_UNSUPPORTED;
   {  // the last job met the host's tail parse: the host's own symbol count at that loop top must be the one counted here
     const uint32_t k = info[n_jobs - 1].end_s - (uint32_t)tail_begin;
-    if (k >= kRecordWindow || h_tail_rec[2 * k + 1] != info[n_jobs].lo) return SPZ_AMD_ERR_UNSUPPORTED;
+    if (k >= kTailWindow || h_tail_rec[2 * k + 1] != info[n_jobs].lo) return SPZ_AMD_ERR_UNSUPPORTED;
   }
   SPZ_HIP_TRY(hipMemcpyAsync(d_goff, goff.data(), goff.size() * sizeof(unsigned long long), hipMemcpyHostToDevice, st));
   // the tables are done with: their memory takes the dense arrays (2 B and 1 B per symbol, at most one symbol per position)
   uint16_t *dense_dist = reinterpret_cast<uint16_t *>(d_r128);
   uint8_t *dense_lc = reinterpret_cast<uint8_t *>(d_r32);
-  hipLaunchKernelGGL(lz_compact_kernel, dim3(n_jobs), dim3(256), 0, st, d_sd, d_sl, d_xd, d_xl, d_info, d_goff, dense_dist, dense_lc);
+  hipLaunchKernelGGL(lz_compact_kernel, dim3(n_jobs), dim3(256), 0, st, d_sd, d_sl, d_xd, d_xl, d_info, job_bytes, d_goff, dense_dist,
+                     dense_lc);
   SPZ_HIP_TRY(hipGetLastError());
   SPZ_HIP_TRY(hipStreamSynchronize(st));
   lap("compact");
@@ -607,7 +652,7 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
   c->data = d_data;
   c->size = size;
   c->scratch_a = block + o_rec;   // the deflate body
-  c->scratch_a_bytes = ((size_t)n_jobs * kJobBytes + kRecordWindow) * sizeof(uint32_t);
+  c->scratch_a_bytes = rec_words * sizeof(uint32_t);
   c->scratch_b = block + o_sd;    // codes, block descriptors, header words
   c->scratch_b_bytes = o_xd - o_sd;
   c->scratch_c = block + o_xd;    // frequencies, per-block counters, static tables

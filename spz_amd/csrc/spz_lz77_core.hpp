@@ -2,11 +2,17 @@
 // spz_deflate.cpp) cut into three data-parallel stages, shared by the HIP kernels (spz_lz77.hip) and by a
 // serial host model of the same stages (spz_lz77_model.cpp) that the CPU tests run:
 //
-//   1. links    link[p] = distance from p to the nearest earlier position with the same 3-byte hash (zlib's
-//               prev[] chain), 0 when there is none within 32 KiB.  zlib inserts EVERY position into its hash
-//               chains at level >= 4, so the chains are a pure function of the input.
-//   2. matches  r128[p] / r32[p] = the input byte at p and what longest_match() returns at a loop top at p with a chain budget of 128 /
-//               32 (the budget is 32 when the previous match is >= good_match) and no previous match.  A
+//   1. chains   zlib walks, per position, the chain of earlier positions with the same 16-bit hash of three bytes
+//               (its prev[] links; EVERY position is in the chains at level >= 4, so they are a pure function of
+//               the input) and spends its budget of 128 steps mostly on strangers: the .spz sh bytes are
+//               multiples of 8 or 16, so whole families of byte triples share a hash.  Two arrays replace the chain:
+//               link[p] = distance to the nearest earlier position with the same value of a DIFFERENT, well-mixed
+//               hash of the triple (hash2), and rank[p] = how many earlier positions share p's zlib hash (mod 2^16).
+//               Walking link[] visits (almost) only positions with the same three bytes, and the difference of
+//               two ranks says how many steps zlib's own walk needs from one to the other.
+//   2. matches  r128[p] / r32[p] = the input byte at p and what longest_match() returns at a loop top at p with a
+//               chain budget of 128 / 32 (the budget is 32 when the previous match is >= good_match) and no
+//               previous match.  A
 //               previous match of length L only raises the bar a candidate has to pass: longest_match with
 //               prev_length = L returns the same (length, start) when that length exceeds L, and "nothing
 //               better" otherwise (a candidate is taken iff it is longer than the best so far; the walk stops
@@ -37,24 +43,33 @@ constexpr uint32_t MIN_MATCH = 3, MAX_MATCH = 258, MIN_LOOKAHEAD = MAX_MATCH + M
 constexpr uint32_t MAX_DIST = W - MIN_LOOKAHEAD, TOO_FAR = 4096;
 constexpr uint32_t GOOD_MATCH = 8, MAX_LAZY = 16, NICE_MATCH = 128, MAX_CHAIN = 128, SHORT_CHAIN = MAX_CHAIN >> 2;
 
-// Geometry of the data-parallel parse.  A job is kJobBytes of input: it runs deflate_slow's loop from its first
+// Geometry of the data-parallel parse.  A job is job_bytes of input: it runs deflate_slow's loop from its first
 // position (lazy state reset) to the first loop top at or past its end, and records its lazy state at every
 // loop top (one word per input position).  A second, short step continues each job into its successor's range
 // until its state at a loop top equals the one the successor recorded there — from that position on the two
 // parses are the same parse, so the successor's symbols take over (spz_deflate.cpp's splice; how many symbols
 // the successor had emitted by then is counted by running its parse up to that position once more).  The
-// meeting point is usually a few positions in, a few thousand after long runs; none inside the successor's
-// range: declined, the caller parses on the host instead.
-constexpr uint32_t kJobBytes = W / 2;
-constexpr uint32_t kRecordWindow = kJobBytes;
-constexpr uint32_t kJobSymbolStride = kJobBytes + 8;        // at most one symbol per position
-constexpr uint32_t kStitchSymbolStride = kRecordWindow + 8;
-// Positions past the last job's end that the tables must cover (loop tops of that job inside its successor's
-// range, plus one match), and the bytes past a position that a match compare may read.
-constexpr uint32_t kTableSlack = kRecordWindow + MAX_MATCH + 6;
+// meeting point is usually a few positions in, a few thousand after long runs, tens of thousands when long
+// stretches of the input repeat; none inside the successor's range: the stage is run again with larger jobs
+// (the tables do not depend on the jobs), and declined after the largest — the caller parses on the host instead.
+constexpr uint32_t kJobSizes[3] = {W / 2, 4 * W, 32 * W};
+constexpr uint32_t kSmallestJob = W / 2;
+constexpr uint32_t kTailWindow = W;  // loop tops of the caller's tail parse that the last job may meet
+SPZ_LZ_HD uint32_t job_symbol_stride(uint32_t job_bytes) { return job_bytes + 8; }  // at most one symbol per position
+// End of the range job j's continuation may run through: its successor's own range, or the tail parse's first loop tops.
+SPZ_LZ_HD uint64_t stitch_end(uint64_t j, uint64_t n_jobs, uint32_t job_bytes, uint64_t head_end) {
+  const uint64_t next = (j + 1) * job_bytes < head_end ? (j + 1) * job_bytes : head_end;
+  if (j + 1 < n_jobs) return next + job_bytes < head_end ? next + job_bytes : head_end;
+  return head_end + (job_bytes < kTailWindow ? job_bytes : kTailWindow);
+}
+// Positions past the last job's end that the tables must cover (loop tops of that job inside the tail window,
+// plus one match), and the bytes past a position that a match compare may read.
+constexpr uint32_t kTableSlack = kTailWindow + MAX_MATCH + 6;
 constexpr uint32_t kReadAhead = MAX_MATCH + 4;
 
 SPZ_LZ_HD uint32_t hash3(uint32_t b0, uint32_t b1, uint32_t b2) { return ((b0 << 12) ^ (b1 << 6) ^ b2) & HASH_MASK; }
+// The other hash of the same three bytes: equal triples have equal values, unequal ones rarely.
+SPZ_LZ_HD uint32_t hash2(uint32_t b0, uint32_t b1, uint32_t b2) { return ((b0 | (b1 << 8) | (b2 << 16)) * 0x9E3779B1u) >> 16; }
 
 // Window base (absolute position of window[0]) after fill_window at a loop top at position s (the same
 // function as spz_deflate.cpp's, which checks it against the simulated window in every job).
@@ -78,54 +93,60 @@ SPZ_LZ_HD uint32_t entry_distance(uint32_t e) { return (e >> 8) & 0x7fffu; }
 SPZ_LZ_HD uint32_t entry_byte(uint32_t e) { return e & 0xffu; }
 
 // Stage 2 for one position p.  Positions are in the caller's coordinates (Pos: absolute int64_t on the host,
-// tile-relative int32_t in the kernel; signed, so that a link that leaves the tile's window makes a negative
-// position and ends the walk like any position below the limit).  `data.load4(pos)`: the four input bytes at
-// pos, little endian (pos up to p + kReadAhead); `link(pos)`: stage 1's value; `base`: base_at(p) in the same
-// coordinates (anything at or below p - W stands for "not in reach").  p has a full lookahead.
-template <class Pos, class Data, class Link>
-SPZ_LZ_HD void find_matches(const Data &data, const Link &link, Pos p, Pos base, uint32_t *r128, uint32_t *r32) {
+// window-relative int32_t in the kernel).  `data.load4(pos)`: the four input bytes at pos, little endian (pos up
+// to p + kReadAhead); `link(pos)`, `rank(pos)`: stage 1's values (ranks need a common origin only among the
+// positions one walk can reach); `base`: base_at(p) in the same coordinates (anything at or below p - W stands
+// for "not in reach").  p has a full lookahead.
+//
+// zlib's walk, restated on the positions with p's three bytes: its first candidate (chain index 0) must lie above
+// the window base and at most MAX_DIST back, every later one strictly above `limit`; positions only fall along
+// the chain, so the first position that fails ends the walk for every later one too, whether it is a stranger or
+// not; the budget ends it at chain index 128; strangers can never be taken (a candidate needs 3 equal bytes).
+template <class Pos, class Data, class Link, class Rank>
+SPZ_LZ_HD void find_matches(const Data &data, const Link &link, const Rank &rank, Pos p, Pos base, uint32_t *r128,
+                            uint32_t *r32) {
   const uint32_t s4 = data.load4(p);
   const uint32_t none = encode_entry(0, 0, s4 & 0xffu);
   *r128 = none;
   *r32 = none;
-  uint32_t gap = link(p);
-  if (gap == 0 || gap > MAX_DIST) return;          // hash_head == NIL, or strstart - hash_head > MAX_DIST
-  Pos cur = p - (Pos)gap;
-  if (cur <= base) return;                           // the window has dropped it (index 0 is NIL too)
   const Pos limit = (p - base > (Pos)MAX_DIST) ? p - (Pos)MAX_DIST : base;
-  uint32_t best = MIN_MATCH - 1, best_dist = 0, k = 0, stop_at = SHORT_CHAIN;
+  const uint32_t rank_p = rank(p);
+  uint32_t best = MIN_MATCH - 1, best_dist = 0;
+  bool snapped = false;
+  Pos cur = p;
   for (;;) {
-    const uint32_t m4 = data.load4(cur);
-    if (((m4 ^ s4) & 0xffffffu) == 0u &&
-        (best < MIN_MATCH || ((data.load4(cur + (Pos)best) ^ data.load4(p + (Pos)best)) & 0xffu) == 0u)) {
-      uint32_t len = MIN_MATCH;
-      while (len < MAX_MATCH) {
-        const uint32_t x = data.load4(p + (Pos)len) ^ data.load4(cur + (Pos)len);
-        if (x != 0u) {
-          len += (uint32_t)__builtin_ctz(x) >> 3;
-          break;
-        }
-        len += 4;
-      }
-      if (len > MAX_MATCH) len = MAX_MATCH;
-      if (len > best) {
-        best = len;
-        best_dist = (uint32_t)(p - cur);
-        if (len >= NICE_MATCH) break;
-      }
-    }
-    if (++k == stop_at) {
-      if (k == MAX_CHAIN) break;
-      *r32 = encode_entry(best, best_dist, s4 & 0xffu);  // what a budget of 32 has found
-      stop_at = MAX_CHAIN;
-    }
-    gap = link(cur);
+    const uint32_t gap = link(cur);
     if (gap == 0) break;
     cur -= (Pos)gap;
-    if (cur <= limit) break;
+    if (cur <= base || p - cur > (Pos)MAX_DIST) break;  // out of reach for the first candidate and for any later one
+    const uint32_t m4 = data.load4(cur);
+    if (((m4 ^ s4) & 0xffffffu) != 0u) continue;        // a stranger on the hash2 chain
+    const uint32_t k = (rank_p - rank(cur) - 1u) & 0xffffu;  // its index in zlib's chain
+    if (k >= MAX_CHAIN) break;
+    if (k > 0 && cur <= limit) break;
+    if (k >= SHORT_CHAIN && !snapped) {
+      *r32 = encode_entry(best, best_dist, s4 & 0xffu);  // what a budget of 32 has found
+      snapped = true;
+    }
+    if (best >= MIN_MATCH && ((data.load4(cur + (Pos)best) ^ data.load4(p + (Pos)best)) & 0xffu) != 0u) continue;
+    uint32_t len = MIN_MATCH;
+    while (len < MAX_MATCH) {
+      const uint32_t x = data.load4(p + (Pos)len) ^ data.load4(cur + (Pos)len);
+      if (x != 0u) {
+        len += (uint32_t)__builtin_ctz(x) >> 3;
+        break;
+      }
+      len += 4;
+    }
+    if (len > MAX_MATCH) len = MAX_MATCH;
+    if (len > best) {
+      best = len;
+      best_dist = (uint32_t)(p - cur);
+      if (len >= NICE_MATCH) break;
+    }
   }
   const uint32_t r = encode_entry(best, best_dist, s4 & 0xffu);
-  if (stop_at == SHORT_CHAIN) *r32 = r;  // the walk ended inside the short budget
+  if (!snapped) *r32 = r;  // the walk ended inside the short budget
   *r128 = r;
 }
 

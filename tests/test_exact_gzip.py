@@ -112,3 +112,23 @@ def test_default_save_path_on_a_real_stream_equals_zlib_and_the_reference(refere
         assert spz._compress_gzipped(raw) == got
     finally:
         del os.environ["SPZ_AMD_GZIP_EXACT_THREADS"]
+
+
+@pytest.mark.parametrize("kind", ["nibbles", "bytes", "words", "runs", "sh_like"])
+def test_staged_parse_model_equals_zlib(kind):
+    """The parse the MI355X runs (spz_lz77.hip), as its serial host model with the same stage functions and job
+    geometry (spz_lz77_core.hpp / spz_lz77_model.cpp): hash2 links + zlib-chain ranks, the two match tables per
+    position, the lazy state machine over 16 KiB jobs, the stitch into the successor's recorded states and the
+    splice with the host's serial tail job.  Sizes around the 16 KiB job / 32 KiB window boundaries."""
+    rng = np.random.default_rng(sum(kind.encode()) + 2)
+    for n in (524288, 524289, 540673, 700001, (1 << 20) + 12345):
+        data = make(kind, n, rng)
+        got = spz._compress_gzipped_exact_model(data, 4, 256 << 10)
+        assert got == zlib_gzip(data), f"{kind} n={n}: the staged parse differs from zlib"
+
+
+def test_staged_parse_model_declines_what_it_cannot_splice():
+    """Constant input: two neighbouring jobs never reach the same lazy-match state (their 258-byte matches stay out
+    of phase), so the staged parse declines and the caller uses another path."""
+    assert spz._compress_gzipped_exact_model(bytes(1 << 20), 4) is None
+    assert spz._compress_gzipped_exact_model(b"x" * 1000, 4) is None           # below 512 KiB

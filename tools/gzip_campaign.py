@@ -75,6 +75,10 @@ def main():
     ap.add_argument("--inputs", type=int, default=9300)
     ap.add_argument("--seed", type=int, default=20261004)
     ap.add_argument("--max-mib", type=float, default=3.0)
+    ap.add_argument("--writer", choices=("host", "model", "device"), default="host",
+                    help="host: the multi-threaded parse of spz_deflate.cpp; model: the serial host model of the device's "
+                         "stages (spz_lz77_model.cpp; inputs of 512 KiB and more); device: compressGzipped with "
+                         "SPZ_AMD_GZIP_DEVICE=1 (needs a GPU; a member counts only if the device did the parse)")
     a = ap.parse_args()
     if zlib.ZLIB_RUNTIME_VERSION != "1.2.11":
         print(json.dumps({"skipped": f"zlib {zlib.ZLIB_RUNTIME_VERSION}: the writer restates 1.2.11 and stands down"}))
@@ -84,15 +88,30 @@ def main():
     t0 = time.time()
     same = declined = total_bytes = 0
     kinds = {}
+    declined_kinds = {}
     for i in range(a.inputs):
         kind, data = make_input(i, rng, int(a.max_mib * (1 << 20)))
         threads = int(rng.integers(2, 17))
         windows = int(rng.integers(4, 33))
-        got = spz._compress_gzipped_exact(data, threads, windows, 0)
+        if a.writer == "model":
+            if len(data) < (512 << 10):
+                data = (data * (1 + (512 << 10) // len(data)))[: (512 << 10) + len(data) % 4099]
+            got = spz._compress_gzipped_exact_model(data, threads, 0)
+        elif a.writer == "device":
+            if len(data) < (1 << 20):
+                data = (data * (1 + (1 << 20) // len(data)))[: (1 << 20) + len(data) % 4099]
+            os.environ["SPZ_AMD_GZIP_DEVICE"] = "1"
+            before = spz._device_gzip_parse_count()
+            got = spz._compress_gzipped(data)
+            if spz._device_gzip_parse_count() == before:
+                got = None if got == zlib_gzip(data) else got   # the device declined; the fallback's bytes must still be zlib's
+        else:
+            got = spz._compress_gzipped_exact(data, threads, windows, 0)
         kinds[kind.split()[0]] = kinds.get(kind.split()[0], 0) + 1
         total_bytes += len(data)
         if got is None:
             declined += 1
+            declined_kinds[kind.split()[0]] = declined_kinds.get(kind.split()[0], 0) + 1
             continue
         if got != zlib_gzip(data):
             print(json.dumps({"FAILED": True, "input": i, "kind": kind, "bytes": len(data), "threads": threads,
@@ -102,8 +121,8 @@ def main():
         if (i + 1) % 500 == 0:
             print(f"[gzip-campaign] {i + 1}/{a.inputs} inputs, {same} identical, {declined} declined, {time.time() - t0:.0f} s",
                   file=sys.stderr, flush=True)
-    print(json.dumps({"inputs": a.inputs, "identical_to_zlib": same, "declined": declined, "different": 0, "seed": a.seed,
-                      "total_MB": round(total_bytes / 1e6, 1), "by_kind": kinds, "seconds": round(time.time() - t0, 1)}))
+    print(json.dumps({"writer": a.writer, "inputs": a.inputs, "identical_to_zlib": same, "declined": declined, "different": 0, "seed": a.seed,
+                      "total_MB": round(total_bytes / 1e6, 1), "by_kind": kinds, "declined_by_kind": declined_kinds, "seconds": round(time.time() - t0, 1)}))
     return 0
 
 
