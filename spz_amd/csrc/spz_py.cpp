@@ -365,6 +365,21 @@ PYBIND11_MODULE(spz, m) {
     const double unpack_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     return py::make_tuple(pack_s, unpack_s, static_cast<int64_t>(back.numPoints));
   }, py::arg("gaussians"), py::arg("pack_options"), py::arg("unpack_options"), "Seconds of packToStream and unpackFromStream at the C++ boundary.");
+  m.def("_save_load_seconds", [](const spz::GaussianCloud &g, const spz::PackOptions &o, const spz::UnpackOptions &u) {
+    // spz::saveSpz / spz::loadSpz (the reference's vector overloads, load-spz.h) timed around the C++ calls themselves
+    std::vector<uint8_t> file;
+    const uint64_t parses_before = spz::deviceGzipParseCount();
+    auto t0 = std::chrono::steady_clock::now();
+    const bool ok = spz::saveSpz(g, o, &file);
+    const double save_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (!ok) raiseIfDeviceUnusable();
+    const bool gzip_on_device = spz::deviceGzipParseCount() != parses_before;
+    t0 = std::chrono::steady_clock::now();
+    spz::GaussianCloud back = spz::loadSpz(file, u);
+    const double load_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    return py::make_tuple(save_s, load_s, static_cast<int64_t>(file.size()), static_cast<int64_t>(back.numPoints), gzip_on_device);
+  }, py::arg("gaussians"), py::arg("pack_options"), py::arg("unpack_options"),
+     "Seconds of saveSpz and loadSpz at the C++ boundary, file bytes, points read back, whether the gzip stage ran on the device.");
   m.def("_pack_to_stream", [](const spz::GaussianCloud &g, const spz::PackOptions &o) -> py::object {
     std::vector<uint8_t> out;
     if (!spz::packToStream(g, o, &out)) {

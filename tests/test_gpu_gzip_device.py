@@ -78,3 +78,27 @@ def test_device_parse_is_off_below_the_threshold_and_when_disabled():
     assert spz._compress_gzipped(big) == zlib_gzip(big)
     assert spz._device_gzip_parse_count() == before
     os.environ["SPZ_AMD_GZIP_DEVICE"] = "1"
+
+
+def test_device_declines_what_it_cannot_splice_and_the_result_is_still_zlibs():
+    """Constant input: neighbouring jobs never reach the same lazy-match state (258-byte matches out of phase), at
+    any job size; the device path declines, the host writer declines too, zlib itself writes the member."""
+    data = bytes(3 << 20)
+    before = spz._device_gzip_parse_count()
+    assert spz._compress_gzipped(data) == zlib_gzip(data)
+    assert spz._device_gzip_parse_count() == before
+
+
+def test_long_repeats_need_larger_jobs_and_get_them():
+    """Pieces of up to 40 KiB that come back at distances around the 32 KiB window: with 16 KiB jobs two neighbours
+    often do not meet inside the successor's range; the stage is rerun with larger jobs on the device."""
+    rng = np.random.default_rng(9)
+    pieces = [rng.integers(0, 256, int(rng.integers(1 << 10, 40 << 10)), dtype=np.uint8).tobytes() for _ in range(6)]
+    out = bytearray()
+    while len(out) < (3 << 20):
+        out += pieces[int(rng.integers(0, 6))]
+        out += rng.integers(0, 64, int(rng.integers(0, 3000)), dtype=np.uint8).tobytes()
+    data = bytes(out)
+    before = spz._device_gzip_parse_count()
+    assert spz._compress_gzipped(data) == zlib_gzip(data)
+    assert spz._device_gzip_parse_count() == before + 1
