@@ -19,6 +19,7 @@
 // Any irregularity returns false and the caller's serial reader decides.
 #include "spz_inflate.hpp"
 #include "spz_host_util.hpp"
+#include "spz_inflate_core.hpp"
 
 #include <zlib.h>
 
@@ -34,226 +35,6 @@
 namespace spz {
 namespace pinflate {
 namespace {
-
-constexpr uint32_t W = 32768;
-constexpr int FAST_L = 11, FAST_D = 9;
-constexpr uint64_t NONE = ~uint64_t(0);
-
-const uint16_t kLenBase[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
-const uint8_t kLenExtra[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
-const uint16_t kDistBase[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
-const uint8_t kDistExtra[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
-const uint8_t kClOrder[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
-
-struct Bits {  // the deflate data of the member
-  const uint8_t *p;
-  uint64_t nbits;
-  size_t nbytes;
-  // >= 56 valid bits starting at bit position `at` (zeros past the end)
-  inline uint64_t peek(uint64_t at) const {
-    const size_t b = static_cast<size_t>(at >> 3);
-    uint64_t v = 0;
-    if (b + 8 <= nbytes) {
-      std::memcpy(&v, p + b, 8);
-    } else {
-      for (size_t k = 0; b + k < nbytes && k < 8; ++k) v |= static_cast<uint64_t>(p[b + k]) << (8 * k);
-    }
-    return v >> (at & 7);
-  }
-};
-
-// Canonical Huffman decoder: a direct table for codes up to `fast` bits, canonical walk for longer ones.
-// Packed decode entry of a literal/length or distance code: everything the inner loop needs in one 32-bit load.
-//   bits 0-3  code length (0: the code is longer than the fast table, take the canonical walk)
-//   bits 4-7  number of extra bits (length / distance codes)
-//   bit  8    literal, bit 9 end of block, bit 10 invalid symbol (286, 287 / distance 30, 31)
-//   bits 16-31 the literal byte, or the base length / base distance
-constexpr uint32_t ENT_LITERAL = 1u << 8, ENT_EOB = 1u << 9, ENT_INVALID = 1u << 10;
-
-struct Huff {
-  uint16_t fast[1 << FAST_L];
-  uint32_t packed[1 << FAST_L];  // filled by pack(): same index as fast[]
-  uint32_t ent[288];             // per symbol, without the code length (slow path)
-  uint16_t count[16];
-  uint16_t symbol[288];
-  int fastbits = 0;
-  int ncodes = 0;
-
-  // returns false for an over-subscribed set, or an incomplete one that is not a single code
-  bool build(const uint8_t *lens, int n, int fast_bits) {
-    fastbits = fast_bits;
-    std::memset(count, 0, sizeof(count));
-    for (int i = 0; i < n; ++i) count[lens[i]]++;
-    ncodes = n - count[0];
-    count[0] = 0;
-    int left = 1;
-    for (int len = 1; len <= 15; ++len) {
-      left <<= 1;
-      left -= count[len];
-      if (left < 0) return false;
-    }
-    if (left > 0 && ncodes != 1 && ncodes != 0) return false;
-    uint16_t offs[16];
-    offs[1] = 0;
-    for (int len = 1; len < 15; ++len) offs[len + 1] = static_cast<uint16_t>(offs[len] + count[len]);
-    for (int i = 0; i < n; ++i) {
-      if (lens[i]) symbol[offs[lens[i]]++] = static_cast<uint16_t>(i);
-    }
-    std::memset(fast, 0, sizeof(uint16_t) << fastbits);
-    unsigned code = 0;
-    int idx = 0;
-    for (int len = 1; len <= fastbits; ++len) {
-      for (int k = 0; k < count[len]; ++k, ++code, ++idx) {
-        unsigned rev = 0;  // codes are sent most significant bit first
-        for (int b = 0; b < len; ++b) rev |= ((code >> b) & 1u) << (len - 1 - b);
-        const uint16_t e = static_cast<uint16_t>((symbol[idx] << 4) | len);
-        for (unsigned j = rev; j < (1u << fastbits); j += (1u << len)) fast[j] = e;
-      }
-      code <<= 1;
-    }
-    return true;
-  }
-  // Builds the packed tables from fast[]; `dist` selects the distance alphabet's bases.
-  void pack(bool dist) {
-    const int nsym = dist ? 32 : 288;
-    for (int sym = 0; sym < nsym; ++sym) {
-      uint32_t e;
-      if (dist) e = sym < 30 ? (static_cast<uint32_t>(kDistExtra[sym]) << 4) | (static_cast<uint32_t>(kDistBase[sym]) << 16) : ENT_INVALID;
-      else if (sym < 256) e = ENT_LITERAL | (static_cast<uint32_t>(sym) << 16);
-      else if (sym == 256) e = ENT_EOB;
-      else if (sym < 286) e = (static_cast<uint32_t>(kLenExtra[sym - 257]) << 4) | (static_cast<uint32_t>(kLenBase[sym - 257]) << 16);
-      else e = ENT_INVALID;
-      ent[sym] = e;
-    }
-    const uint32_t n = 1u << fastbits;
-    for (uint32_t i = 0; i < n; ++i) {
-      const uint16_t f = fast[i];
-      packed[i] = f ? (ent[f >> 4] | (f & 15u)) : 0u;
-    }
-  }
-  // packed entry of the next code (code length in its low 4 bits); 0 if there is no such code
-  inline uint32_t lookup(uint64_t bits) const {
-    const uint32_t e = packed[bits & ((1u << fastbits) - 1)];
-    if (e) return e;
-    int len;
-    const int sym = decode(bits, &len);
-    if (sym < 0) return 0u;
-    return ent[sym] | static_cast<uint32_t>(len);  // len <= 15
-  }
-  // returns the symbol and sets *len, or -1
-  inline int decode(uint64_t bits, int *len) const {
-    const uint16_t e = fast[bits & ((1u << fastbits) - 1)];
-    if (e) {
-      *len = e & 15;
-      return e >> 4;
-    }
-    int code = 0, first = 0, index = 0;
-    for (int l = 1; l <= 15; ++l) {
-      code |= static_cast<int>(bits & 1);
-      bits >>= 1;
-      const int c = count[l];
-      if (code - c < first) {
-        *len = l;
-        return symbol[index + (code - first)];
-      }
-      index += c;
-      first += c;
-      first <<= 1;
-      code <<= 1;
-    }
-    return -1;
-  }
-};
-
-struct StaticHuff {
-  Huff lit, dist;
-  StaticHuff() {
-    uint8_t l[288];
-    for (int i = 0; i < 144; ++i) l[i] = 8;
-    for (int i = 144; i < 256; ++i) l[i] = 9;
-    for (int i = 256; i < 280; ++i) l[i] = 7;
-    for (int i = 280; i < 288; ++i) l[i] = 8;
-    lit.build(l, 288, FAST_L);
-    lit.pack(false);
-    uint8_t d[30];
-    for (int i = 0; i < 30; ++i) d[i] = 5;
-    dist.build(d, 30, FAST_D);
-    dist.pack(true);
-  }
-};
-const StaticHuff &staticHuff() {
-  static const StaticHuff s;
-  return s;
-}
-
-// Reads a dynamic block's code lengths (after the 3 header bits) and builds both decoders.
-bool readDynamic(const Bits &in, uint64_t *at, Huff *lit, Huff *dist) {
-  uint64_t pos = *at;
-  if (pos + 14 > in.nbits) return false;
-  uint64_t v = in.peek(pos);
-  const int hlit = static_cast<int>(v & 31) + 257, hdist = static_cast<int>((v >> 5) & 31) + 1,
-            hclen = static_cast<int>((v >> 10) & 15) + 4;
-  if (hlit > 286 || hdist > 30) return false;
-  pos += 14;
-  uint8_t cl[19] = {};
-  if (pos + 3 * static_cast<uint64_t>(hclen) > in.nbits) return false;
-  v = in.peek(pos);
-  for (int i = 0; i < hclen; ++i) {  // 19 * 3 = 57 bits: one peek is not always enough
-    if (i == 16) v = in.peek(pos + 48);
-    cl[kClOrder[i]] = static_cast<uint8_t>((v >> (3 * (i & 15))) & 7);
-  }
-  pos += 3 * static_cast<uint64_t>(hclen);
-  Huff clh;
-  if (!clh.build(cl, 19, 7)) return false;
-  if (clh.ncodes < 1) return false;
-  uint8_t lens[286 + 30] = {};
-  int n = 0;
-  const int total = hlit + hdist;
-  while (n < total) {
-    if (pos >= in.nbits) return false;
-    v = in.peek(pos);
-    int len;
-    const int sym = clh.decode(v, &len);
-    if (sym < 0) return false;
-    v >>= len;
-    pos += static_cast<uint64_t>(len);
-    if (sym < 16) {
-      lens[n++] = static_cast<uint8_t>(sym);
-    } else {
-      int rep, val = 0;
-      if (sym == 16) {
-        if (n == 0) return false;
-        val = lens[n - 1];
-        rep = 3 + static_cast<int>(v & 3);
-        pos += 2;
-      } else if (sym == 17) {
-        rep = 3 + static_cast<int>(v & 7);
-        pos += 3;
-      } else {
-        rep = 11 + static_cast<int>(v & 127);
-        pos += 7;
-      }
-      if (n + rep > total) return false;
-      while (rep--) lens[n++] = static_cast<uint8_t>(val);
-    }
-  }
-  if (pos > in.nbits || lens[256] == 0) return false;
-  if (!lit->build(lens, hlit, FAST_L)) return false;
-  if (!dist->build(lens + hlit, hdist, FAST_D)) return false;
-  if (lit->ncodes < 2) return false;  // zlib never writes fewer; keeps the block-start search strict
-  lit->pack(false);
-  dist->pack(true);
-  *at = pos;
-  return true;
-}
-
-// ---- sinks ---------------------------------------------------------------------------------------------
-struct NullSink {  // block-start validation
-  uint64_t n = 0;
-  inline bool lit(uint8_t) { ++n; return true; }
-  inline bool match(uint32_t len, uint32_t) { n += len; return true; }
-  inline bool raw(const uint8_t *, uint32_t len) { n += len; return true; }
-};
 
 // The one-pass form: the whole chunk in 16-bit symbols (a byte, or 256 + k for "byte k of the predecessor's final
 // window").  The buffer opens with the W references to that window, so a match that reaches back before the chunk
@@ -308,128 +89,16 @@ struct SymbolSink {
   inline uint16_t tail(uint32_t back) const { return sym[W + n - back]; }
 };
 
-template <class Sink>
-bool decodeHuffBlock(const Bits &in, uint64_t *at, const Huff &L, const Huff &D, Sink &sink) {
-  uint64_t pos = *at;
-  for (;;) {
-    if (pos >= in.nbits) return false;
-    uint64_t bits = in.peek(pos);  // >= 56 valid bits
-    uint32_t e = L.lookup(bits);
-    // up to three literals per refill (3 x 15 bits <= 56)
-    if (e & ENT_LITERAL) {
-      if (!sink.lit(static_cast<uint8_t>(e >> 16))) return false;
-      pos += e & 15u;
-      bits >>= e & 15u;
-      e = L.lookup(bits);
-      if (e & ENT_LITERAL) {
-        if (!sink.lit(static_cast<uint8_t>(e >> 16))) return false;
-        pos += e & 15u;
-        bits >>= e & 15u;
-        e = L.lookup(bits);
-        if (e & ENT_LITERAL) {
-          if (!sink.lit(static_cast<uint8_t>(e >> 16))) return false;
-          pos += e & 15u;
-        }
-      }
-      continue;  // refill before anything that needs more than a code
-    }
-    if (e == 0u || (e & ENT_INVALID)) return false;
-    uint32_t used = e & 15u;
-    if (e & ENT_EOB) {
-      pos += used;
-      if (pos > in.nbits) return false;
-      *at = pos;
-      return true;
-    }
-    bits >>= used;
-    const uint32_t lextra = (e >> 4) & 15u;
-    const uint32_t length = (e >> 16) + static_cast<uint32_t>(bits & ((1u << lextra) - 1u));
-    bits >>= lextra;
-    used += lextra;  // <= 20
-    const uint32_t d = D.lookup(bits);
-    if (d == 0u || (d & ENT_INVALID)) return false;
-    bits >>= d & 15u;
-    const uint32_t dextra = (d >> 4) & 15u;
-    const uint32_t dist = (d >> 16) + static_cast<uint32_t>(bits & ((1u << dextra) - 1u));
-    used += (d & 15u) + dextra;  // <= 48 of the >= 56 bits
-    pos += used;
-    if (pos > in.nbits) return false;
-    if (!sink.match(length, dist)) return false;
-  }
-}
-
-enum Outcome { FAILED, LINKED, FINAL };
-
-// Decodes whole blocks from `start` until a block would start at `stop` (LINKED) or the final block ends
-// (FINAL, *end = first bit after it).
-template <class Sink>
-Outcome decodeBlocks(const Bits &in, uint64_t start, uint64_t stop, Sink &sink, uint64_t *end) {
-  uint64_t pos = start;
-  Huff lit, dist;
-  for (;;) {
-    if (pos == stop) return LINKED;
-    if (pos > stop || pos + 3 > in.nbits) return FAILED;
-    const uint64_t v = in.peek(pos);
-    const bool final_block = v & 1;
-    const int type = static_cast<int>((v >> 1) & 3);
-    pos += 3;
-    if (type == 0) {
-      pos = (pos + 7) & ~uint64_t(7);
-      if (pos + 32 > in.nbits) return FAILED;
-      const uint64_t h = in.peek(pos);
-      const uint32_t len = static_cast<uint32_t>(h & 0xffff), nlen = static_cast<uint32_t>((h >> 16) & 0xffff);
-      if ((len ^ nlen) != 0xffff) return FAILED;
-      pos += 32;
-      if (pos + 8 * static_cast<uint64_t>(len) > in.nbits) return FAILED;
-      if (!sink.raw(in.p + (pos >> 3), len)) return FAILED;
-      pos += 8 * static_cast<uint64_t>(len);
-    } else if (type == 1) {
-      const StaticHuff &s = staticHuff();
-      if (!decodeHuffBlock(in, &pos, s.lit, s.dist, sink)) return FAILED;
-    } else if (type == 2) {
-      if (!readDynamic(in, &pos, &lit, &dist)) return FAILED;
-      if (!decodeHuffBlock(in, &pos, lit, dist, sink)) return FAILED;
-    } else {
-      return FAILED;
-    }
-    if (final_block) {
-      *end = pos;
-      return FINAL;
-    }
-  }
-}
-
 // First bit position in [lo, hi) where a non-final dynamic block starts, decodes to its end-of-block and is
 // followed by a plausible header.
 uint64_t findBlockStart(const Bits &in, uint64_t lo, uint64_t hi) {
-  Huff lit, dist;
+  HuffLit lit;
+  HuffDist dist;
   for (uint64_t p = lo; p < hi && p + 64 < in.nbits; ++p) {
-    const uint64_t v = in.peek(p);
-    if ((v & 7) != 4) continue;                          // BFINAL = 0, BTYPE = 2
-    if (((v >> 3) & 31) > 29 || ((v >> 8) & 31) > 29) continue;
-    {  // the code-length code must be complete (zlib's always is): Kraft sum over its 3-bit lengths
-      const int hclen = static_cast<int>((v >> 13) & 15) + 4;
-      uint64_t c = v >> 17;  // 39+ valid bits = 13 lengths; the rest from a second peek
-      unsigned kraft = 0;
-      for (int i = 0; i < hclen; ++i) {
-        if (i == 13) c = in.peek(p + 17 + 39);
-        const unsigned l = static_cast<unsigned>(c & 7);
-        c >>= 3;
-        if (l) kraft += 128u >> l;
-      }
-      if (kraft != 128) continue;
-    }
-    uint64_t pos = p + 3;
-    if (!readDynamic(in, &pos, &lit, &dist)) continue;
-    NullSink sink;
-    if (!decodeHuffBlock(in, &pos, lit, dist, sink)) continue;
-    if (sink.n < 64) continue;                           // real blocks carry thousands of bytes
-    if (pos + 3 > in.nbits || ((in.peek(pos) >> 1) & 3) == 3) continue;
-    return p;
+    if (isBlockStart(in, p, &lit, &dist)) return p;
   }
   return NONE;
 }
-
 template <class F>
 void parallel_for(size_t n, int threads, F fn) {
   std::atomic<size_t> next{0};
@@ -522,7 +191,9 @@ bool inflate(const uint8_t *gz, size_t size, size_t header_len, int threads, std
       return;
     }
     const auto t_chunk = std::chrono::steady_clock::now();
-    const Outcome r = decodeBlocks(in, from, to, sink, &end);
+    HuffLit lit_tables;
+    HuffDist dist_tables;
+    const Outcome r = decodeBlocks(in, from, to, sink, &end, &lit_tables, &dist_tables);
     if (timing) chunk_s[j] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_chunk).count();
     length[j] = sink.n;
     end_bit[j] = end;

@@ -1,0 +1,377 @@
+// spz_inflate_core.hpp — the deflate decoder of the parallel readers, shared by the host reader
+// (spz_inflate.cpp) and the device reader (spz_inflate_dev.hip): bit access, canonical Huffman tables with a
+// packed fast table, dynamic-block headers, the block decode loop over a symbol sink, and the tests that make a
+// bit position a plausible block start.  RFC 1951; nothing here allocates.
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+
+#if defined(__HIPCC__)
+#define SPZ_INF_HD __host__ __device__ __forceinline__
+#else
+#define SPZ_INF_HD inline
+#endif
+
+namespace spz {
+namespace pinflate {
+
+constexpr uint32_t W = 32768;
+constexpr int FAST_L = 11, FAST_D = 9;
+constexpr uint64_t NONE = ~uint64_t(0);
+
+SPZ_INF_HD uint32_t lenBase(int i) {
+  constexpr uint16_t t[29] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258};
+  return t[i];
+}
+SPZ_INF_HD uint32_t lenExtra(int i) {
+  constexpr uint8_t t[29] = {0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0};
+  return t[i];
+}
+SPZ_INF_HD uint32_t distBase(int i) {
+  constexpr uint16_t t[30] = {1, 2, 3, 4, 5, 7, 9, 13, 17, 25, 33, 49, 65, 97, 129, 193, 257, 385, 513, 769, 1025, 1537, 2049, 3073, 4097, 6145, 8193, 12289, 16385, 24577};
+  return t[i];
+}
+SPZ_INF_HD uint32_t distExtra(int i) {
+  constexpr uint8_t t[30] = {0, 0, 0, 0, 1, 1, 2, 2, 3, 3, 4, 4, 5, 5, 6, 6, 7, 7, 8, 8, 9, 9, 10, 10, 11, 11, 12, 12, 13, 13};
+  return t[i];
+}
+SPZ_INF_HD int clOrder(int i) {
+  constexpr uint8_t t[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+  return t[i];
+}
+
+struct Bits {  // the deflate data of the member
+  const uint8_t *p;
+  uint64_t nbits;
+  size_t nbytes;
+  // >= 56 valid bits starting at bit position `at` (zeros past the end)
+  SPZ_INF_HD uint64_t peek(uint64_t at) const {
+    const size_t b = static_cast<size_t>(at >> 3);
+    uint64_t v = 0;
+    if (b + 8 <= nbytes) {
+      std::memcpy(&v, p + b, 8);
+    } else {
+      for (size_t k = 0; b + k < nbytes && k < 8; ++k) v |= static_cast<uint64_t>(p[b + k]) << (8 * k);
+    }
+    return v >> (at & 7);
+  }
+};
+
+// Canonical Huffman decoder: a direct table for codes up to `fast` bits, canonical walk for longer ones.
+// Packed decode entry of a literal/length or distance code: everything the inner loop needs in one 32-bit load.
+//   bits 0-3  code length (0: the code is longer than the fast table, take the canonical walk)
+//   bits 4-7  number of extra bits (length / distance codes)
+//   bit  8    literal, bit 9 end of block, bit 10 invalid symbol (286, 287 / distance 30, 31)
+//   bits 16-31 the literal byte, or the base length / base distance
+constexpr uint32_t ENT_LITERAL = 1u << 8, ENT_EOB = 1u << 9, ENT_INVALID = 1u << 10;
+
+template <int FAST, int NSYM>
+struct HuffT {
+  uint16_t fast[1 << FAST];
+  uint32_t packed[1 << FAST];  // filled by pack(): same index as fast[]
+  uint32_t ent[NSYM];          // per symbol, without the code length (slow path)
+  uint16_t count[16];
+  uint16_t symbol[NSYM];
+  int ncodes;
+  static constexpr int fastbits = FAST;
+
+  // returns false for an over-subscribed set, or an incomplete one that is not a single code
+  SPZ_INF_HD bool build(const uint8_t *lens, int n) {
+    for (int i = 0; i < 16; ++i) count[i] = 0;
+    for (int i = 0; i < n; ++i) count[lens[i]]++;
+    ncodes = n - count[0];
+    count[0] = 0;
+    int left = 1;
+    for (int len = 1; len <= 15; ++len) {
+      left <<= 1;
+      left -= count[len];
+      if (left < 0) return false;
+    }
+    if (left > 0 && ncodes != 1 && ncodes != 0) return false;
+    uint16_t offs[16];
+    offs[1] = 0;
+    for (int len = 1; len < 15; ++len) offs[len + 1] = static_cast<uint16_t>(offs[len] + count[len]);
+    for (int i = 0; i < n; ++i) {
+      if (lens[i]) symbol[offs[lens[i]]++] = static_cast<uint16_t>(i);
+    }
+    for (int i = 0; i < (1 << FAST); ++i) fast[i] = 0;
+    unsigned code = 0;
+    int idx = 0;
+    for (int len = 1; len <= fastbits; ++len) {
+      for (int k = 0; k < count[len]; ++k, ++code, ++idx) {
+        unsigned rev = 0;  // codes are sent most significant bit first
+        for (int b = 0; b < len; ++b) rev |= ((code >> b) & 1u) << (len - 1 - b);
+        const uint16_t e = static_cast<uint16_t>((symbol[idx] << 4) | len);
+        for (unsigned j = rev; j < (1u << fastbits); j += (1u << len)) fast[j] = e;
+      }
+      code <<= 1;
+    }
+    return true;
+  }
+  // Builds the packed tables from fast[]; `dist` selects the distance alphabet's bases.
+  SPZ_INF_HD void pack(bool dist) {
+    const int nsym = dist ? 32 : 288;
+    for (int sym = 0; sym < nsym; ++sym) {
+      uint32_t e;
+      if (dist) e = sym < 30 ? (distExtra(sym) << 4) | (distBase(sym) << 16) : ENT_INVALID;
+      else if (sym < 256) e = ENT_LITERAL | (static_cast<uint32_t>(sym) << 16);
+      else if (sym == 256) e = ENT_EOB;
+      else if (sym < 286) e = (lenExtra(sym - 257) << 4) | (lenBase(sym - 257) << 16);
+      else e = ENT_INVALID;
+      ent[sym] = e;
+    }
+    const uint32_t n = 1u << fastbits;
+    for (uint32_t i = 0; i < n; ++i) {
+      const uint16_t f = fast[i];
+      packed[i] = f ? (ent[f >> 4] | (f & 15u)) : 0u;
+    }
+  }
+  // packed entry of the next code (code length in its low 4 bits); 0 if there is no such code
+  SPZ_INF_HD uint32_t lookup(uint64_t bits) const {
+    const uint32_t e = packed[bits & ((1u << fastbits) - 1)];
+    if (e) return e;
+    int len;
+    const int sym = decode(bits, &len);
+    if (sym < 0) return 0u;
+    return ent[sym] | static_cast<uint32_t>(len);  // len <= 15
+  }
+  // returns the symbol and sets *len, or -1
+  SPZ_INF_HD int decode(uint64_t bits, int *len) const {
+    const uint16_t e = fast[bits & ((1u << fastbits) - 1)];
+    if (e) {
+      *len = e & 15;
+      return e >> 4;
+    }
+    int code = 0, first = 0, index = 0;
+    for (int l = 1; l <= 15; ++l) {
+      code |= static_cast<int>(bits & 1);
+      bits >>= 1;
+      const int c = count[l];
+      if (code - c < first) {
+        *len = l;
+        return symbol[index + (code - first)];
+      }
+      index += c;
+      first += c;
+      first <<= 1;
+      code <<= 1;
+    }
+    return -1;
+  }
+};
+
+using HuffLit = HuffT<FAST_L, 288>;
+using HuffDist = HuffT<FAST_D, 32>;
+
+// The fixed Huffman codes of block type 1 (RFC 1951 §3.2.6), built into the caller's tables.
+SPZ_INF_HD void buildStatic(HuffLit *lit, HuffDist *dist) {
+  uint8_t l[288];
+  for (int i = 0; i < 144; ++i) l[i] = 8;
+  for (int i = 144; i < 256; ++i) l[i] = 9;
+  for (int i = 256; i < 280; ++i) l[i] = 7;
+  for (int i = 280; i < 288; ++i) l[i] = 8;
+  lit->build(l, 288);
+  lit->pack(false);
+  uint8_t d[30];
+  for (int i = 0; i < 30; ++i) d[i] = 5;
+  dist->build(d, 30);
+  dist->pack(true);
+}
+
+// Reads a dynamic block's code lengths (after the 3 header bits) and builds both decoders.
+SPZ_INF_HD bool readDynamic(const Bits &in, uint64_t *at, HuffLit *lit, HuffDist *dist) {
+  uint64_t pos = *at;
+  if (pos + 14 > in.nbits) return false;
+  uint64_t v = in.peek(pos);
+  const int hlit = static_cast<int>(v & 31) + 257, hdist = static_cast<int>((v >> 5) & 31) + 1,
+            hclen = static_cast<int>((v >> 10) & 15) + 4;
+  if (hlit > 286 || hdist > 30) return false;
+  pos += 14;
+  uint8_t cl[19] = {};
+  if (pos + 3 * static_cast<uint64_t>(hclen) > in.nbits) return false;
+  v = in.peek(pos);
+  for (int i = 0; i < hclen; ++i) {  // 19 * 3 = 57 bits: one peek is not always enough
+    if (i == 16) v = in.peek(pos + 48);
+    cl[clOrder(i)] = static_cast<uint8_t>((v >> (3 * (i & 15))) & 7);
+  }
+  pos += 3 * static_cast<uint64_t>(hclen);
+  HuffT<7, 19> clh;
+  if (!clh.build(cl, 19)) return false;
+  if (clh.ncodes < 1) return false;
+  uint8_t lens[286 + 30] = {};
+  int n = 0;
+  const int total = hlit + hdist;
+  while (n < total) {
+    if (pos >= in.nbits) return false;
+    v = in.peek(pos);
+    int len;
+    const int sym = clh.decode(v, &len);
+    if (sym < 0) return false;
+    v >>= len;
+    pos += static_cast<uint64_t>(len);
+    if (sym < 16) {
+      lens[n++] = static_cast<uint8_t>(sym);
+    } else {
+      int rep, val = 0;
+      if (sym == 16) {
+        if (n == 0) return false;
+        val = lens[n - 1];
+        rep = 3 + static_cast<int>(v & 3);
+        pos += 2;
+      } else if (sym == 17) {
+        rep = 3 + static_cast<int>(v & 7);
+        pos += 3;
+      } else {
+        rep = 11 + static_cast<int>(v & 127);
+        pos += 7;
+      }
+      if (n + rep > total) return false;
+      while (rep--) lens[n++] = static_cast<uint8_t>(val);
+    }
+  }
+  if (pos > in.nbits || lens[256] == 0) return false;
+  if (!lit->build(lens, hlit)) return false;
+  if (!dist->build(lens + hlit, hdist)) return false;
+  if (lit->ncodes < 2) return false;  // zlib never writes fewer; keeps the block-start search strict
+  lit->pack(false);
+  dist->pack(true);
+  *at = pos;
+  return true;
+}
+
+// ---- sinks ---------------------------------------------------------------------------------------------
+struct NullSink {  // block-start validation
+  uint64_t n;
+  SPZ_INF_HD bool lit(uint8_t) { ++n; return true; }
+  SPZ_INF_HD bool match(uint32_t len, uint32_t) { n += len; return true; }
+  SPZ_INF_HD bool raw(const uint8_t *, uint32_t len) { n += len; return true; }
+};
+
+
+template <class Sink>
+SPZ_INF_HD bool decodeHuffBlock(const Bits &in, uint64_t *at, const HuffLit &L, const HuffDist &D, Sink &sink) {
+  uint64_t pos = *at;
+  for (;;) {
+    if (pos >= in.nbits) return false;
+    uint64_t bits = in.peek(pos);  // >= 56 valid bits
+    uint32_t e = L.lookup(bits);
+    // up to three literals per refill (3 x 15 bits <= 56)
+    if (e & ENT_LITERAL) {
+      if (!sink.lit(static_cast<uint8_t>(e >> 16))) return false;
+      pos += e & 15u;
+      bits >>= e & 15u;
+      e = L.lookup(bits);
+      if (e & ENT_LITERAL) {
+        if (!sink.lit(static_cast<uint8_t>(e >> 16))) return false;
+        pos += e & 15u;
+        bits >>= e & 15u;
+        e = L.lookup(bits);
+        if (e & ENT_LITERAL) {
+          if (!sink.lit(static_cast<uint8_t>(e >> 16))) return false;
+          pos += e & 15u;
+        }
+      }
+      continue;  // refill before anything that needs more than a code
+    }
+    if (e == 0u || (e & ENT_INVALID)) return false;
+    uint32_t used = e & 15u;
+    if (e & ENT_EOB) {
+      pos += used;
+      if (pos > in.nbits) return false;
+      *at = pos;
+      return true;
+    }
+    bits >>= used;
+    const uint32_t lextra = (e >> 4) & 15u;
+    const uint32_t length = (e >> 16) + static_cast<uint32_t>(bits & ((1u << lextra) - 1u));
+    bits >>= lextra;
+    used += lextra;  // <= 20
+    const uint32_t d = D.lookup(bits);
+    if (d == 0u || (d & ENT_INVALID)) return false;
+    bits >>= d & 15u;
+    const uint32_t dextra = (d >> 4) & 15u;
+    const uint32_t dist = (d >> 16) + static_cast<uint32_t>(bits & ((1u << dextra) - 1u));
+    used += (d & 15u) + dextra;  // <= 48 of the >= 56 bits
+    pos += used;
+    if (pos > in.nbits) return false;
+    if (!sink.match(length, dist)) return false;
+  }
+}
+
+enum Outcome { FAILED, LINKED, FINAL };
+
+// Decodes whole blocks from `start` until a block would start at `stop` (LINKED) or the final block ends
+// (FINAL, *end = first bit after it).
+// `lit`, `dist`: the caller's table memory (14 KiB + 3 KiB).
+template <class Sink>
+SPZ_INF_HD Outcome decodeBlocks(const Bits &in, uint64_t start, uint64_t stop, Sink &sink, uint64_t *end, HuffLit *lit,
+                                HuffDist *dist) {
+  uint64_t pos = start;
+  for (;;) {
+    if (pos == stop) return LINKED;
+    if (pos > stop || pos + 3 > in.nbits) return FAILED;
+    const uint64_t v = in.peek(pos);
+    const bool final_block = v & 1;
+    const int type = static_cast<int>((v >> 1) & 3);
+    pos += 3;
+    if (type == 0) {
+      pos = (pos + 7) & ~uint64_t(7);
+      if (pos + 32 > in.nbits) return FAILED;
+      const uint64_t h = in.peek(pos);
+      const uint32_t len = static_cast<uint32_t>(h & 0xffff), nlen = static_cast<uint32_t>((h >> 16) & 0xffff);
+      if ((len ^ nlen) != 0xffff) return FAILED;
+      pos += 32;
+      if (pos + 8 * static_cast<uint64_t>(len) > in.nbits) return FAILED;
+      if (!sink.raw(in.p + (pos >> 3), len)) return FAILED;
+      pos += 8 * static_cast<uint64_t>(len);
+    } else if (type == 1) {
+      buildStatic(lit, dist);
+      if (!decodeHuffBlock(in, &pos, *lit, *dist, sink)) return FAILED;
+    } else if (type == 2) {
+      if (!readDynamic(in, &pos, lit, dist)) return FAILED;
+      if (!decodeHuffBlock(in, &pos, *lit, *dist, sink)) return FAILED;
+    } else {
+      return FAILED;
+    }
+    if (final_block) {
+      *end = pos;
+      return FINAL;
+    }
+  }
+}
+
+// The cheap part of the block-start test at bit position p: BFINAL = 0, BTYPE = 2, code counts in range and a
+// complete code-length code (zlib's always is: Kraft sum over its 3-bit lengths).
+SPZ_INF_HD bool plausibleDynamicHeader(const Bits &in, uint64_t p) {
+  const uint64_t v = in.peek(p);
+  if ((v & 7) != 4) return false;
+  if (((v >> 3) & 31) > 29 || ((v >> 8) & 31) > 29) return false;
+  const int hclen = static_cast<int>((v >> 13) & 15) + 4;
+  uint64_t c = v >> 17;  // 39+ valid bits = 13 lengths; the rest from a second peek
+  unsigned kraft = 0;
+  for (int i = 0; i < hclen; ++i) {
+    if (i == 13) c = in.peek(p + 17 + 39);
+    const unsigned l = static_cast<unsigned>(c & 7);
+    c >>= 3;
+    if (l) kraft += 128u >> l;
+  }
+  return kraft == 128;
+}
+
+// The full test: a non-final dynamic block starts at p, decodes to its end-of-block and is followed by a
+// plausible header.
+SPZ_INF_HD bool isBlockStart(const Bits &in, uint64_t p, HuffLit *lit, HuffDist *dist) {
+  if (p + 64 >= in.nbits || !plausibleDynamicHeader(in, p)) return false;
+  uint64_t pos = p + 3;
+  if (!readDynamic(in, &pos, lit, dist)) return false;
+  NullSink sink;
+  sink.n = 0;
+  if (!decodeHuffBlock(in, &pos, *lit, *dist, sink)) return false;
+  if (sink.n < 64) return false;                           // real blocks carry thousands of bytes
+  if (pos + 3 > in.nbits || ((in.peek(pos) >> 1) & 3) == 3) return false;
+  return true;
+}
+
+}  // namespace pinflate
+}  // namespace spz
