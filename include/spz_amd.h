@@ -368,6 +368,23 @@ int spz_amd_zlib_encode_blocks(void *ctx, const spz_amd_deflate_static *tables, 
                                uint64_t num_header_words, uint64_t body_bytes, uint8_t *h_body,
                                uint64_t *h_symbol_bits);
 
+/* ---- container stage, reading: inflate of one ordinary deflate stream on the device (spz_inflate_dev.hip).  The
+ *      reference's files are a single zlib stream (decompressGzipped, load-spz.cc:141-184); it is cut into 64 KiB
+ *      chunks whose block starts are found by search, decoded in parallel without their left context and resolved
+ *      afterwards (the scheme of spz_inflate.cpp).  h_deflate: the raw deflate data of a gzip member (after its
+ *      header, before its 8-byte trailer).  open: decodes; *out_bytes = size of the result, which stays on the
+ *      device.  piece_crcs: CRC-32 of consecutive pieces of crc_piece_bytes() of the result — the caller folds them
+ *      (crc32_combine) and compares with the trailer's CRC-32 and ISIZE before it believes the result.  fetch: the
+ *      bytes; device_data: the device pointer (a decode can read the stream where it is).  close: frees.
+ *      SPZ_AMD_ERR_UNSUPPORTED = declined (no usable block starts, chunks that do not link up, a chunk that expands
+ *      more than 8 x, not enough device memory): the caller's host readers take over.  Blocking. ------------------- */
+int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, void **ctx, uint64_t *out_bytes);
+uint32_t spz_amd_inflate_crc_piece_bytes(void);
+int spz_amd_inflate_piece_crcs(void *ctx, uint32_t *h_crcs, uint32_t capacity, uint32_t *num_pieces);
+int spz_amd_inflate_fetch(void *ctx, uint8_t *h_out);
+const uint8_t *spz_amd_inflate_device_data(void *ctx);
+void spz_amd_inflate_close(void *ctx);
+
 #ifdef __cplusplus
 }
 #endif

@@ -185,6 +185,9 @@ unsigned effectiveCpuCount();
 // environment SPZ_AMD_GZIP_DEVICE = 0 never, 1 always, unset: inputs of 8 MiB and more).  The bytes are zlib's
 // whichever way the parse ran; this says which way it was.
 uint64_t deviceGzipParseCount();
+// Members decompressGzipped has inflated on the device in this process (spz_inflate_dev.hip; SPZ_AMD_GUNZIP_DEVICE = 0
+// never, 1 from 1 MiB, unset: from 8 MiB); believed only after the CRC-32 and ISIZE of the trailer matched.
+uint64_t deviceInflateCount();
 // Status (spz_amd.h codes) of the last device call made by this thread; 0 = ok.
 int lastDeviceStatus();
 void setLastDeviceStatus(int status);

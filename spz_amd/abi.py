@@ -51,6 +51,8 @@ EXPORTS = (
     "spz_amd_ipc_alloc", "spz_amd_ipc_free", "spz_amd_ipc_open", "spz_amd_ipc_close",
     "spz_amd_zlib_parse_open", "spz_amd_zlib_parse_fetch", "spz_amd_zlib_parse_close",
     "spz_amd_zlib_parse_append", "spz_amd_zlib_block_stats", "spz_amd_zlib_encode_blocks",
+    "spz_amd_inflate_open", "spz_amd_inflate_crc_piece_bytes", "spz_amd_inflate_piece_crcs", "spz_amd_inflate_fetch",
+    "spz_amd_inflate_device_data", "spz_amd_inflate_close",
 )
 
 RCCL_UNIQUE_ID_BYTES = 128
@@ -213,6 +215,18 @@ def bind(L):
     L.spz_amd_zlib_parse_append.argtypes = [vp, vp, vp, u64]
     L.spz_amd_zlib_block_stats.restype = i32
     L.spz_amd_zlib_block_stats.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp]
+    L.spz_amd_inflate_open.restype = i32
+    L.spz_amd_inflate_open.argtypes = [vp, u64, i32, C.POINTER(vp), C.POINTER(u64)]
+    L.spz_amd_inflate_crc_piece_bytes.restype = u32
+    L.spz_amd_inflate_crc_piece_bytes.argtypes = []
+    L.spz_amd_inflate_piece_crcs.restype = i32
+    L.spz_amd_inflate_piece_crcs.argtypes = [vp, vp, u32, C.POINTER(u32)]
+    L.spz_amd_inflate_fetch.restype = i32
+    L.spz_amd_inflate_fetch.argtypes = [vp, vp]
+    L.spz_amd_inflate_device_data.restype = vp
+    L.spz_amd_inflate_device_data.argtypes = [vp]
+    L.spz_amd_inflate_close.restype = None
+    L.spz_amd_inflate_close.argtypes = [vp]
     L.spz_amd_zlib_encode_blocks.restype = i32
     L.spz_amd_zlib_encode_blocks.argtypes = [vp, vp, u32, u32, vp, vp, vp, u64, u64, vp, vp]
     return L

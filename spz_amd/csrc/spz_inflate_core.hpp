@@ -46,6 +46,9 @@ struct Bits {  // the deflate data of the member
   uint64_t nbits;
   size_t nbytes;
   // >= 56 valid bits starting at bit position `at` (zeros past the end)
+  SPZ_INF_HD const uint8_t *bytes(uint64_t byte_offset) const { return p + byte_offset; }
+  // a value every caller of one decoder agrees on (the device's lockstep decoder moves it to a scalar register)
+  SPZ_INF_HD uint32_t uniform(uint32_t v) const { return v; }
   SPZ_INF_HD uint64_t peek(uint64_t at) const {
     const size_t b = static_cast<size_t>(at >> 3);
     uint64_t v = 0;
@@ -165,7 +168,8 @@ using HuffLit = HuffT<FAST_L, 288>;
 using HuffDist = HuffT<FAST_D, 32>;
 
 // The fixed Huffman codes of block type 1 (RFC 1951 §3.2.6), built into the caller's tables.
-SPZ_INF_HD void buildStatic(HuffLit *lit, HuffDist *dist) {
+template <class HL, class HD>
+SPZ_INF_HD void buildStatic(HL *lit, HD *dist) {
   uint8_t l[288];
   for (int i = 0; i < 144; ++i) l[i] = 8;
   for (int i = 144; i < 256; ++i) l[i] = 9;
@@ -179,8 +183,26 @@ SPZ_INF_HD void buildStatic(HuffLit *lit, HuffDist *dist) {
   dist->pack(true);
 }
 
-// Reads a dynamic block's code lengths (after the 3 header bits) and builds both decoders.
-SPZ_INF_HD bool readDynamic(const Bits &in, uint64_t *at, HuffLit *lit, HuffDist *dist) {
+// Same acceptance rule as HuffT::build(): not over-subscribed, and complete unless it has at most one code.
+SPZ_INF_HD bool completeCode(const uint8_t *lens, int n, int *ncodes) {
+  int count[16];
+  for (int i = 0; i < 16; ++i) count[i] = 0;
+  for (int i = 0; i < n; ++i) count[lens[i]]++;
+  const int codes = n - count[0];
+  int left = 1;
+  for (int len = 1; len <= 15; ++len) {
+    left <<= 1;
+    left -= count[len];
+    if (left < 0) return false;
+  }
+  *ncodes = codes;
+  return !(left > 0 && codes != 1 && codes != 0);
+}
+
+// Reads a dynamic block's code lengths (after the 3 header bits): lens[0 .. hlit) literal/length, lens[hlit .. hlit + hdist)
+// distance codes.
+template <class In>
+SPZ_INF_HD bool readCodeLengths(const In &in, uint64_t *at, uint8_t *lens, int *hlit_out, int *hdist_out) {
   uint64_t pos = *at;
   if (pos + 14 > in.nbits) return false;
   uint64_t v = in.peek(pos);
@@ -188,7 +210,8 @@ SPZ_INF_HD bool readDynamic(const Bits &in, uint64_t *at, HuffLit *lit, HuffDist
             hclen = static_cast<int>((v >> 10) & 15) + 4;
   if (hlit > 286 || hdist > 30) return false;
   pos += 14;
-  uint8_t cl[19] = {};
+  uint8_t cl[19];
+  for (int i = 0; i < 19; ++i) cl[i] = 0;
   if (pos + 3 * static_cast<uint64_t>(hclen) > in.nbits) return false;
   v = in.peek(pos);
   for (int i = 0; i < hclen; ++i) {  // 19 * 3 = 57 bits: one peek is not always enough
@@ -199,9 +222,9 @@ SPZ_INF_HD bool readDynamic(const Bits &in, uint64_t *at, HuffLit *lit, HuffDist
   HuffT<7, 19> clh;
   if (!clh.build(cl, 19)) return false;
   if (clh.ncodes < 1) return false;
-  uint8_t lens[286 + 30] = {};
   int n = 0;
   const int total = hlit + hdist;
+  for (int i = 0; i < 286 + 30; ++i) lens[i] = 0;
   while (n < total) {
     if (pos >= in.nbits) return false;
     v = in.peek(pos);
@@ -231,6 +254,19 @@ SPZ_INF_HD bool readDynamic(const Bits &in, uint64_t *at, HuffLit *lit, HuffDist
     }
   }
   if (pos > in.nbits || lens[256] == 0) return false;
+  *hlit_out = hlit;
+  *hdist_out = hdist;
+  *at = pos;
+  return true;
+}
+
+// ... and builds both decoders.
+template <class In, class HL, class HD>
+SPZ_INF_HD bool readDynamic(const In &in, uint64_t *at, HL *lit, HD *dist) {
+  uint8_t lens[286 + 30];
+  int hlit = 0, hdist = 0;
+  uint64_t pos = *at;
+  if (!readCodeLengths(in, &pos, lens, &hlit, &hdist)) return false;
   if (!lit->build(lens, hlit)) return false;
   if (!dist->build(lens + hlit, hdist)) return false;
   if (lit->ncodes < 2) return false;  // zlib never writes fewer; keeps the block-start search strict
@@ -249,24 +285,24 @@ struct NullSink {  // block-start validation
 };
 
 
-template <class Sink>
-SPZ_INF_HD bool decodeHuffBlock(const Bits &in, uint64_t *at, const HuffLit &L, const HuffDist &D, Sink &sink) {
+template <class In, class HL, class HD, class Sink>
+SPZ_INF_HD bool decodeHuffBlock(const In &in, uint64_t *at, const HL &L, const HD &D, Sink &sink) {
   uint64_t pos = *at;
   for (;;) {
     if (pos >= in.nbits) return false;
     uint64_t bits = in.peek(pos);  // >= 56 valid bits
-    uint32_t e = L.lookup(bits);
+    uint32_t e = in.uniform(L.lookup(bits));
     // up to three literals per refill (3 x 15 bits <= 56)
     if (e & ENT_LITERAL) {
       if (!sink.lit(static_cast<uint8_t>(e >> 16))) return false;
       pos += e & 15u;
       bits >>= e & 15u;
-      e = L.lookup(bits);
+      e = in.uniform(L.lookup(bits));
       if (e & ENT_LITERAL) {
         if (!sink.lit(static_cast<uint8_t>(e >> 16))) return false;
         pos += e & 15u;
         bits >>= e & 15u;
-        e = L.lookup(bits);
+        e = in.uniform(L.lookup(bits));
         if (e & ENT_LITERAL) {
           if (!sink.lit(static_cast<uint8_t>(e >> 16))) return false;
           pos += e & 15u;
@@ -287,7 +323,7 @@ SPZ_INF_HD bool decodeHuffBlock(const Bits &in, uint64_t *at, const HuffLit &L, 
     const uint32_t length = (e >> 16) + static_cast<uint32_t>(bits & ((1u << lextra) - 1u));
     bits >>= lextra;
     used += lextra;  // <= 20
-    const uint32_t d = D.lookup(bits);
+    const uint32_t d = in.uniform(D.lookup(bits));
     if (d == 0u || (d & ENT_INVALID)) return false;
     bits >>= d & 15u;
     const uint32_t dextra = (d >> 4) & 15u;
@@ -304,9 +340,8 @@ enum Outcome { FAILED, LINKED, FINAL };
 // Decodes whole blocks from `start` until a block would start at `stop` (LINKED) or the final block ends
 // (FINAL, *end = first bit after it).
 // `lit`, `dist`: the caller's table memory (14 KiB + 3 KiB).
-template <class Sink>
-SPZ_INF_HD Outcome decodeBlocks(const Bits &in, uint64_t start, uint64_t stop, Sink &sink, uint64_t *end, HuffLit *lit,
-                                HuffDist *dist) {
+template <class In, class HL, class HD, class Sink>
+SPZ_INF_HD Outcome decodeBlocks(const In &in, uint64_t start, uint64_t stop, Sink &sink, uint64_t *end, HL *lit, HD *dist) {
   uint64_t pos = start;
   for (;;) {
     if (pos == stop) return LINKED;
@@ -323,7 +358,7 @@ SPZ_INF_HD Outcome decodeBlocks(const Bits &in, uint64_t start, uint64_t stop, S
       if ((len ^ nlen) != 0xffff) return FAILED;
       pos += 32;
       if (pos + 8 * static_cast<uint64_t>(len) > in.nbits) return FAILED;
-      if (!sink.raw(in.p + (pos >> 3), len)) return FAILED;
+      if (!sink.raw(in.bytes(pos >> 3), len)) return FAILED;
       pos += 8 * static_cast<uint64_t>(len);
     } else if (type == 1) {
       buildStatic(lit, dist);
@@ -343,7 +378,8 @@ SPZ_INF_HD Outcome decodeBlocks(const Bits &in, uint64_t start, uint64_t stop, S
 
 // The cheap part of the block-start test at bit position p: BFINAL = 0, BTYPE = 2, code counts in range and a
 // complete code-length code (zlib's always is: Kraft sum over its 3-bit lengths).
-SPZ_INF_HD bool plausibleDynamicHeader(const Bits &in, uint64_t p) {
+template <class In>
+SPZ_INF_HD bool plausibleDynamicHeader(const In &in, uint64_t p) {
   const uint64_t v = in.peek(p);
   if ((v & 7) != 4) return false;
   if (((v >> 3) & 31) > 29 || ((v >> 8) & 31) > 29) return false;
@@ -359,9 +395,23 @@ SPZ_INF_HD bool plausibleDynamicHeader(const Bits &in, uint64_t p) {
   return kraft == 128;
 }
 
+// Header and both code-length sets valid — exactly what readDynamic() accepts, without building tables or decoding
+// the block: what the device's search takes; the chunk before it has to end exactly there, which is the rest of
+// the proof.
+template <class In>
+SPZ_INF_HD bool hasValidDynamicHeader(const In &in, uint64_t p) {
+  if (p + 64 >= in.nbits || !plausibleDynamicHeader(in, p)) return false;
+  uint64_t pos = p + 3;
+  uint8_t lens[286 + 30];
+  int hlit = 0, hdist = 0, nl = 0, nd = 0;
+  if (!readCodeLengths(in, &pos, lens, &hlit, &hdist)) return false;
+  return completeCode(lens, hlit, &nl) && completeCode(lens + hlit, hdist, &nd) && nl >= 2;
+}
+
 // The full test: a non-final dynamic block starts at p, decodes to its end-of-block and is followed by a
 // plausible header.
-SPZ_INF_HD bool isBlockStart(const Bits &in, uint64_t p, HuffLit *lit, HuffDist *dist) {
+template <class In, class HL, class HD>
+SPZ_INF_HD bool isBlockStart(const In &in, uint64_t p, HL *lit, HD *dist) {
   if (p + 64 >= in.nbits || !plausibleDynamicHeader(in, p)) return false;
   uint64_t pos = p + 3;
   if (!readDynamic(in, &pos, lit, dist)) return false;

@@ -1,0 +1,518 @@
+// spz_inflate_dev.hip — inflate of a single, ordinary deflate stream on the MI355X (include/spz_amd.h:
+// spz_amd_inflate_*).  The files the reference writes are one zlib stream with no index (load-spz.cc:141-184 reads
+// them with one inflate loop); a deflate stream can still be decoded in parallel (pugz, Kerbiriou & Chikhi 2019;
+// the host version is spz_inflate.cpp), and the decoder source is the same here (spz_inflate_core.hpp):
+//
+//   inf_search_kernel   one workgroup per 64 KiB of compressed bytes: all threads test bit positions for a dynamic
+//                       block header (type bits, code counts, a complete code-length code); thread 0 takes the
+//                       candidates in order and accepts the first whose two code-length sets are valid.
+//   inf_decode_kernel   one wave per chunk, its 64 lanes in lockstep (tables and 2 KiB of compressed bytes in LDS; a
+//                       match is copied by as many lanes as it is long):
+//                       from its block start to the next chunk's — they must link up bit-exactly — into 16-bit
+//                       symbols: a byte, or 256 + k = "byte k of the 32 KiB before this chunk", which the chunk
+//                       does not have.
+//   inf_window_kernel   one workgroup walks the chunks in order and resolves each chunk's final 32 KiB against its
+//                       predecessor's (kept in LDS): the only serial step.
+//   inf_place_kernel    symbols -> bytes at their final offsets, references resolved from the predecessor's window.
+//   inf_crc_kernel      CRC-32 of 256 KiB pieces (the caller folds them with crc32_combine and compares with the
+//                       member's trailer: the result can only be right or refused).
+// Anything irregular (a chunk that does not link, a reference where there is no predecessor, a chunk that expands
+// more than 8x, stored-only data with no block starts) declines: the caller's host readers take over.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <new>
+#include <vector>
+
+#include "spz_amd.h"
+#include "spz_common.hpp"
+#include "spz_inflate_core.hpp"
+
+namespace spz_amd_detail {
+namespace {
+
+using namespace spz::pinflate;
+
+constexpr uint32_t kChunkBytes = 65536;    // compressed bytes per chunk
+constexpr uint32_t kSearchBytes = 131072;  // how far past its chunk's first byte a block start is looked for
+constexpr uint32_t kExpand = 8;            // symbols a chunk may produce per compressed byte
+constexpr uint32_t kCrcPiece = 262144;
+constexpr uint32_t kMaxCand = 192;
+constexpr uint32_t kSearchPerThread = 64;  // bit positions a thread tests per round
+
+// Tables of the device decoder: 9- and 7-bit fast tables (4.7 + 1 KiB per wave: the decode is bound by the latency
+// of its match copies, so what counts is how many waves a CU holds; longer codes take the canonical walk).
+using DevLit = HuffT<9, 288>;
+using DevDist = HuffT<7, 32>;
+struct alignas(16) Tables {
+  DevLit lit;
+  DevDist dist;
+};
+constexpr uint32_t kWinBytes = 1024;  // compressed bytes a wave keeps in LDS around its bit position
+
+// ---- search -----------------------------------------------------------------------------------------------
+// 128 input bits in registers: what the cheap header test of 16 neighbouring bit positions needs (at most 74 bits each).
+struct RegBits {
+  uint64_t lo, hi;     // the bits from bit position `base` on
+  uint64_t base, nbits;
+  __device__ __forceinline__ uint32_t uniform(uint32_t v) const { return v; }
+  __device__ __forceinline__ uint64_t peek(uint64_t at) const {
+    const uint32_t s = (uint32_t)(at - base);  // < 128
+    if (s == 0) return lo;
+    if (s < 64) return (lo >> s) | (hi << (64u - s));
+    return s < 128 ? hi >> (s - 64u) : 0ull;
+  }
+};
+
+__global__ __launch_bounds__(256) void inf_search_kernel(const uint8_t *__restrict__ d, uint64_t nbytes, uint32_t n_chunks,
+                                                         unsigned long long *__restrict__ starts) {
+  __shared__ unsigned long long cand[kMaxCand];
+  __shared__ uint32_t ncand;
+  __shared__ unsigned long long found;
+  const uint32_t tid = threadIdx.x, chunk = blockIdx.x + 1;  // chunk 0 starts at bit 0
+  if (chunk >= n_chunks) return;
+  const Bits in = {d, 8ull * nbytes, (size_t)nbytes};
+  const uint64_t lo = 8ull * kChunkBytes * chunk;
+  uint64_t hi = lo + 8ull * kSearchBytes;
+  if (hi > in.nbits) hi = in.nbits;
+  if (tid == 0) found = NONE;
+  __syncthreads();
+  for (uint64_t base = lo; base < hi; base += 256 * kSearchPerThread) {
+    if (tid == 0) ncand = 0;
+    __syncthreads();
+    {
+      // 16 bit positions at a time: they start at a byte boundary, and 16 bytes from there cover every test (padded data)
+      for (uint32_t g = 0; g < kSearchPerThread / 16; ++g) {
+        const uint64_t p0 = base + ((uint64_t)tid * (kSearchPerThread / 16) + g) * 16;
+        RegBits rb;
+        __builtin_memcpy(&rb.lo, d + (p0 >> 3), 8);
+        __builtin_memcpy(&rb.hi, d + (p0 >> 3) + 8, 8);
+        rb.base = p0;
+        rb.nbits = in.nbits;
+        for (uint32_t k = 0; k < 16; ++k) {
+          const uint64_t p = p0 + k;
+          if (p < hi && p + 64 < in.nbits && plausibleDynamicHeader(rb, p)) {
+            const uint32_t slot = atomicAdd(&ncand, 1u);
+            if (slot < kMaxCand) cand[slot] = p;
+          }
+        }
+      }
+    }
+    __syncthreads();
+    // one candidate per thread: header and both code-length sets valid?  The lowest position that is wins.
+    const uint32_t n = ncand < kMaxCand ? ncand : kMaxCand;
+    if (tid < n && hasValidDynamicHeader(in, cand[tid])) atomicMin(&found, cand[tid]);
+    __syncthreads();
+    if (found != NONE) break;
+    if (ncand > kMaxCand) {  // too many look-alikes to be sure none was missed: no start for this chunk
+      break;
+    }
+  }
+  if (tid == 0) starts[chunk] = found;
+}
+
+// ---- decode -----------------------------------------------------------------------------------------------
+struct ChunkJob {
+  unsigned long long from, to;      // bit positions: first block, the next chunk's first block (NONE: to the final block)
+  unsigned long long region;        // first symbol of the chunk's region
+  unsigned long long capacity;      // symbols
+};
+struct ChunkResult {
+  unsigned long long length;        // symbols produced
+  unsigned long long end_bit;       // FINAL: first bit after the final block
+  uint32_t outcome;                 // Outcome
+  uint32_t overflow;
+};
+
+// The wave's view of the deflate data: all 64 lanes run the decoder in lockstep (same bits, same decisions), the
+// compressed bytes around the current position are kept in LDS and refilled by all lanes (16 bytes each).
+struct WaveBits {
+  const uint8_t *p;
+  uint64_t nbits;
+  size_t nbytes;
+  uint32_t *win;             // LDS: kWinBytes + 16 bytes
+  uint32_t lane;
+  mutable uint64_t win_lo;   // byte offset of win[0], a multiple of 16; ~0: nothing loaded
+  __device__ __forceinline__ const uint8_t *bytes(uint64_t byte_offset) const { return p + byte_offset; }
+  __device__ __forceinline__ uint32_t uniform(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
+  __device__ __forceinline__ uint64_t peek(uint64_t at) const {
+    const uint64_t b = at >> 3;
+    if (b < win_lo || b + 12 > win_lo + kWinBytes) {
+      win_lo = b & ~15ull;   // the allocation is padded: reads past the end see zeros
+      const uint4 *src = reinterpret_cast<const uint4 *>(p + win_lo);
+      uint4 *dst = reinterpret_cast<uint4 *>(win);
+      for (uint32_t i = lane; i < kWinBytes / 16; i += 64) dst[i] = src[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const uint32_t off = (uint32_t)(b - win_lo);
+    const uint32_t w0 = uniform(win[off >> 2]), w1 = uniform(win[(off >> 2) + 1]), w2 = uniform(win[(off >> 2) + 2]);
+    const uint32_t s = (off & 3u) * 8u;
+    uint64_t v = ((uint64_t)w0 | ((uint64_t)w1 << 32)) >> s;
+    if (s) v |= (uint64_t)w2 << (64u - s);
+    return v >> (at & 7);    // >= 56 valid bits
+  }
+};
+
+// Symbols go straight to the chunk's region in HBM: literals by lane 0, matches by as many lanes as they are long
+// (one load and one store for the wave instead of a round trip per symbol).  A ring of recent symbols in LDS with
+// block-wise flushes was tried: it costs registers (occupancy 2 waves per SIMD instead of 6) and a wave's speed here
+// is set by its instruction stream, not by these loads and stores (profiles/r02_device_inflate.txt).
+struct WaveSymbolSink {
+  uint16_t *sym;   // sym[i] = symbol of the chunk's byte i
+  uint64_t cap, n;
+  uint32_t lane;
+  bool overflow;
+  __device__ __forceinline__ bool lit(uint8_t b) {
+    if (n >= cap) {
+      overflow = true;
+      return false;
+    }
+    if (lane == 0) sym[n] = b;
+    ++n;
+    return true;
+  }
+  __device__ __forceinline__ bool match(uint32_t len, uint32_t dist) {
+    if (n + len > cap) {
+      overflow = true;
+      return false;
+    }
+    // byte n + i is byte n + i - dist, which for an overlapping copy is byte n - dist + (i mod dist): never one of this
+    // match's own; a source before the chunk's first byte is byte W + (index) of the predecessor's final window
+    for (uint32_t base = 0; base < len; base += 64) {
+      const uint32_t i = base + lane;
+      if (i < len) {
+        const long long src = (long long)n - (long long)dist + (long long)(dist < len ? i % dist : i);
+        sym[n + i] = src >= 0 ? sym[src] : (uint16_t)(256 + W + src);
+      }
+    }
+    n += len;
+    return true;
+  }
+  __device__ __forceinline__ bool raw(const uint8_t *src, uint32_t len) {
+    if (n + len > cap) {
+      overflow = true;
+      return false;
+    }
+    for (uint32_t i = lane; i < len; i += 64) sym[n + i] = src[i];
+    n += len;
+    return true;
+  }
+};
+
+__global__ __launch_bounds__(64, 6) void inf_decode_kernel(const uint8_t *__restrict__ d, uint64_t nbytes,
+                                                        const ChunkJob *__restrict__ jobs, uint16_t *symbols,
+                                                        ChunkResult *__restrict__ results) {
+  __shared__ Tables tb;
+  __shared__ uint32_t s_win[kWinBytes / 4 + 4];
+  const ChunkJob job = jobs[blockIdx.x];
+  const WaveBits in = {d, 8ull * nbytes, (size_t)nbytes, s_win, threadIdx.x, ~0ull};
+  WaveSymbolSink sink = {symbols + job.region, job.capacity, 0, threadIdx.x, false};
+  uint64_t end = 0;
+  const Outcome r = decodeBlocks(in, job.from, job.to, sink, &end, &tb.lit, &tb.dist);
+  if (threadIdx.x == 0) {
+    ChunkResult &o = results[blockIdx.x];
+    o.length = sink.n;
+    o.end_bit = end;
+    o.outcome = (uint32_t)r;
+    o.overflow = sink.overflow ? 1u : 0u;
+  }
+}
+
+// ---- windows ----------------------------------------------------------------------------------------------
+struct ChunkPlace {
+  unsigned long long region, length, offset;  // symbols at `region`, bytes at `offset`
+};
+
+__global__ __launch_bounds__(1024) void inf_window_kernel(const uint16_t *__restrict__ symbols, const ChunkPlace *__restrict__ chunks,
+                                                          uint32_t n_chunks, uint8_t *__restrict__ windows, uint32_t *__restrict__ bad) {
+  __shared__ uint8_t win[2][W];
+  const uint32_t tid = threadIdx.x;
+  uint32_t cur = 0, broken = 0;
+  for (uint32_t c = 0; c < n_chunks; ++c) {
+    const ChunkPlace ch = chunks[c];
+    const uint16_t *sym = symbols + ch.region;
+    const uint8_t *prev = win[cur ^ 1];
+    uint8_t *mine = win[cur];
+    uint32_t sy[W / 1024];
+#pragma unroll
+    for (uint32_t q = 0; q < W / 1024; ++q) {  // all loads of the step in flight together
+      const long long idx = (long long)ch.length - (long long)W + (tid + q * 1024);
+      sy[q] = idx >= 0 ? (uint32_t)sym[idx] : 0xffffffffu;
+    }
+#pragma unroll
+    for (uint32_t q = 0; q < W / 1024; ++q) {
+      const uint32_t k = tid + q * 1024;
+      const uint32_t s = sy[q];
+      uint32_t b;
+      if (s < 256) {
+        b = s;
+      } else {
+        if (c == 0) broken = 1;  // the first chunk has nothing before it
+        // a reference, or (a chunk shorter than the window) the predecessor's own bytes moving up
+        b = s != 0xffffffffu ? prev[s - 256] : prev[(uint32_t)((long long)ch.length + k)];
+      }
+      mine[k] = (uint8_t)b;
+      windows[(size_t)c * W + k] = (uint8_t)b;
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  if (broken) atomicOr(bad, 1u);
+}
+
+// ---- place ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void inf_place_kernel(const uint16_t *__restrict__ symbols, const ChunkPlace *__restrict__ chunks,
+                                                        const uint8_t *__restrict__ windows, uint8_t *__restrict__ out,
+                                                        uint32_t *__restrict__ bad) {
+  const uint32_t c = blockIdx.y;
+  const ChunkPlace ch = chunks[c];
+  const uint16_t *sym = symbols + ch.region;
+  const uint8_t *prev = c ? windows + (size_t)(c - 1) * W : nullptr;
+  uint8_t *dst = out + ch.offset;
+  uint32_t broken = 0;
+  for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < ch.length; i += (unsigned long long)gridDim.x * 256) {
+    const uint32_t s = sym[i];
+    uint32_t b = s;
+    if (s >= 256) {
+      if (prev) b = prev[s - 256];
+      else broken = 1;
+    }
+    dst[i] = (uint8_t)b;
+  }
+  if (broken) atomicOr(bad, 1u);
+}
+
+// ---- CRC-32 (IEEE 802.3, the one gzip uses) of pieces ------------------------------------------------------------
+__global__ __launch_bounds__(64) void inf_crc_kernel(const uint8_t *__restrict__ data, uint64_t nbytes, uint32_t piece,
+                                                     uint32_t *__restrict__ crcs) {
+  __shared__ uint32_t table[256];
+  for (uint32_t i = threadIdx.x; i < 256; i += 64) {
+    uint32_t c = i;
+    for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
+    table[i] = c;
+  }
+  __syncthreads();
+  const uint64_t idx = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  const uint64_t lo = idx * piece;
+  if (lo >= nbytes) return;
+  const uint64_t hi = lo + piece < nbytes ? lo + piece : nbytes;
+  uint32_t c = 0xffffffffu;
+  uint64_t p = lo;
+  auto eat = [&](uint32_t w) {
+    c ^= w;
+    c = table[c & 0xffu] ^ (c >> 8);
+    c = table[c & 0xffu] ^ (c >> 8);
+    c = table[c & 0xffu] ^ (c >> 8);
+    c = table[c & 0xffu] ^ (c >> 8);
+  };
+  for (; p + 64 <= hi; p += 64) {  // pieces start 256-byte aligned
+    const uint4 *q = reinterpret_cast<const uint4 *>(data + p);
+    const uint4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
+    eat(a0.x); eat(a0.y); eat(a0.z); eat(a0.w);
+    eat(a1.x); eat(a1.y); eat(a1.z); eat(a1.w);
+    eat(a2.x); eat(a2.y); eat(a2.z); eat(a2.w);
+    eat(a3.x); eat(a3.y); eat(a3.z); eat(a3.w);
+  }
+  for (; p < hi; ++p) c = table[(c ^ data[p]) & 0xffu] ^ (c >> 8);
+  crcs[idx] = c ^ 0xffffffffu;
+}
+
+struct InfContext {
+  int device = 0;
+  char *block = nullptr;
+  uint8_t *out = nullptr;
+  uint64_t out_bytes = 0;
+  uint32_t *crcs = nullptr;
+  uint32_t n_pieces = 0;
+};
+
+size_t round256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+}  // namespace spz_amd_detail
+
+using namespace spz_amd_detail;
+
+extern "C" {
+
+int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, void **ctx, uint64_t *out_bytes) {
+  if (h_deflate == nullptr || ctx == nullptr || out_bytes == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  *ctx = nullptr;
+  if (nbytes < 4ull * kChunkBytes || nbytes >= (1ull << 32)) return SPZ_AMD_ERR_UNSUPPORTED;
+  if (((h_deflate[0] >> 1) & 3) == 0) return SPZ_AMD_ERR_UNSUPPORTED;  // opens with a stored block: nothing to gain
+  DeviceGuard guard;
+  int rc = guard.enter(device);
+  if (rc != SPZ_AMD_OK) return rc;
+  static const bool timing = std::getenv("SPZ_AMD_LZ_TIMING") != nullptr;
+  auto t_prev = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (!timing) return;
+    (void)hipDeviceSynchronize();
+    const auto now = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[inflate] %-8s %.4f s\n", what, std::chrono::duration<double>(now - t_prev).count());
+    t_prev = now;
+  };
+  const uint32_t n_chunks = (uint32_t)(nbytes / kChunkBytes);  // the last one takes the remainder
+  // one allocation: the deflate data, block starts, jobs/results/places, symbols, windows; the output and CRCs later
+  const size_t sym_capacity = (size_t)nbytes * kExpand + (size_t)n_chunks * 128;
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    const size_t at = off;
+    off += round256(bytes);
+    return at;
+  };
+  const size_t o_data = carve(nbytes + kWinBytes + 64);
+  const size_t o_starts = carve((size_t)n_chunks * sizeof(unsigned long long));
+  const size_t o_jobs = carve((size_t)n_chunks * sizeof(ChunkJob));
+  const size_t o_res = carve((size_t)n_chunks * sizeof(ChunkResult));
+  const size_t o_place = carve((size_t)n_chunks * sizeof(ChunkPlace));
+  const size_t o_bad = carve(256);
+  const size_t o_win = carve((size_t)n_chunks * W);
+  const size_t o_sym = carve(sym_capacity * sizeof(uint16_t));
+  const size_t total = off;
+  size_t free_b = 0, total_b = 0;
+  SPZ_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  if (total + (size_t)nbytes * kExpand + (size_t(512) << 20) > free_b) return SPZ_AMD_ERR_UNSUPPORTED;
+  char *block = nullptr;
+  SPZ_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&block), total));
+  struct Free {
+    char *p;
+    ~Free() {
+      if (p) (void)hipFree(p);
+    }
+  } holder{block};
+  uint8_t *d_data = reinterpret_cast<uint8_t *>(block + o_data);
+  unsigned long long *d_starts = reinterpret_cast<unsigned long long *>(block + o_starts);
+  ChunkJob *d_jobs = reinterpret_cast<ChunkJob *>(block + o_jobs);
+  ChunkResult *d_res = reinterpret_cast<ChunkResult *>(block + o_res);
+  ChunkPlace *d_place = reinterpret_cast<ChunkPlace *>(block + o_place);
+  uint32_t *d_bad = reinterpret_cast<uint32_t *>(block + o_bad);
+  uint8_t *d_win = reinterpret_cast<uint8_t *>(block + o_win);
+  uint16_t *d_sym = reinterpret_cast<uint16_t *>(block + o_sym);
+  hipStream_t st = nullptr;
+  SPZ_HIP_TRY(hipMemcpyAsync(d_data, h_deflate, nbytes, hipMemcpyHostToDevice, st));
+  SPZ_HIP_TRY(hipMemsetAsync(d_data + nbytes, 0, kWinBytes + 64, st));
+  SPZ_HIP_TRY(hipMemsetAsync(d_bad, 0, 256, st));
+  lap("upload");
+  // ---- 1. block starts
+  hipLaunchKernelGGL(inf_search_kernel, dim3(n_chunks - 1), dim3(256), 0, st, d_data, nbytes, n_chunks, d_starts);
+  SPZ_HIP_TRY(hipGetLastError());
+  std::vector<unsigned long long> starts(n_chunks);
+  SPZ_HIP_TRY(hipMemcpyAsync(starts.data(), d_starts, (size_t)n_chunks * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  SPZ_HIP_TRY(hipStreamSynchronize(st));
+  starts[0] = 0;
+  lap("search");
+  std::vector<ChunkJob> jobs;
+  jobs.reserve(n_chunks);
+  for (uint32_t i = 0; i < n_chunks; ++i) {
+    if (starts[i] == NONE) continue;
+    if (!jobs.empty() && starts[i] <= jobs.back().from) continue;  // found again from the chunk before: one job
+    jobs.push_back({starts[i], NONE, 0, 0});
+  }
+  const uint32_t n = (uint32_t)jobs.size();
+  if (n < 2 || n * 2 < n_chunks) return SPZ_AMD_ERR_UNSUPPORTED;  // mostly stored / static data: no gain
+  unsigned long long region = 0;
+  for (uint32_t j = 0; j < n; ++j) {
+    jobs[j].to = (j + 1 < n) ? jobs[j + 1].from : NONE;
+    const unsigned long long span_bits = (j + 1 < n ? jobs[j + 1].from : 8ull * nbytes) - jobs[j].from;
+    jobs[j].region = region;
+    jobs[j].capacity = ((span_bits / 8 + 1) * kExpand + 32 + 63) / 64 * 64;  // regions stay 128-byte aligned
+    region += jobs[j].capacity;
+  }
+  if (region > sym_capacity) return SPZ_AMD_ERR_UNSUPPORTED;
+  SPZ_HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), (size_t)n * sizeof(ChunkJob), hipMemcpyHostToDevice, st));
+  // ---- 2. decode
+  hipLaunchKernelGGL(inf_decode_kernel, dim3(n), dim3(64), 0, st, d_data, nbytes, d_jobs, d_sym, d_res);
+  SPZ_HIP_TRY(hipGetLastError());
+  std::vector<ChunkResult> res(n);
+  SPZ_HIP_TRY(hipMemcpyAsync(res.data(), d_res, (size_t)n * sizeof(ChunkResult), hipMemcpyDeviceToHost, st));
+  SPZ_HIP_TRY(hipStreamSynchronize(st));
+  lap("decode");
+  std::vector<ChunkPlace> place(n);
+  unsigned long long offset = 0;
+  for (uint32_t j = 0; j < n; ++j) {
+    if (res[j].overflow || res[j].outcome != (uint32_t)(j + 1 < n ? LINKED : FINAL)) return SPZ_AMD_ERR_UNSUPPORTED;
+    place[j] = {jobs[j].region, res[j].length, offset};
+    offset += res[j].length;
+  }
+  if (((res[n - 1].end_bit + 7) >> 3) != nbytes) return SPZ_AMD_ERR_UNSUPPORTED;  // the stream must end exactly at the trailer
+  const uint64_t total_out = offset;
+  if (total_out == 0) return SPZ_AMD_ERR_UNSUPPORTED;
+  SPZ_HIP_TRY(hipMemcpyAsync(d_place, place.data(), (size_t)n * sizeof(ChunkPlace), hipMemcpyHostToDevice, st));
+  // ---- 3. windows, 4. place, 5. piece CRCs
+  const uint32_t n_pieces = (uint32_t)((total_out + kCrcPiece - 1) / kCrcPiece);
+  char *outblock = nullptr;
+  const size_t out_alloc = round256(total_out + 64) + round256((size_t)n_pieces * sizeof(uint32_t));
+  SPZ_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&outblock), out_alloc));
+  Free holder2{outblock};
+  uint8_t *d_out = reinterpret_cast<uint8_t *>(outblock);
+  uint32_t *d_crcs = reinterpret_cast<uint32_t *>(outblock + round256(total_out + 64));
+  hipLaunchKernelGGL(inf_window_kernel, dim3(1), dim3(1024), 0, st, d_sym, d_place, n, d_win, d_bad);
+  SPZ_HIP_TRY(hipGetLastError());
+  lap("windows");
+  hipLaunchKernelGGL(inf_place_kernel, dim3(16, n), dim3(256), 0, st, d_sym, d_place, d_win, d_out, d_bad);
+  SPZ_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(inf_crc_kernel, dim3((n_pieces + 63) / 64), dim3(64), 0, st, d_out, total_out, kCrcPiece, d_crcs);
+  SPZ_HIP_TRY(hipGetLastError());
+  uint32_t bad = 0;
+  SPZ_HIP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, st));
+  SPZ_HIP_TRY(hipStreamSynchronize(st));
+  lap("place+crc");
+  if (bad) return SPZ_AMD_ERR_UNSUPPORTED;
+  InfContext *c = new (std::nothrow) InfContext();
+  if (c == nullptr) return SPZ_AMD_ERR_HIP;
+  c->device = device;
+  c->block = outblock;
+  holder2.p = nullptr;  // the scratch block goes now, the output stays with the context
+  c->out = d_out;
+  c->out_bytes = total_out;
+  c->crcs = d_crcs;
+  c->n_pieces = n_pieces;
+  *ctx = c;
+  *out_bytes = total_out;
+  return SPZ_AMD_OK;
+}
+
+uint32_t spz_amd_inflate_crc_piece_bytes(void) { return kCrcPiece; }
+
+int spz_amd_inflate_piece_crcs(void *ctx, uint32_t *h_crcs, uint32_t capacity, uint32_t *num_pieces) {
+  InfContext *c = static_cast<InfContext *>(ctx);
+  if (c == nullptr || h_crcs == nullptr || num_pieces == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  *num_pieces = c->n_pieces;
+  if (capacity < c->n_pieces) return SPZ_AMD_ERR_CAPACITY;
+  DeviceGuard guard;
+  int rc = guard.enter(c->device);
+  if (rc != SPZ_AMD_OK) return rc;
+  SPZ_HIP_TRY(hipMemcpy(h_crcs, c->crcs, (size_t)c->n_pieces * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return SPZ_AMD_OK;
+}
+
+int spz_amd_inflate_fetch(void *ctx, uint8_t *h_out) {
+  InfContext *c = static_cast<InfContext *>(ctx);
+  if (c == nullptr || h_out == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  DeviceGuard guard;
+  int rc = guard.enter(c->device);
+  if (rc != SPZ_AMD_OK) return rc;
+  SPZ_HIP_TRY(hipMemcpy(h_out, c->out, c->out_bytes, hipMemcpyDeviceToHost));
+  return SPZ_AMD_OK;
+}
+
+const uint8_t *spz_amd_inflate_device_data(void *ctx) {
+  InfContext *c = static_cast<InfContext *>(ctx);
+  return c ? c->out : nullptr;
+}
+
+void spz_amd_inflate_close(void *ctx) {
+  InfContext *c = static_cast<InfContext *>(ctx);
+  if (c == nullptr) return;
+  DeviceGuard guard;
+  if (guard.enter(c->device) == SPZ_AMD_OK && c->block) (void)hipFree(c->block);
+  delete c;
+}
+
+}  // extern "C"

@@ -276,6 +276,8 @@ PYBIND11_MODULE(spz, m) {
   }, py::arg("data"), py::arg("threads") = 4, py::arg("verify_prefix") = 0,
      "Test hook: the exact writer with its parse done by the serial host model of the device stages "
      "(links, match tables, lazy state machine, record-window splice); None when declined.");
+  m.def("_device_inflate_count", []() { return spz::deviceInflateCount(); },
+        "gzip members inflated on the device so far.");
   m.def("_device_gzip_parse_count", []() { return spz::deviceGzipParseCount(); },
         "gzip members written so far with their LZ77 parse done on the device.");
   m.def("_effective_cpu_count", []() { return spz::effectiveCpuCount(); },
