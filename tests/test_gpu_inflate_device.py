@@ -84,3 +84,27 @@ def test_what_the_device_declines_or_rejects_still_gets_zlibs_verdict():
     member[-6] ^= 0x01                                     # a wrong CRC-32 in the trailer
     assert spz._decompress_gzipped(bytes(member)) is None
     assert spz._decompress_gzipped(good) == data
+
+
+def test_random_damage_gets_zlibs_verdict_not_a_crash():
+    """Bit flips, truncations and spliced garbage anywhere in a member: whatever the device makes of it, the answer is
+    zlib's (the bytes, or an error), because nothing is believed before the CRC-32 and ISIZE of the trailer match."""
+    rng = np.random.default_rng(21)
+    data = make("sh_like", 5_000_000, rng)
+    good = zlib_gzip(data)
+    for trial in range(12):
+        m = bytearray(good)
+        kind = trial % 3
+        if kind == 0:
+            for _ in range(int(rng.integers(1, 4))):
+                m[int(rng.integers(10, len(m) - 8))] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            m = m[: int(rng.integers(len(m) // 2, len(m) - 1))]
+        else:
+            at = int(rng.integers(10, len(m) - 70000))
+            m[at:at + 65536] = rng.integers(0, 256, 65536, dtype=np.uint8).tobytes()
+        try:
+            want = zlib.decompress(bytes(m), 16 + 15)
+        except zlib.error:
+            want = None
+        assert spz._decompress_gzipped(bytes(m)) == want, f"trial {trial}"
