@@ -225,6 +225,18 @@ SPZ_INF_HD bool readCodeLengths(const In &in, uint64_t *at, uint8_t *lens, int *
   int n = 0;
   const int total = hlit + hdist;
   for (int i = 0; i < 286 + 30; ++i) lens[i] = 0;
+  // Kraft sums of the two sets as they come, in units of 2^-15: an over-subscribed set (which build() would refuse
+  // in the end anyway) ends the reading at once — random bits that look like a header get there within a few
+  // dozen lengths, and the block-start searches spend most of their time on those.
+  uint32_t kraft_lit = 0, kraft_dist = 0;
+  auto add = [&](int from, int to, int len) {
+    if (len == 0) return true;
+    for (int i = from; i < to; ++i) {
+      if (i < hlit) kraft_lit += 32768u >> len;
+      else kraft_dist += 32768u >> len;
+    }
+    return kraft_lit <= 32768u && kraft_dist <= 32768u;
+  };
   while (n < total) {
     if (pos >= in.nbits) return false;
     v = in.peek(pos);
@@ -235,6 +247,7 @@ SPZ_INF_HD bool readCodeLengths(const In &in, uint64_t *at, uint8_t *lens, int *
     pos += static_cast<uint64_t>(len);
     if (sym < 16) {
       lens[n++] = static_cast<uint8_t>(sym);
+      if (!add(n - 1, n, sym)) return false;
     } else {
       int rep, val = 0;
       if (sym == 16) {
@@ -250,6 +263,7 @@ SPZ_INF_HD bool readCodeLengths(const In &in, uint64_t *at, uint8_t *lens, int *
         pos += 7;
       }
       if (n + rep > total) return false;
+      if (!add(n, n + rep, val)) return false;
       while (rep--) lens[n++] = static_cast<uint8_t>(val);
     }
   }
