@@ -226,6 +226,11 @@ int spz_amd_convert_coordinates_device(float *d_positions, float *d_rotations, f
 int spz_amd_encode_host(const spz_amd_cloud_in *h_cloud, uint64_t num_points, int sh_degree,
                         int antialiased, int from_coord, int version, uint8_t *h_stream,
                         size_t capacity, int device);
+/* The same with the stream already in device memory (what spz_amd_inflate_device_data() returns): no upload, the
+ * decoded floats come back to the host arrays through the same chunked pipeline.  `hdr`: the stream's header
+ * (spz_amd_peek_header_device, or _ex on its first 16 bytes). */
+int spz_amd_decode_host_from_device(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr, int to_coord,
+                                    const spz_amd_cloud_out *h_cloud, int device);
 int spz_amd_decode_host(const uint8_t *h_stream, size_t size, int to_coord,
                         const spz_amd_cloud_out *h_cloud, int device);
 int spz_amd_decode_host_ex(const uint8_t *h_stream, size_t size, uint64_t max_points, int to_coord,

@@ -40,7 +40,7 @@ EXPORTS = (
     "spz_amd_decode_shard_device", "spz_amd_decode_gather_device", "spz_amd_decode_gather_host",
     "spz_amd_convert_coordinates_device",
     "spz_amd_encode_host",
-    "spz_amd_decode_host", "spz_amd_decode_host_ex", "spz_amd_convert_coordinates_host", "spz_amd_get_tables",
+    "spz_amd_decode_host", "spz_amd_decode_host_ex", "spz_amd_decode_host_from_device", "spz_amd_convert_coordinates_host", "spz_amd_get_tables",
     "spz_amd_ply_default_columns", "spz_amd_ply_rows_to_cloud_device", "spz_amd_cloud_to_ply_rows_device",
     "spz_amd_ply_rows_to_cloud_host", "spz_amd_cloud_to_ply_rows_host",
     "spz_amd_median_scale_sum_device", "spz_amd_median_scale_sum_host",
@@ -215,6 +215,8 @@ def bind(L):
     L.spz_amd_zlib_parse_append.argtypes = [vp, vp, vp, u64]
     L.spz_amd_zlib_block_stats.restype = i32
     L.spz_amd_zlib_block_stats.argtypes = [vp, vp, u32, u32, vp, vp, vp, vp]
+    L.spz_amd_decode_host_from_device.restype = i32
+    L.spz_amd_decode_host_from_device.argtypes = [vp, sz, vp, i32, vp, i32]
     L.spz_amd_inflate_open.restype = i32
     L.spz_amd_inflate_open.argtypes = [vp, u64, i32, C.POINTER(vp), C.POINTER(u64)]
     L.spz_amd_inflate_crc_piece_bytes.restype = u32

@@ -800,14 +800,15 @@ namespace {
 // of 8 MiB and more on hosts with fewer than 32 usable CPUs.  The result is believed only when its length matches ISIZE and its CRC-32 the trailer's.
 std::atomic<uint64_t> g_device_inflates{0};
 
-bool inflateOnDevice(const uint8_t *gz, size_t size, size_t header_len, std::vector<uint8_t> *out) {
+// Inflates the member on the device and checks length and CRC-32 against its trailer; nullptr: declined or wrong.
+void *openVerifiedDeviceInflate(const uint8_t *gz, size_t size, size_t header_len, uint64_t *out_bytes) {
   const char *e = std::getenv("SPZ_AMD_GUNZIP_DEVICE");
-  if (e && e[0] == '0') return false;
+  if (e && e[0] == '0') return nullptr;
   const bool forced = e && e[0] == '1';
-  if (size < header_len + 8 + (forced ? (size_t(1) << 20) : (size_t(8) << 20))) return false;
+  if (size < header_len + 8 + (forced ? (size_t(1) << 20) : (size_t(8) << 20))) return nullptr;
   // 409 MB member: 0.17 s on the device, 0.25 s on 16 CPUs; the host reader scales with cores, the device one does not
-  if (!forced && detail::effectiveCpuCount() >= 32) return false;
-  if (spz_amd_device_count() <= 0) return false;
+  if (!forced && detail::effectiveCpuCount() >= 32) return nullptr;
+  if (spz_amd_device_count() <= 0) return nullptr;
   const size_t nbytes = size - header_len - 8;
   auto le32 = [&](const uint8_t *q) {
     return static_cast<uint32_t>(q[0]) | (static_cast<uint32_t>(q[1]) << 8) | (static_cast<uint32_t>(q[2]) << 16) |
@@ -815,26 +816,38 @@ bool inflateOnDevice(const uint8_t *gz, size_t size, size_t header_len, std::vec
   };
   const uint32_t want_crc = le32(gz + size - 8), isize = le32(gz + size - 4);
   void *ctx = nullptr;
+  if (spz_amd_inflate_open(gz + header_len, nbytes, deviceIndex(), &ctx, out_bytes) != SPZ_AMD_OK) return nullptr;
+  bool ok = static_cast<uint32_t>(*out_bytes & 0xffffffffull) == isize;
+  if (ok) {
+    const uint32_t piece = spz_amd_inflate_crc_piece_bytes();
+    std::vector<uint32_t> crcs(static_cast<size_t>((*out_bytes + piece - 1) / piece));
+    uint32_t n_pieces = 0;
+    ok = spz_amd_inflate_piece_crcs(ctx, crcs.data(), static_cast<uint32_t>(crcs.size()), &n_pieces) == SPZ_AMD_OK &&
+         n_pieces == crcs.size();
+    if (ok) {
+      uLong crc = crcs.empty() ? crc32(0L, Z_NULL, 0) : crcs[0];
+      for (size_t i = 1; i < crcs.size(); ++i) {
+        const uint64_t len = std::min<uint64_t>(piece, *out_bytes - static_cast<uint64_t>(i) * piece);
+        crc = crc32_combine(crc, crcs[i], static_cast<z_off_t>(len));
+      }
+      ok = static_cast<uint32_t>(crc) == want_crc;
+    }
+  }
+  if (!ok) {
+    spz_amd_inflate_close(ctx);
+    return nullptr;
+  }
+  return ctx;
+}
+
+bool inflateOnDevice(const uint8_t *gz, size_t size, size_t header_len, std::vector<uint8_t> *out) {
   uint64_t out_bytes = 0;
-  if (spz_amd_inflate_open(gz + header_len, nbytes, deviceIndex(), &ctx, &out_bytes) != SPZ_AMD_OK) return false;
+  void *ctx = openVerifiedDeviceInflate(gz, size, header_len, &out_bytes);
+  if (ctx == nullptr) return false;
   struct Close {
     void *c;
     ~Close() { spz_amd_inflate_close(c); }
   } closer{ctx};
-  if (static_cast<uint32_t>(out_bytes & 0xffffffffull) != isize) return false;
-  const uint32_t piece = spz_amd_inflate_crc_piece_bytes();
-  std::vector<uint32_t> crcs(static_cast<size_t>((out_bytes + piece - 1) / piece));
-  uint32_t n_pieces = 0;
-  if (spz_amd_inflate_piece_crcs(ctx, crcs.data(), static_cast<uint32_t>(crcs.size()), &n_pieces) != SPZ_AMD_OK ||
-      n_pieces != crcs.size()) {
-    return false;
-  }
-  uLong crc = crcs.empty() ? crc32(0L, Z_NULL, 0) : crcs[0];
-  for (size_t i = 1; i < crcs.size(); ++i) {
-    const uint64_t len = std::min<uint64_t>(piece, out_bytes - static_cast<uint64_t>(i) * piece);
-    crc = crc32_combine(crc, crcs[i], static_cast<z_off_t>(len));
-  }
-  if (static_cast<uint32_t>(crc) != want_crc) return false;
   out->clear();
   detail::resizeUninitialized(out, static_cast<size_t>(out_bytes));
   {
@@ -1148,6 +1161,47 @@ PackedGaussians loadSpzPacked(const std::string &filename) {
 
 GaussianCloud loadSpz(const uint8_t *data, int32_t size, const UnpackOptions &o) {
   g_last_status = SPZ_AMD_OK;
+  // An ordinary member that the device inflates stays there: the decode kernels read the stream where it is and only
+  // the floats cross PCIe.
+  if (data != nullptr && size > 0) {
+    GzipIndex idx;
+    const size_t headerLen = parseGzipHeader(data, static_cast<size_t>(size), &idx);
+    uint64_t stream_bytes = 0;
+    void *ctx = (headerLen != 0 && idx.pieceBytes.empty())
+                    ? openVerifiedDeviceInflate(data, static_cast<size_t>(size), headerLen, &stream_bytes)
+                    : nullptr;
+    if (ctx != nullptr) {
+      struct Close {
+        void *c;
+        ~Close() { spz_amd_inflate_close(c); }
+      } closer{ctx};
+      const uint8_t *d_stream = spz_amd_inflate_device_data(ctx);
+      uint8_t first16[16] = {};
+      spz_amd_header hdr;
+      if (stream_bytes >= 16 && spz_amd_peek_header_device(d_stream, static_cast<size_t>(stream_bytes), 0, &hdr, nullptr) == SPZ_AMD_OK &&
+          spz_amd_write_header(&hdr, first16) == SPZ_AMD_OK) {
+        // the reference's checks and log lines (load-spz.cc:553-568), on the 16 header bytes and the stream's size
+        if (!peekHeaderLogged(first16, static_cast<size_t>(stream_bytes), &hdr)) return {};
+        GaussianCloud r;
+        r.numPoints = static_cast<int32_t>(hdr.num_points);
+        r.shDegree = hdr.sh_degree;
+        r.antialiased = (hdr.flags & 1) != 0;
+        detail::Prefault prefault;
+        sizeCloudArrays(&r, hdr.num_points, static_cast<size_t>(dimForDegree(hdr.sh_degree)), &prefault);
+        prefault.start();
+        spz_amd_cloud_out out = {r.positions.data(), r.scales.data(), r.rotations.data(),
+                                 r.alphas.data(),    r.colors.data(), r.sh.empty() ? nullptr : r.sh.data()};
+        const int rc = spz_amd_decode_host_from_device(d_stream, static_cast<size_t>(stream_bytes), &hdr, static_cast<int>(o.to),
+                                                       &out, deviceIndex());
+        prefault.join();
+        if (rc == SPZ_AMD_OK) {
+          g_device_inflates.fetch_add(1);
+          return r;
+        }
+      }
+      // anything unusual about the stream: the ordinary route below produces the reference's log line and result
+    }
+  }
   std::vector<uint8_t> stream;
   // A failed gunzip yields an empty PackedGaussians and hence an empty cloud, silently
   // (load-spz.cc:609-612).

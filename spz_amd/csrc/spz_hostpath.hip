@@ -312,6 +312,54 @@ int spz_amd_decode_host_ex(const uint8_t *h_stream, size_t size, uint64_t max_po
   return run_pipeline(pipe, device, chunks, up, down);
 }
 
+int spz_amd_decode_host_from_device(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr, int to_coord,
+                                    const spz_amd_cloud_out *h, int device) {
+  if (d_stream == nullptr || hdr == nullptr || h == nullptr || !valid_coord(to_coord)) return SPZ_AMD_ERR_INVALID_ARG;
+  const uint64_t n = hdr->num_points;
+  spz_amd_layout lay;
+  int rc = spz_amd_stream_layout(n, hdr->sh_degree, (int)hdr->version, &lay);
+  if (rc != SPZ_AMD_OK) return rc;
+  if (size < lay.total_bytes) return SPZ_AMD_ERR_SHORT_STREAM;
+  if (n == 0) return SPZ_AMD_OK;
+  const int sd = sh_dim_for_degree(hdr->sh_degree);
+  if (!h->positions || !h->scales || !h->rotations || !h->alphas || !h->colors || (sd > 0 && !h->sh)) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  DeviceGuard guard;
+  rc = guard.enter(device);
+  if (rc != SPZ_AMD_OK) return rc;
+  const size_t fpp[6] = {3, 3, 4, 1, 3, (size_t)sd * 3};
+  float *dst[6] = {h->positions, h->scales, h->rotations, h->alphas, h->colors, h->sh};
+  size_t total = 0;
+  for (int i = 0; i < 6; ++i) total += Workspace::aligned(n * fpp[i] * sizeof(float));
+  Workspace ws;
+  rc = ws.open(device, total);
+  if (rc != SPZ_AMD_OK) return rc;
+  float *fb[6];
+  for (int i = 0; i < 6; ++i) fb[i] = static_cast<float *>(ws.take(n * fpp[i] * sizeof(float)));
+  HostPipe *pipe = ws.pipe();
+  uint64_t cp = 0;
+  const int chunks = plan_chunks(n, (14 + (size_t)sd * 3) * sizeof(float), &cp);
+  // the stream is where it is: chunk k is a kernel launch, the downloader copies its floats out
+  auto up = [&](int k) -> int {
+    const uint64_t first = (uint64_t)k * cp, count = std::min<uint64_t>(cp, n - first);
+    const spz_amd_cloud_out d = {fb[0] + first * 3, fb[1] + first * 3, fb[2] + first * 4,
+                                 fb[3] + first,     fb[4] + first * 3, fb[5] + first * fpp[5]};
+    return spz_amd_decode_shard_device(d_stream, size, hdr, first, count, to_coord, &d, pipe->up);
+  };
+  auto down = [&](int k) -> int {
+    const uint64_t first = (uint64_t)k * cp, count = std::min<uint64_t>(cp, n - first);
+    for (int i = 0; i < 6; ++i) {
+      if (fpp[i]) {
+        SPZ_HIP_TRY(hipMemcpyAsync(dst[i] + first * fpp[i], fb[i] + first * fpp[i], count * fpp[i] * sizeof(float),
+                                   hipMemcpyDeviceToHost, pipe->down));
+      }
+    }
+    return SPZ_AMD_OK;
+  };
+  return run_pipeline(pipe, device, chunks, up, down);
+}
+
 int spz_amd_decode_host(const uint8_t *h_stream, size_t size, int to_coord, const spz_amd_cloud_out *h,
                         int device) {
   return spz_amd_decode_host_ex(h_stream, size, SPZ_AMD_REFERENCE_MAX_POINTS, to_coord, h, device);
