@@ -865,14 +865,23 @@ bool inflateOnDevice(const uint8_t *gz, size_t size, size_t header_len, std::vec
 
 uint64_t deviceInflateCount() { return g_device_inflates.load(); }
 
+namespace {
+bool decompressGzippedWith(const uint8_t *compressed, size_t size, std::vector<uint8_t> *out, bool try_device);
+}  // namespace
+
 bool decompressGzipped(const uint8_t *compressed, size_t size, std::vector<uint8_t> *out) {
+  return decompressGzippedWith(compressed, size, out, true);
+}
+
+namespace {
+bool decompressGzippedWith(const uint8_t *compressed, size_t size, std::vector<uint8_t> *out, bool try_device) {
   if (compressed != nullptr) {
     GzipIndex idx;
     const size_t headerLen = parseGzipHeader(compressed, size, &idx);
     if (headerLen != 0) {
       if (!idx.pieceBytes.empty() && inflateIndexed(compressed, size, headerLen, idx, out)) return true;
       // an ordinary single deflate stream (what the reference writes): on the device when it is large and one answers
-      if (inflateOnDevice(compressed, size, headerLen, out)) return true;
+      if (try_device && inflateOnDevice(compressed, size, headerLen, out)) return true;
       // ... or decoded in parallel on the host
       if (size >= (size_t(4) << 20)) {
         const int threads = gunzipThreads(size_t(1) << 20);
@@ -909,6 +918,7 @@ bool decompressGzipped(const uint8_t *compressed, size_t size, std::vector<uint8
   inflateEnd(&stream);
   return success;
 }
+}  // namespace
 
 // ---- (de)serialise, load-spz.cc:533-596 ----------------------------------------------------------
 void serializePackedGaussians(const PackedGaussians &packed, std::ostream *out) {
@@ -1163,6 +1173,7 @@ GaussianCloud loadSpz(const uint8_t *data, int32_t size, const UnpackOptions &o)
   g_last_status = SPZ_AMD_OK;
   // An ordinary member that the device inflates stays there: the decode kernels read the stream where it is and only
   // the floats cross PCIe.
+  bool device_declined = false;
   if (data != nullptr && size > 0) {
     GzipIndex idx;
     const size_t headerLen = parseGzipHeader(data, static_cast<size_t>(size), &idx);
@@ -1200,12 +1211,14 @@ GaussianCloud loadSpz(const uint8_t *data, int32_t size, const UnpackOptions &o)
         }
       }
       // anything unusual about the stream: the ordinary route below produces the reference's log line and result
+    } else if (headerLen != 0 && idx.pieceBytes.empty()) {
+      device_declined = true;  // not asked a second time by decompressGzipped
     }
   }
   std::vector<uint8_t> stream;
   // A failed gunzip yields an empty PackedGaussians and hence an empty cloud, silently
   // (load-spz.cc:609-612).
-  if (!decompressGzipped(data, static_cast<size_t>(size), &stream)) return {};
+  if (!decompressGzippedWith(data, static_cast<size_t>(size), &stream, !device_declined)) return {};
   return unpackFromStream(stream.data(), stream.size(), o);
 }
 

@@ -60,6 +60,7 @@ struct SymbolSink {
     cap = want;
     return true;
   }
+  inline void mark() {}
   inline bool lit(uint8_t b) {
     if (W + n + 9 > cap && !grow(1)) return false;
     sym[W + n++] = b;

@@ -292,6 +292,7 @@ SPZ_INF_HD bool readDynamic(const In &in, uint64_t *at, HL *lit, HD *dist) {
 
 // ---- sinks ---------------------------------------------------------------------------------------------
 struct NullSink {  // block-start validation
+  SPZ_INF_HD void mark() {}
   uint64_t n;
   SPZ_INF_HD bool lit(uint8_t) { ++n; return true; }
   SPZ_INF_HD bool match(uint32_t len, uint32_t) { n += len; return true; }
@@ -300,10 +301,12 @@ struct NullSink {  // block-start validation
 
 
 template <class In, class HL, class HD, class Sink>
-SPZ_INF_HD bool decodeHuffBlock(const In &in, uint64_t *at, const HL &L, const HD &D, Sink &sink) {
+SPZ_INF_HD bool decodeHuffBlock(const In &in, uint64_t *at, const HL &L, const HD &D, Sink &sink, uint64_t limit = NONE) {
+  // `limit`: a bit position at which a block is known (or believed) to start: a block that runs past it is not one
+  // that ends there, and a decoder on a look-alike start must not run on to the end of the data
   uint64_t pos = *at;
   for (;;) {
-    if (pos >= in.nbits) return false;
+    if (pos >= in.nbits || pos > limit) return false;
     uint64_t bits = in.peek(pos);  // >= 56 valid bits
     uint32_t e = in.uniform(L.lookup(bits));
     // up to three literals per refill (3 x 15 bits <= 56)
@@ -360,6 +363,8 @@ SPZ_INF_HD Outcome decodeBlocks(const In &in, uint64_t start, uint64_t stop, Sin
   for (;;) {
     if (pos == stop) return LINKED;
     if (pos > stop || pos + 3 > in.nbits) return FAILED;
+    *end = pos;   // on FAILED: where the block that did not work out begins (with sink.mark(): how far the output was)
+    sink.mark();
     const uint64_t v = in.peek(pos);
     const bool final_block = v & 1;
     const int type = static_cast<int>((v >> 1) & 3);
@@ -376,10 +381,10 @@ SPZ_INF_HD Outcome decodeBlocks(const In &in, uint64_t start, uint64_t stop, Sin
       pos += 8 * static_cast<uint64_t>(len);
     } else if (type == 1) {
       buildStatic(lit, dist);
-      if (!decodeHuffBlock(in, &pos, *lit, *dist, sink)) return FAILED;
+      if (!decodeHuffBlock(in, &pos, *lit, *dist, sink, stop)) return FAILED;
     } else if (type == 2) {
       if (!readDynamic(in, &pos, lit, dist)) return FAILED;
-      if (!decodeHuffBlock(in, &pos, *lit, *dist, sink)) return FAILED;
+      if (!decodeHuffBlock(in, &pos, *lit, *dist, sink, stop)) return FAILED;
     } else {
       return FAILED;
     }

@@ -16,8 +16,11 @@
 //   inf_place_kernel    symbols -> bytes at their final offsets, references resolved from the predecessor's window.
 //   inf_crc_kernel      CRC-32 of 256 KiB pieces (the caller folds them with crc32_combine and compares with the
 //                       member's trailer: the result can only be right or refused).
-// Anything irregular (a chunk that does not link, a reference where there is no predecessor, a chunk that expands
-// more than 8x, stored-only data with no block starts) declines: the caller's host readers take over.
+// Runs of stored blocks (incompressible sections) have no block starts to find: the chunk before a run walks it.  Raw
+// bytes now and then read like a block header: the chunk before such a look-alike does not end on it, so the
+// look-alike is dropped and the chunk resumes, from the block that ran past it, towards the next start.
+// Anything else irregular (a reference where there is no predecessor, a chunk that expands more than 8x, data
+// that opens with a stored block) declines: the caller's host readers take over.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -119,14 +122,15 @@ struct ChunkJob {
   unsigned long long from, to;      // bit positions: first block, the next chunk's first block (NONE: to the final block)
   unsigned long long region;        // first symbol of the chunk's region
   unsigned long long capacity;      // symbols
+  unsigned long long start_n;       // symbols of the region that an earlier attempt has already produced (kept)
 };
 struct ChunkResult {
   unsigned long long length;        // symbols produced
   unsigned long long end_bit;       // FINAL: first bit after the final block
   uint32_t outcome;                 // Outcome
   uint32_t overflow;
+  unsigned long long mark_n;        // FAILED: symbols before the block that did not work out (end_bit: where it begins)
 };
-
 // The wave's view of the deflate data: all 64 lanes run the decoder in lockstep (same bits, same decisions), the
 // compressed bytes around the current position are kept in LDS and refilled by all lanes (16 bytes each).
 struct WaveBits {
@@ -167,6 +171,8 @@ struct WaveSymbolSink {
   uint64_t cap, n;
   uint32_t lane;
   bool overflow;
+  uint64_t mark_n;
+  __device__ __forceinline__ void mark() { mark_n = n; }
   __device__ __forceinline__ bool lit(uint8_t b) {
     if (n >= cap) {
       overflow = true;
@@ -193,7 +199,7 @@ struct WaveSymbolSink {
     n += len;
     return true;
   }
-  __device__ __forceinline__ bool raw(const uint8_t *src, uint32_t len) {
+  __device__ __forceinline__ bool raw(const uint8_t *src, uint32_t len) {  // a stored block: 64 bytes per round
     if (n + len > cap) {
       overflow = true;
       return false;
@@ -205,21 +211,23 @@ struct WaveSymbolSink {
 };
 
 __global__ __launch_bounds__(64, 6) void inf_decode_kernel(const uint8_t *__restrict__ d, uint64_t nbytes,
-                                                        const ChunkJob *__restrict__ jobs, uint16_t *symbols,
-                                                        ChunkResult *__restrict__ results) {
+                                                           const ChunkJob *__restrict__ jobs, const uint32_t *__restrict__ run,
+                                                           uint16_t *symbols, ChunkResult *__restrict__ results) {
   __shared__ Tables tb;
   __shared__ uint32_t s_win[kWinBytes / 4 + 4];
-  const ChunkJob job = jobs[blockIdx.x];
+  const uint32_t j = run[blockIdx.x];
+  const ChunkJob job = jobs[j];
   const WaveBits in = {d, 8ull * nbytes, (size_t)nbytes, s_win, threadIdx.x, ~0ull};
-  WaveSymbolSink sink = {symbols + job.region, job.capacity, 0, threadIdx.x, false};
+  WaveSymbolSink sink = {symbols + job.region, job.capacity, job.start_n, threadIdx.x, false, job.start_n};
   uint64_t end = 0;
   const Outcome r = decodeBlocks(in, job.from, job.to, sink, &end, &tb.lit, &tb.dist);
   if (threadIdx.x == 0) {
-    ChunkResult &o = results[blockIdx.x];
+    ChunkResult &o = results[j];
     o.length = sink.n;
     o.end_bit = end;
     o.outcome = (uint32_t)r;
     o.overflow = sink.overflow ? 1u : 0u;
+    o.mark_n = sink.mark_n;
   }
 }
 
@@ -372,6 +380,7 @@ int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, 
   const size_t o_res = carve((size_t)n_chunks * sizeof(ChunkResult));
   const size_t o_place = carve((size_t)n_chunks * sizeof(ChunkPlace));
   const size_t o_bad = carve(256);
+  const size_t o_run = carve((size_t)n_chunks * sizeof(uint32_t));
   const size_t o_win = carve((size_t)n_chunks * W);
   const size_t o_sym = carve(sym_capacity * sizeof(uint16_t));
   const size_t total = off;
@@ -392,6 +401,7 @@ int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, 
   ChunkResult *d_res = reinterpret_cast<ChunkResult *>(block + o_res);
   ChunkPlace *d_place = reinterpret_cast<ChunkPlace *>(block + o_place);
   uint32_t *d_bad = reinterpret_cast<uint32_t *>(block + o_bad);
+  uint32_t *d_run = reinterpret_cast<uint32_t *>(block + o_run);
   uint8_t *d_win = reinterpret_cast<uint8_t *>(block + o_win);
   uint16_t *d_sym = reinterpret_cast<uint16_t *>(block + o_sym);
   hipStream_t st = nullptr;
@@ -412,10 +422,11 @@ int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, 
   for (uint32_t i = 0; i < n_chunks; ++i) {
     if (starts[i] == NONE) continue;
     if (!jobs.empty() && starts[i] <= jobs.back().from) continue;  // found again from the chunk before: one job
-    jobs.push_back({starts[i], NONE, 0, 0});
+    jobs.push_back({starts[i], NONE, 0, 0, 0});
   }
-  const uint32_t n = (uint32_t)jobs.size();
-  if (n < 2 || n * 2 < n_chunks) return SPZ_AMD_ERR_UNSUPPORTED;  // mostly stored / static data: no gain
+  uint32_t n = (uint32_t)jobs.size();
+  if (n < 2) return SPZ_AMD_ERR_UNSUPPORTED;
+  if (timing) std::fprintf(stderr, "[inflate] %u of %u chunks have a block start\n", n, n_chunks);
   unsigned long long region = 0;
   for (uint32_t j = 0; j < n; ++j) {
     jobs[j].to = (j + 1 < n) ? jobs[j + 1].from : NONE;
@@ -425,22 +436,56 @@ int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, 
     region += jobs[j].capacity;
   }
   if (region > sym_capacity) return SPZ_AMD_ERR_UNSUPPORTED;
-  SPZ_HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), (size_t)n * sizeof(ChunkJob), hipMemcpyHostToDevice, st));
-  // ---- 2. decode
-  hipLaunchKernelGGL(inf_decode_kernel, dim3(n), dim3(64), 0, st, d_data, nbytes, d_jobs, d_sym, d_res);
-  SPZ_HIP_TRY(hipGetLastError());
+  // ---- 2. decode.  A chunk that does not end exactly at its successor's block start has met a look-alike (raw bytes
+  // of a stored block that read like a header): the successor is dropped, the chunk takes its range and region and
+  // is decoded again.  Chunk 0 starts at a true block start, so this is sound by induction.
+  std::vector<uint32_t> live(n), todo(n);
+  for (uint32_t j = 0; j < n; ++j) live[j] = todo[j] = j;
   std::vector<ChunkResult> res(n);
-  SPZ_HIP_TRY(hipMemcpyAsync(res.data(), d_res, (size_t)n * sizeof(ChunkResult), hipMemcpyDeviceToHost, st));
-  SPZ_HIP_TRY(hipStreamSynchronize(st));
+  bool linked = false;
+  for (uint32_t round = 0; round < 8 && !linked; ++round) {
+    SPZ_HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), (size_t)n * sizeof(ChunkJob), hipMemcpyHostToDevice, st));
+    SPZ_HIP_TRY(hipMemcpyAsync(d_run, todo.data(), todo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(inf_decode_kernel, dim3((unsigned)todo.size()), dim3(64), 0, st, d_data, nbytes, d_jobs, d_run, d_sym, d_res);
+    SPZ_HIP_TRY(hipGetLastError());
+    SPZ_HIP_TRY(hipMemcpyAsync(res.data(), d_res, (size_t)n * sizeof(ChunkResult), hipMemcpyDeviceToHost, st));
+    SPZ_HIP_TRY(hipStreamSynchronize(st));
+    todo.clear();
+    std::vector<uint32_t> next_live;
+    next_live.reserve(live.size());
+    for (size_t k = 0; k < live.size(); ++k) {
+      const uint32_t j = live[k];
+      const bool last = k + 1 == live.size();
+      if (res[j].overflow) return SPZ_AMD_ERR_UNSUPPORTED;
+      if (res[j].outcome == (uint32_t)(last ? FINAL : LINKED)) {
+        next_live.push_back(j);
+        continue;
+      }
+      if (last) return SPZ_AMD_ERR_UNSUPPORTED;  // the final block was not reached: not this reader's case
+      const uint32_t drop = live[k + 1];           // its block start was not one
+      jobs[j].to = jobs[drop].to;
+      jobs[j].capacity += jobs[drop].capacity;     // regions are adjacent
+      jobs[j].from = res[j].end_bit;               // the blocks before the one that ran past the look-alike stand
+      jobs[j].start_n = res[j].mark_n;
+      next_live.push_back(j);
+      todo.push_back(j);
+      ++k;                                         // the dropped chunk's own result does not count
+    }
+    live.swap(next_live);
+    linked = todo.empty();
+    if (timing && !linked) std::fprintf(stderr, "[inflate] round %u: %zu chunks decoded again\n", round, todo.size());
+  }
+  if (!linked) return SPZ_AMD_ERR_UNSUPPORTED;
   lap("decode");
+  n = (uint32_t)live.size();
   std::vector<ChunkPlace> place(n);
   unsigned long long offset = 0;
-  for (uint32_t j = 0; j < n; ++j) {
-    if (res[j].overflow || res[j].outcome != (uint32_t)(j + 1 < n ? LINKED : FINAL)) return SPZ_AMD_ERR_UNSUPPORTED;
-    place[j] = {jobs[j].region, res[j].length, offset};
+  for (uint32_t k = 0; k < n; ++k) {
+    const uint32_t j = live[k];
+    place[k] = {jobs[j].region, res[j].length, offset};
     offset += res[j].length;
   }
-  if (((res[n - 1].end_bit + 7) >> 3) != nbytes) return SPZ_AMD_ERR_UNSUPPORTED;  // the stream must end exactly at the trailer
+  if (((res[live[n - 1]].end_bit + 7) >> 3) != nbytes) return SPZ_AMD_ERR_UNSUPPORTED;  // the stream must end exactly at the trailer
   const uint64_t total_out = offset;
   if (total_out == 0) return SPZ_AMD_ERR_UNSUPPORTED;
   SPZ_HIP_TRY(hipMemcpyAsync(d_place, place.data(), (size_t)n * sizeof(ChunkPlace), hipMemcpyHostToDevice, st));

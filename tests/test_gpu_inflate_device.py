@@ -108,3 +108,18 @@ def test_random_damage_gets_zlibs_verdict_not_a_crash():
         except zlib.error:
             want = None
         assert spz._decompress_gzipped(bytes(m)) == want, f"trial {trial}"
+
+
+def test_stored_runs_between_huffman_sections():
+    """Incompressible sections (zlib stores them: runs of stored blocks, whose raw bytes now and then read like a block
+    header) between compressible ones — the shape of a real .spz stream.  The device walks the stored runs, copies
+    them with a kernel of their own and drops look-alike block starts; it must still be the one that did the work."""
+    rng = np.random.default_rng(31)
+    parts = [make("sh_like", 3_000_000, rng), make("bytes", 3_000_000, rng), make("sh_like", 2_500_000, rng),
+             make("bytes", 2_000_000, rng), make("words", 2_000_000, rng), make("bytes", 700_000, rng),
+             make("nibbles", 1_500_000, rng)]
+    data = b"".join(parts)
+    member = zlib_gzip(data)
+    before = spz._device_inflate_count()
+    assert spz._decompress_gzipped(member) == data
+    assert spz._device_inflate_count() == before + 1
