@@ -89,6 +89,7 @@ def main():
     same = declined = total_bytes = 0
     kinds = {}
     declined_kinds = {}
+    device_inflates = 0
     for i in range(a.inputs):
         kind, data = make_input(i, rng, int(a.max_mib * (1 << 20)))
         threads = int(rng.integers(2, 17))
@@ -105,6 +106,13 @@ def main():
             got = spz._compress_gzipped(data)
             if spz._device_gzip_parse_count() == before:
                 got = None if got == zlib_gzip(data) else got   # the device declined; the fallback's bytes must still be zlib's
+            # and back: the member through the device reader (or, where it declines, the host readers) must give the input
+            os.environ["SPZ_AMD_GUNZIP_DEVICE"] = "1"
+            inflates_before = spz._device_inflate_count()
+            if spz._decompress_gzipped(got if got is not None else zlib_gzip(data)) != data:
+                print(json.dumps({"FAILED": "inflate", "input": i, "kind": kind, "bytes": len(data), "seed": a.seed}))
+                return 1
+            device_inflates += spz._device_inflate_count() - inflates_before
         else:
             got = spz._compress_gzipped_exact(data, threads, windows, 0)
         kinds[kind.split()[0]] = kinds.get(kind.split()[0], 0) + 1
@@ -122,7 +130,8 @@ def main():
             print(f"[gzip-campaign] {i + 1}/{a.inputs} inputs, {same} identical, {declined} declined, {time.time() - t0:.0f} s",
                   file=sys.stderr, flush=True)
     print(json.dumps({"writer": a.writer, "inputs": a.inputs, "identical_to_zlib": same, "declined": declined, "different": 0, "seed": a.seed,
-                      "total_MB": round(total_bytes / 1e6, 1), "by_kind": kinds, "declined_by_kind": declined_kinds, "seconds": round(time.time() - t0, 1)}))
+                      "total_MB": round(total_bytes / 1e6, 1), "by_kind": kinds, "declined_by_kind": declined_kinds,
+                      **({"inflated_back_identical": a.inputs, "of_them_on_the_device": device_inflates} if a.writer == "device" else {}), "seconds": round(time.time() - t0, 1)}))
     return 0
 
 
