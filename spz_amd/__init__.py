@@ -7,6 +7,10 @@ Layout:
   csrc/spz_abi.hip      the C ABI (include/spz_amd.h) over them: device-pointer entry points
   csrc/spz_hostpath.hip host-pointer entry points: device workspace + chunked H2D/kernel/D2H pipeline
   csrc/spz_exchange.hip multi-GPU exchange: native RCCL gatherv/scatterv, IPC-mapped root stream
+  csrc/spz_lz77.hip     the gzip writer's stages on the device: zlib's level-6 parse (exact) and Huffman bit packing
+  csrc/spz_lz77_core.hpp  ... their stage functions, shared with the serial host model (spz_lz77_model.cpp, tests)
+  csrc/spz_inflate_dev.hip  inflate of single-stream gzip members on the device (CRC-verified)
+  csrc/spz_inflate_core.hpp ... the deflate decoder shared by the host and the device reader
   csrc/spz_host.cpp     C++ drop-in layer: namespace spz saveSpz/loadSpz/... + host gzip
   csrc/spz_deflate.cpp  multi-threaded gzip writer with zlib's exact bytes (the default container stage)
   csrc/spz_inflate.cpp  multi-threaded, CRC-verified inflate of ordinary single-stream members
