@@ -140,25 +140,31 @@ struct WaveBits {
   uint32_t *win;             // LDS: kWinBytes + 16 bytes
   uint32_t lane;
   mutable uint64_t win_lo;   // byte offset of win[0], a multiple of 16; ~0: nothing loaded
+  // 128 bits of the stream in (scalar) registers: a peek that still finds its 56 bits there costs no LDS round trip
+  mutable uint64_t reg_lo, reg_hi, reg_base;  // reg_base: bit position of reg_lo's bit 0, a multiple of 32; ~0: empty
   __device__ __forceinline__ const uint8_t *bytes(uint64_t byte_offset) const { return p + byte_offset; }
   __device__ __forceinline__ uint32_t uniform(uint32_t v) const { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); }
   __device__ __forceinline__ uint64_t peek(uint64_t at) const {
-    const uint64_t b = at >> 3;
-    if (b < win_lo || b + 12 > win_lo + kWinBytes) {
-      win_lo = b & ~15ull;   // the allocation is padded: reads past the end see zeros
-      const uint4 *src = reinterpret_cast<const uint4 *>(p + win_lo);
-      uint4 *dst = reinterpret_cast<uint4 *>(win);
-      for (uint32_t i = lane; i < kWinBytes / 16; i += 64) dst[i] = src[i];
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (at < reg_base || at - reg_base > 128u - 56u) {
+      const uint64_t b = (at >> 5) << 2;   // byte offset of the dword `at` lies in
+      if (b < win_lo || b + 16 > win_lo + kWinBytes) {
+        win_lo = b & ~15ull;   // the allocation is padded: reads past the end see zeros
+        const uint4 *src = reinterpret_cast<const uint4 *>(p + win_lo);
+        uint4 *dst = reinterpret_cast<uint4 *>(win);
+        for (uint32_t i = lane; i < kWinBytes / 16; i += 64) dst[i] = src[i];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      }
+      const uint32_t i = (uint32_t)(b - win_lo) >> 2;
+      const uint32_t w0 = uniform(win[i]), w1 = uniform(win[i + 1]), w2 = uniform(win[i + 2]), w3 = uniform(win[i + 3]);
+      reg_lo = (uint64_t)w0 | ((uint64_t)w1 << 32);
+      reg_hi = (uint64_t)w2 | ((uint64_t)w3 << 32);
+      reg_base = b * 8;
     }
-    const uint32_t off = (uint32_t)(b - win_lo);
-    const uint32_t w0 = uniform(win[off >> 2]), w1 = uniform(win[(off >> 2) + 1]), w2 = uniform(win[(off >> 2) + 2]);
-    const uint32_t s = (off & 3u) * 8u;
-    uint64_t v = ((uint64_t)w0 | ((uint64_t)w1 << 32)) >> s;
-    if (s) v |= (uint64_t)w2 << (64u - s);
-    return v >> (at & 7);    // >= 56 valid bits
+    const uint32_t s = (uint32_t)(at - reg_base);  // <= 72
+    if (s == 0) return reg_lo;
+    return s < 64 ? (reg_lo >> s) | (reg_hi << (64u - s)) : reg_hi >> (s - 64u);  // >= 56 valid bits
   }
 };
 
@@ -204,7 +210,28 @@ struct WaveSymbolSink {
       overflow = true;
       return false;
     }
-    for (uint32_t i = lane; i < len; i += 64) sym[n + i] = src[i];
+    // a run of stored blocks can be tens of megabytes, all met by this one wave: 64 bytes per lane and round, four
+    // 16-byte loads in flight
+    uint32_t done = 0;
+    for (; done + 4096 <= len; done += 4096) {
+      const uint8_t *s = src + done + 64u * lane;
+      uint4 q[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) __builtin_memcpy(&q[k], s + 16 * k, 16);
+      uint16_t *dst = sym + n + done + 64u * lane;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const uint32_t w[4] = {q[k].x, q[k].y, q[k].z, q[k].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          dst[16 * k + 4 * j + 0] = (uint16_t)(w[j] & 0xffu);
+          dst[16 * k + 4 * j + 1] = (uint16_t)((w[j] >> 8) & 0xffu);
+          dst[16 * k + 4 * j + 2] = (uint16_t)((w[j] >> 16) & 0xffu);
+          dst[16 * k + 4 * j + 3] = (uint16_t)(w[j] >> 24);
+        }
+      }
+    }
+    for (uint32_t i = done + lane; i < len; i += 64) sym[n + i] = src[i];
     n += len;
     return true;
   }
@@ -217,7 +244,7 @@ __global__ __launch_bounds__(64, 6) void inf_decode_kernel(const uint8_t *__rest
   __shared__ uint32_t s_win[kWinBytes / 4 + 4];
   const uint32_t j = run[blockIdx.x];
   const ChunkJob job = jobs[j];
-  const WaveBits in = {d, 8ull * nbytes, (size_t)nbytes, s_win, threadIdx.x, ~0ull};
+  const WaveBits in = {d, 8ull * nbytes, (size_t)nbytes, s_win, threadIdx.x, ~0ull, 0ull, 0ull, ~0ull};
   WaveSymbolSink sink = {symbols + job.region, job.capacity, job.start_n, threadIdx.x, false, job.start_n};
   uint64_t end = 0;
   const Outcome r = decodeBlocks(in, job.from, job.to, sink, &end, &tb.lit, &tb.dist);
