@@ -170,8 +170,8 @@ struct WaveBits {
 
 // Symbols go straight to the chunk's region in HBM: literals by lane 0, matches by as many lanes as they are long
 // (one load and one store for the wave instead of a round trip per symbol).  A ring of recent symbols in LDS with
-// block-wise flushes was tried: it costs registers (occupancy 2 waves per SIMD instead of 6) and a wave's speed here
-// is set by its instruction stream, not by these loads and stores (profiles/r02_device_inflate.txt).
+// block-wise flushes was tried: it costs registers (occupancy 2 waves per SIMD instead of 6) and did not pay
+// (profiles/r02_device_inflate.txt).
 struct WaveSymbolSink {
   uint16_t *sym;   // sym[i] = symbol of the chunk's byte i
   uint64_t cap, n;
