@@ -5,8 +5,11 @@
 
 #include <hip/hip_runtime.h>
 
+#include <chrono>
 #include <cstddef>
 #include <cstdint>
+#include <cstring>
+#include <mutex>
 
 #include "spz_amd.h"
 
@@ -132,6 +135,66 @@ class Workspace {
   int device_ = 0;
   bool open_ = false;
 };
+
+// Host -> device copy of a large pageable range that the runtime has not seen before.  hipMemcpy pins such a range
+// page by page first; on hosts where that is cheap it runs at the link's rate (409 MB in 8 ms), on others (seen on
+// some boxes of the pool: every fresh std::vector, e.g. the stream a saveSpz has just produced) at 0.7-1.4 GB/s.
+// The first 8 MiB are copied directly and timed; a slow start switches to staging through two pinned 32 MiB buffers of
+// this library's own (a memcpy per chunk, overlapped with the previous chunk's DMA: ~10 GB/s whatever the range).
+// Blocking: the data is on the device when this returns.
+inline hipError_t upload_adaptive(void *d_dst, const void *h_src, size_t bytes, hipStream_t st) {
+  constexpr size_t kProbe = size_t(8) << 20, kStage = size_t(32) << 20;
+  hipError_t e;
+  if (bytes < 4 * kProbe) {
+    e = hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+  }
+  const auto t0 = std::chrono::steady_clock::now();
+  e = hipMemcpyAsync(d_dst, h_src, kProbe, hipMemcpyHostToDevice, st);
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  if (e != hipSuccess) return e;
+  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  char *dst = static_cast<char *>(d_dst) + kProbe;
+  const char *src = static_cast<const char *>(h_src) + kProbe;
+  size_t left = bytes - kProbe;
+  if (static_cast<double>(kProbe) / dt >= 5e9) {
+    e = hipMemcpyAsync(dst, src, left, hipMemcpyHostToDevice, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+  }
+  static std::mutex mu;
+  static void *pinned[2] = {nullptr, nullptr};
+  static hipEvent_t done[2] = {nullptr, nullptr};
+  std::lock_guard<std::mutex> lock(mu);
+  for (int i = 0; i < 2; ++i) {
+    if (pinned[i] == nullptr) {
+      e = hipHostMalloc(&pinned[i], kStage, hipHostMallocDefault);
+      if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+      if (e != hipSuccess) {  // no pinned memory to be had: the runtime's own way
+        pinned[i] = nullptr;
+        e = hipMemcpyAsync(dst, src, left, hipMemcpyHostToDevice, st);
+        return e != hipSuccess ? e : hipStreamSynchronize(st);
+      }
+    }
+  }
+  bool used[2] = {false, false};
+  for (int k = 0; left > 0; ++k) {
+    const int b = k & 1;
+    const size_t n = left < kStage ? left : kStage;
+    if (used[b]) {
+      e = hipEventSynchronize(done[b]);
+      if (e != hipSuccess) return e;
+    }
+    std::memcpy(pinned[b], src, n);
+    e = hipMemcpyAsync(dst, pinned[b], n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipEventRecord(done[b], st);
+    if (e != hipSuccess) return e;
+    used[b] = true;
+    dst += n;
+    src += n;
+    left -= n;
+  }
+  return hipStreamSynchronize(st);
+}
 
 struct DeviceGuard {
   int prev = -1;

@@ -83,6 +83,30 @@ __global__ __launch_bounds__(256) void inf_search_kernel(const uint8_t *__restri
   if (hi > in.nbits) hi = in.nbits;
   if (tid == 0) found = NONE;
   __syncthreads();
+  // Inside a run of stored blocks (an incompressible section) there is no dynamic header to find, but the blocks start
+  // at byte boundaries with 00 LEN ~LEN, one after the other: a position whose LEN leads to another such header (or to
+  // the final one) is a block start.  Looked for in the chunk's own bytes only; the lowest wins against a dynamic
+  // header found below.
+  {
+    const uint64_t b0 = (uint64_t)kChunkBytes * chunk;
+    for (uint32_t k = tid; k < kChunkBytes; k += 256) {
+      const uint64_t b = b0 + k;
+      if (b + 5 > nbytes || d[b] != 0) continue;
+      const uint32_t len = (uint32_t)d[b + 1] | ((uint32_t)d[b + 2] << 8), nlen = (uint32_t)d[b + 3] | ((uint32_t)d[b + 4] << 8);
+      if ((len ^ nlen) != 0xffffu || len < 1024) continue;   // zlib's stored blocks carry tens of kilobytes
+      const uint64_t b2 = b + 5 + len;
+      if (b2 + 5 > nbytes) continue;
+      const uint32_t h2 = d[b2], len2 = (uint32_t)d[b2 + 1] | ((uint32_t)d[b2 + 2] << 8),
+                     nlen2 = (uint32_t)d[b2 + 3] | ((uint32_t)d[b2 + 4] << 8);
+      const bool stored_next = (h2 == 0 || h2 == 1) && (len2 ^ nlen2) == 0xffffu;
+      const bool dynamic_next = (h2 & 6u) == 4u && plausibleDynamicHeader(in, 8 * b2);
+      if (stored_next || dynamic_next) atomicMin(&found, 8ull * b);
+    }
+    __syncthreads();
+  }
+  const unsigned long long stored_start = found;
+  if (stored_start != NONE && stored_start < hi) hi = stored_start;   // a dynamic header counts only below it
+  __syncthreads();
   for (uint64_t base = lo; base < hi; base += 256 * kSearchPerThread) {
     if (tid == 0) ncand = 0;
     __syncthreads();
@@ -432,7 +456,7 @@ int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, 
   uint8_t *d_win = reinterpret_cast<uint8_t *>(block + o_win);
   uint16_t *d_sym = reinterpret_cast<uint16_t *>(block + o_sym);
   hipStream_t st = nullptr;
-  SPZ_HIP_TRY(hipMemcpyAsync(d_data, h_deflate, nbytes, hipMemcpyHostToDevice, st));
+  SPZ_HIP_TRY(upload_adaptive(d_data, h_deflate, nbytes, st));
   SPZ_HIP_TRY(hipMemsetAsync(d_data + nbytes, 0, kWinBytes + 64, st));
   SPZ_HIP_TRY(hipMemsetAsync(d_bad, 0, 256, st));
   lap("upload");
