@@ -7,6 +7,8 @@
 
 #include <chrono>
 #include <cstddef>
+#include <cstdio>
+#include <cstdlib>
 #include <cstdint>
 #include <cstring>
 #include <mutex>
@@ -137,37 +139,44 @@ class Workspace {
 };
 
 // Host -> device copy of a large pageable range that the runtime has not seen before.  hipMemcpy pins such a range
-// page by page first; on hosts where that is cheap it runs at the link's rate (409 MB in 8 ms), on others (seen on
-// some boxes of the pool: every fresh std::vector, e.g. the stream a saveSpz has just produced) at 0.7-1.4 GB/s.
-// The first 8 MiB are copied directly and timed; a slow start switches to staging through two pinned 32 MiB buffers of
-// this library's own (a memcpy per chunk, overlapped with the previous chunk's DMA: ~10 GB/s whatever the range).
+// page by page first; where the range is backed by huge pages that is cheap and the copy runs at the link's rate
+// (409 MB in 8 ms), where it is not (a fresh std::vector whose huge-page request the kernel could not honour, in whole or
+// from some point on: seen in about one process in four on the pool's boxes) at 0.7-1.4 GB/s.  The range goes up in
+// 32 MiB steps, each timed; the first slow one switches the rest to staging through two pinned 32 MiB buffers of
+// this library's own (a memcpy per step, overlapped with the previous step's DMA: ~10 GB/s whatever backs the range).
 // Blocking: the data is on the device when this returns.
 inline hipError_t upload_adaptive(void *d_dst, const void *h_src, size_t bytes, hipStream_t st) {
-  constexpr size_t kProbe = size_t(8) << 20, kStage = size_t(32) << 20;
+  constexpr size_t kStep = size_t(32) << 20;
   hipError_t e;
-  if (bytes < 4 * kProbe) {
-    e = hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, st);
-    return e != hipSuccess ? e : hipStreamSynchronize(st);
+  char *dst = static_cast<char *>(d_dst);
+  const char *src = static_cast<const char *>(h_src);
+  size_t left = bytes;
+  while (left > 0) {  // direct, while it is fast
+    const size_t n = left < kStep ? left : kStep;
+    const auto t0 = std::chrono::steady_clock::now();
+    e = hipMemcpyAsync(dst, src, n, hipMemcpyHostToDevice, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (e != hipSuccess) return e;
+    const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    dst += n;
+    src += n;
+    left -= n;
+    if (n == kStep && static_cast<double>(n) / dt < 5e9) {
+      if (std::getenv("SPZ_AMD_LZ_TIMING")) {
+        std::fprintf(stderr, "[upload] %.1f GB/s after %zu MiB: the rest (%zu MiB) through pinned staging\n", n / dt / 1e9,
+                     (bytes - left) >> 20, left >> 20);
+      }
+      break;
+    }
   }
-  const auto t0 = std::chrono::steady_clock::now();
-  e = hipMemcpyAsync(d_dst, h_src, kProbe, hipMemcpyHostToDevice, st);
-  if (e == hipSuccess) e = hipStreamSynchronize(st);
-  if (e != hipSuccess) return e;
-  const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-  char *dst = static_cast<char *>(d_dst) + kProbe;
-  const char *src = static_cast<const char *>(h_src) + kProbe;
-  size_t left = bytes - kProbe;
-  if (static_cast<double>(kProbe) / dt >= 5e9) {
-    e = hipMemcpyAsync(dst, src, left, hipMemcpyHostToDevice, st);
-    return e != hipSuccess ? e : hipStreamSynchronize(st);
-  }
+  if (left == 0) return hipSuccess;
   static std::mutex mu;
   static void *pinned[2] = {nullptr, nullptr};
   static hipEvent_t done[2] = {nullptr, nullptr};
   std::lock_guard<std::mutex> lock(mu);
   for (int i = 0; i < 2; ++i) {
     if (pinned[i] == nullptr) {
-      e = hipHostMalloc(&pinned[i], kStage, hipHostMallocDefault);
+      e = hipHostMalloc(&pinned[i], kStep, hipHostMallocDefault);
       if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
       if (e != hipSuccess) {  // no pinned memory to be had: the runtime's own way
         pinned[i] = nullptr;
@@ -179,7 +188,7 @@ inline hipError_t upload_adaptive(void *d_dst, const void *h_src, size_t bytes, 
   bool used[2] = {false, false};
   for (int k = 0; left > 0; ++k) {
     const int b = k & 1;
-    const size_t n = left < kStage ? left : kStage;
+    const size_t n = left < kStep ? left : kStep;
     if (used[b]) {
       e = hipEventSynchronize(done[b]);
       if (e != hipSuccess) return e;

@@ -455,6 +455,7 @@ int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, 
   uint32_t *d_run = reinterpret_cast<uint32_t *>(block + o_run);
   uint8_t *d_win = reinterpret_cast<uint8_t *>(block + o_win);
   uint16_t *d_sym = reinterpret_cast<uint16_t *>(block + o_sym);
+  lap("alloc");
   hipStream_t st = nullptr;
   SPZ_HIP_TRY(upload_adaptive(d_data, h_deflate, nbytes, st));
   SPZ_HIP_TRY(hipMemsetAsync(d_data + nbytes, 0, kWinBytes + 64, st));

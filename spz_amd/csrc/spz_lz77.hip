@@ -573,6 +573,7 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
 
   hipStream_t st = nullptr;
   const size_t upload = std::min<size_t>(size, data_bytes);
+  lap("alloc");
   SPZ_HIP_TRY(upload_adaptive(d_data, h_data, upload, st));
   if (upload < data_bytes) SPZ_HIP_TRY(hipMemsetAsync(d_data + upload, 0, data_bytes - upload, st));
   SPZ_HIP_TRY(hipMemsetAsync(d_link, 0, pos_padded * sizeof(uint16_t), st));
