@@ -109,6 +109,14 @@ int workspace_acquire(int device, size_t bytes, void **base, HostPipe **pipe);  
 void workspace_release(int device);                                              // unlocks
 void workspace_free_all();                                                       // drops the cached allocations
 
+// Large transient device blocks of the container stage (spz_lz77.hip: ~23 bytes per input byte; spz_inflate_dev.hip:
+// ~17 per compressed byte): kept between calls, up to three per device, because a hipMalloc of several GB that
+// follows the hipFree of another has been seen to take 0.4 s on some boxes of the pool (the free is still in
+// progress).  Returned by spz_amd_release_device_memory() like the host path's workspace.  The current device is
+// `device`.  A block of at least `bytes`; when all cached ones are in use, a plain allocation that scratch_release frees.
+int scratch_acquire(int device, size_t bytes, void **block);
+void scratch_release(int device, void *block);
+
 class Workspace {
  public:
   ~Workspace() {

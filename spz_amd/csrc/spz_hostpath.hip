@@ -72,6 +72,60 @@ int workspace_acquire(int device, size_t bytes, void **base, HostPipe **pipe) {
 
 void workspace_release(int device) { g_ws_mutex[device].unlock(); }
 
+namespace {
+struct ScratchSlot {
+  void *ptr = nullptr;
+  size_t bytes = 0;
+  bool in_use = false;
+};
+constexpr int kScratchSlots = 3;
+ScratchSlot g_scratch[kMaxDevices][kScratchSlots];
+std::mutex g_scratch_mutex;
+}  // namespace
+
+int scratch_acquire(int device, size_t bytes, void **block) {
+  *block = nullptr;
+  if (device < 0 || device >= kMaxDevices) return SPZ_AMD_ERR_INVALID_ARG;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  ScratchSlot *slots = g_scratch[device];
+  int best = -1, idle = -1;
+  for (int i = 0; i < kScratchSlots; ++i) {
+    if (slots[i].in_use) continue;
+    if (slots[i].ptr && slots[i].bytes >= bytes && (best < 0 || slots[i].bytes < slots[best].bytes)) best = i;
+    if (idle < 0 || slots[i].bytes < slots[idle].bytes) idle = i;   // the smallest idle one is the one to replace
+  }
+  if (best >= 0) {
+    slots[best].in_use = true;
+    *block = slots[best].ptr;
+    return SPZ_AMD_OK;
+  }
+  void *p = nullptr;
+  if (idle >= 0) {
+    if (slots[idle].ptr) (void)hipFree(slots[idle].ptr);
+    slots[idle] = ScratchSlot();
+    SPZ_HIP_TRY(hipMalloc(&p, bytes));
+    slots[idle].ptr = p;
+    slots[idle].bytes = bytes;
+    slots[idle].in_use = true;
+  } else {
+    SPZ_HIP_TRY(hipMalloc(&p, bytes));  // every slot busy: not cached
+  }
+  *block = p;
+  return SPZ_AMD_OK;
+}
+
+void scratch_release(int device, void *block) {
+  if (block == nullptr || device < 0 || device >= kMaxDevices) return;
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  for (int i = 0; i < kScratchSlots; ++i) {
+    if (g_scratch[device][i].ptr == block) {
+      g_scratch[device][i].in_use = false;
+      return;
+    }
+  }
+  (void)hipFree(block);
+}
+
 void workspace_free_all() {
   int prev = 0;
   if (hipGetDevice(&prev) != hipSuccess) return;
@@ -84,6 +138,18 @@ void workspace_free_all() {
       }
       g_ws_ptr[d] = nullptr;
       g_ws_cap[d] = 0;
+    }
+  }
+  {
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    for (int d = 0; d < kMaxDevices; ++d) {
+      for (int i = 0; i < kScratchSlots; ++i) {
+        ScratchSlot &sl = g_scratch[d][i];
+        if (sl.ptr && !sl.in_use && hipSetDevice(d) == hipSuccess) {
+          (void)hipFree(sl.ptr);
+          sl = ScratchSlot();
+        }
+      }
     }
   }
   (void)hipSetDevice(prev);

@@ -439,13 +439,15 @@ int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, 
   SPZ_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   if (total + (size_t)nbytes * kExpand + (size_t(512) << 20) > free_b) return SPZ_AMD_ERR_UNSUPPORTED;
   char *block = nullptr;
-  SPZ_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&block), total));
+  rc = scratch_acquire(device, total, reinterpret_cast<void **>(&block));
+  if (rc != SPZ_AMD_OK) return rc;
   struct Free {
     char *p;
+    int device;
     ~Free() {
-      if (p) (void)hipFree(p);
+      if (p) scratch_release(device, p);
     }
-  } holder{block};
+  } holder{block, device};
   uint8_t *d_data = reinterpret_cast<uint8_t *>(block + o_data);
   unsigned long long *d_starts = reinterpret_cast<unsigned long long *>(block + o_starts);
   ChunkJob *d_jobs = reinterpret_cast<ChunkJob *>(block + o_jobs);
@@ -545,8 +547,9 @@ int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, 
   const uint32_t n_pieces = (uint32_t)((total_out + kCrcPiece - 1) / kCrcPiece);
   char *outblock = nullptr;
   const size_t out_alloc = round256(total_out + 64) + round256((size_t)n_pieces * sizeof(uint32_t));
-  SPZ_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&outblock), out_alloc));
-  Free holder2{outblock};
+  rc = scratch_acquire(device, out_alloc, reinterpret_cast<void **>(&outblock));
+  if (rc != SPZ_AMD_OK) return rc;
+  Free holder2{outblock, device};
   uint8_t *d_out = reinterpret_cast<uint8_t *>(outblock);
   uint32_t *d_crcs = reinterpret_cast<uint32_t *>(outblock + round256(total_out + 64));
   hipLaunchKernelGGL(inf_window_kernel, dim3(1), dim3(1024), 0, st, d_sym, d_place, n, d_win, d_bad);
@@ -608,7 +611,7 @@ void spz_amd_inflate_close(void *ctx) {
   InfContext *c = static_cast<InfContext *>(ctx);
   if (c == nullptr) return;
   DeviceGuard guard;
-  if (guard.enter(c->device) == SPZ_AMD_OK && c->block) (void)hipFree(c->block);
+  if (guard.enter(c->device) == SPZ_AMD_OK && c->block) scratch_release(c->device, c->block);
   delete c;
 }
 

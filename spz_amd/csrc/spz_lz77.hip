@@ -551,13 +551,15 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
   SPZ_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
   if (total + (size_t(256) << 20) > free_b) return SPZ_AMD_ERR_UNSUPPORTED;  // the caller parses on the host
   char *block = nullptr;
-  SPZ_HIP_TRY(hipMalloc(reinterpret_cast<void **>(&block), total));
+  rc = scratch_acquire(device, total, reinterpret_cast<void **>(&block));
+  if (rc != SPZ_AMD_OK) return rc;
   struct Free {
     char *p;
+    int device;
     ~Free() {
-      if (p) (void)hipFree(p);
+      if (p) scratch_release(device, p);
     }
-  } holder{block};
+  } holder{block, device};
   uint8_t *d_data = reinterpret_cast<uint8_t *>(block + o_data);
   uint16_t *d_link = reinterpret_cast<uint16_t *>(block + o_link);
   uint16_t *d_rank = reinterpret_cast<uint16_t *>(block + o_rank);
@@ -681,7 +683,7 @@ void spz_amd_zlib_parse_close(void *ctx) {
   LzContext *c = static_cast<LzContext *>(ctx);
   if (c == nullptr) return;
   DeviceGuard guard;
-  if (guard.enter(c->device) == SPZ_AMD_OK && c->block) (void)hipFree(c->block);
+  if (guard.enter(c->device) == SPZ_AMD_OK && c->block) scratch_release(c->device, c->block);
   delete c;
 }
 
