@@ -100,7 +100,8 @@ int spz_amd_device_count(void);
 int spz_amd_last_hip_error(void);
 
 /* Frees what the library keeps on the devices between calls (decode tables / thresholds, the cached
- * workspace of the *_host entry points).  Optional: everything is re-created on demand.  Must not
+ * workspace of the *_host entry points, up to three large blocks of the gzip container stage: ~23 bytes per byte of
+ * the largest stream compressed so far).  Optional: everything is re-created on demand.  Must not
  * run concurrently with other calls into the library. */
 int spz_amd_release_device_memory(void);
 
