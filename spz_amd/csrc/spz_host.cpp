@@ -20,6 +20,7 @@
 #include <cstring>
 #include <fstream>
 #include <istream>
+#include <mutex>
 #include <ostream>
 #include <thread>
 
@@ -1131,14 +1132,52 @@ GaussianCloud unpackIndices(const PackedGaussians &packed, const std::vector<uin
 }
 
 // ---- saveSpz / loadSpz overloads, load-spz.cc:598-668 ---------------------------------------------
+namespace {
+std::mutex g_stream_cache_mutex;
+std::vector<uint8_t> g_stream_cache;
+}  // namespace
+
 bool saveSpz(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *out) {
-  std::vector<uint8_t> stream;
+  static const bool timing = std::getenv("SPZ_AMD_EXACT_GZIP_TIMING") != nullptr;
+  const auto t0 = std::chrono::steady_clock::now();
+  struct Report {
+    std::chrono::steady_clock::time_point t0;
+    bool on;
+    ~Report() {
+      if (on) std::fprintf(stderr, "[saveSpz] %.3f s in all (stream freed)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+  } report{t0, timing};
+  // The stream is a transient of this call, 65 bytes per Gaussian.  Giving such a buffer back costs ~80 ms per GB once
+  // device copies have pinned it (measured: 52 ms of a 0.36 s save), in the foreground or — contending with
+  // whatever the caller does next — in the background; so one buffer of up to 1 GiB is kept for the next save
+  // (spz::releaseHostMemory() drops it).  A second save at the same time uses a buffer of its own.
+  std::vector<uint8_t> local;
+  static const bool keep = [] {
+    const char *e = std::getenv("SPZ_AMD_KEEP_STREAM_BUFFER");
+    return !(e && e[0] == '0');
+  }();
+  std::unique_lock<std::mutex> cache_lock(g_stream_cache_mutex, std::defer_lock);
+  if (keep) (void)cache_lock.try_lock();
+  std::vector<uint8_t> &stream = cache_lock.owns_lock() ? g_stream_cache : local;
+  struct Trim {
+    std::vector<uint8_t> &v;
+    bool cached;
+    ~Trim() {
+      if (cached && v.capacity() > (size_t(1) << 30)) std::vector<uint8_t>().swap(v);
+    }
+  } trim{stream, cache_lock.owns_lock()};
   if (!packToStream(g, o, &stream)) return false;
+  if (timing) std::fprintf(stderr, "[saveSpz] pack %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   // Default: the reference's single deflate stream (byte-identical files).  SPZ_AMD_GZIP_THREADS=n>1
   // opts into the parallel container (same content, different bytes, n x faster).
   const char *e = std::getenv("SPZ_AMD_GZIP_THREADS");
   const int threads = e ? std::atoi(e) : 1;
   return compressGzippedParallel(stream.data(), stream.size(), out, threads);
+}
+
+void releaseHostMemory() {
+  std::lock_guard<std::mutex> lock(g_stream_cache_mutex);
+  std::vector<uint8_t>().swap(g_stream_cache);
 }
 
 bool saveSpz(const GaussianCloud &g, const PackOptions &o, const std::string &filename) {
