@@ -16,8 +16,8 @@
 //   inf_place_kernel    symbols -> bytes at their final offsets, references resolved from the predecessor's window.
 //   inf_crc_kernel      CRC-32 of 256 KiB pieces (the caller folds them with crc32_combine and compares with the
 //                       member's trailer: the result can only be right or refused).
-// Runs of stored blocks (incompressible sections) have no block starts to find: the chunk before a run walks it.  Raw
-// bytes now and then read like a block header: the chunk before such a look-alike does not end on it, so the
+// Runs of stored blocks (incompressible sections) have no dynamic header to find: their blocks are found by their own
+// pattern (00 LEN ~LEN at a byte boundary, leading to another header).  Raw bytes now and then read like a block header: the chunk before such a look-alike does not end on it, so the
 // look-alike is dropped and the chunk resumes, from the block that ran past it, towards the next start.
 // Anything else irregular (a reference where there is no predecessor, a chunk that expands more than 8x, data
 // that opens with a stored block) declines: the caller's host readers take over.
