@@ -39,7 +39,8 @@ namespace {
 
 using namespace spz::pinflate;
 
-constexpr uint32_t kChunkBytes = 65536;    // compressed bytes per chunk
+constexpr uint32_t kMinChunkBytes = 65536;  // compressed bytes per chunk, at least; more when that lets every chunk's wave be resident at once
+constexpr uint32_t kDecodeWavesPerCU = 23;  // what the decode kernel's registers and LDS allow
 constexpr uint32_t kSearchBytes = 131072;  // how far past its chunk's first byte a block start is looked for
 constexpr uint32_t kExpand = 8;            // symbols a chunk may produce per compressed byte
 constexpr uint32_t kCrcPiece = 262144;
@@ -70,15 +71,15 @@ struct RegBits {
   }
 };
 
-__global__ __launch_bounds__(256) void inf_search_kernel(const uint8_t *__restrict__ d, uint64_t nbytes, uint32_t n_chunks,
-                                                         unsigned long long *__restrict__ starts) {
+__global__ __launch_bounds__(256) void inf_search_kernel(const uint8_t *__restrict__ d, uint64_t nbytes, uint32_t chunk_bytes,
+                                                         uint32_t n_chunks, unsigned long long *__restrict__ starts) {
   __shared__ unsigned long long cand[kMaxCand];
   __shared__ uint32_t ncand;
   __shared__ unsigned long long found;
   const uint32_t tid = threadIdx.x, chunk = blockIdx.x + 1;  // chunk 0 starts at bit 0
   if (chunk >= n_chunks) return;
   const Bits in = {d, 8ull * nbytes, (size_t)nbytes};
-  const uint64_t lo = 8ull * kChunkBytes * chunk;
+  const uint64_t lo = 8ull * chunk_bytes * chunk;
   uint64_t hi = lo + 8ull * kSearchBytes;
   if (hi > in.nbits) hi = in.nbits;
   if (tid == 0) found = NONE;
@@ -88,8 +89,8 @@ __global__ __launch_bounds__(256) void inf_search_kernel(const uint8_t *__restri
   // the final one) is a block start.  Looked for in the chunk's own bytes only; the lowest wins against a dynamic
   // header found below.
   {
-    const uint64_t b0 = (uint64_t)kChunkBytes * chunk;
-    for (uint32_t k = tid; k < kChunkBytes; k += 256) {
+    const uint64_t b0 = (uint64_t)chunk_bytes * chunk;
+    for (uint32_t k = tid; k < chunk_bytes; k += 256) {
       const uint64_t b = b0 + k;
       if (b + 5 > nbytes || d[b] != 0) continue;
       const uint32_t len = (uint32_t)d[b + 1] | ((uint32_t)d[b + 2] << 8), nlen = (uint32_t)d[b + 3] | ((uint32_t)d[b + 4] << 8);
@@ -402,7 +403,7 @@ extern "C" {
 int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, void **ctx, uint64_t *out_bytes) {
   if (h_deflate == nullptr || ctx == nullptr || out_bytes == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
   *ctx = nullptr;
-  if (nbytes < 4ull * kChunkBytes || nbytes >= (1ull << 32)) return SPZ_AMD_ERR_UNSUPPORTED;
+  if (nbytes < 4ull * kMinChunkBytes || nbytes >= (1ull << 32)) return SPZ_AMD_ERR_UNSUPPORTED;
   if (((h_deflate[0] >> 1) & 3) == 0) return SPZ_AMD_ERR_UNSUPPORTED;  // opens with a stored block: nothing to gain
   DeviceGuard guard;
   int rc = guard.enter(device);
@@ -416,7 +417,16 @@ int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, 
     std::fprintf(stderr, "[inflate] %-8s %.4f s\n", what, std::chrono::duration<double>(now - t_prev).count());
     t_prev = now;
   };
-  const uint32_t n_chunks = (uint32_t)(nbytes / kChunkBytes);  // the last one takes the remainder
+  // One wave per chunk, and a decode stage that is as long as its slowest wave: with a few more chunks than the chip holds
+  // waves, the stragglers' second round doubles the stage (6236 chunks on 5888 slots: 70 ms; 5700 chunks: one round).
+  int cus = 0;
+  SPZ_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
+  const uint64_t slots = (uint64_t)(cus > 0 ? cus : 256) * kDecodeWavesPerCU;
+  uint32_t chunk_bytes = kMinChunkBytes;
+  if (nbytes / kMinChunkBytes > slots * 95 / 100 && nbytes / kMinChunkBytes <= 2 * slots) {
+    chunk_bytes = (uint32_t)((nbytes / (slots * 95 / 100) + 4095) / 4096 * 4096);
+  }
+  const uint32_t n_chunks = (uint32_t)(nbytes / chunk_bytes);  // the last one takes the remainder
   // one allocation: the deflate data, block starts, jobs/results/places, symbols, windows; the output and CRCs later
   const size_t sym_capacity = (size_t)nbytes * kExpand + (size_t)n_chunks * 128;
   size_t off = 0;
@@ -464,7 +474,7 @@ int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, 
   SPZ_HIP_TRY(hipMemsetAsync(d_bad, 0, 256, st));
   lap("upload");
   // ---- 1. block starts
-  hipLaunchKernelGGL(inf_search_kernel, dim3(n_chunks - 1), dim3(256), 0, st, d_data, nbytes, n_chunks, d_starts);
+  hipLaunchKernelGGL(inf_search_kernel, dim3(n_chunks - 1), dim3(256), 0, st, d_data, nbytes, chunk_bytes, n_chunks, d_starts);
   SPZ_HIP_TRY(hipGetLastError());
   std::vector<unsigned long long> starts(n_chunks);
   SPZ_HIP_TRY(hipMemcpyAsync(starts.data(), d_starts, (size_t)n_chunks * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
