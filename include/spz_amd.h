@@ -315,12 +315,12 @@ int spz_amd_selftest_device(int mode, uint64_t begin, uint64_t count, uint64_t r
  *      the quantise step runs on the GPU, and its output has to stay the reference's bytes.  These entry points
  *      produce the literal/match symbols zlib 1.2.11's deflate_slow + longest_match produce for h_data[0 .. ) up to
  *      the point where they meet the caller's own serial parse of the input's end (`tail_begin`, a multiple of
- *      32768 with 64-96 KiB after it; h_tail_rec: 16384 pairs {lazy-match state, symbols emitted so far} recorded at the
+ *      32768 with 64-96 KiB after it; h_tail_rec: 32768 pairs {lazy-match state, symbols emitted so far} recorded at the
  *      loop tops tail_begin + k of that parse, state 0 where k is not a loop top — spz_deflate.cpp's TopRec).
  *      open: uploads, runs the stages (spz_lz77.hip), returns the symbol count and the index of the first symbol
  *      the tail parse contributes; fetch: copies the symbols out (distance, 0 = literal; literal byte or
  *      length - 3); close: frees the device memory.  SPZ_AMD_ERR_UNSUPPORTED = declined (two neighbouring jobs did not
- *      meet inside 16384 positions, or not enough free device memory: ~21 bytes per input byte): the caller parses on
+ *      meet even with parse jobs of 1 MiB, or not enough free device memory: ~23 bytes per input byte): the caller parses on
  *      the host, with the same result.  Blocking; Huffman coding and the gzip framing stay on the host. ---------- */
 int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_begin, const uint32_t *h_tail_rec,
                             uint32_t n_rec, int device, void **ctx, uint64_t *num_symbols,
