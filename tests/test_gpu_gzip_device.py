@@ -102,3 +102,41 @@ def test_long_repeats_need_larger_jobs_and_get_them():
     before = spz._device_gzip_parse_count()
     assert spz._compress_gzipped(data) == zlib_gzip(data)
     assert spz._device_gzip_parse_count() == before + 1
+
+
+@pytest.mark.parametrize("deg", [0, 1, 2])
+def test_whole_files_of_every_degree_through_the_device_container(deg, tmp_path):
+    """saveSpz / loadSpz with both halves of the container stage forced onto the device, SH degrees 0-2 (degree 3 is
+    the test above and the bench): the file is zlib's member of the raw stream, and it loads back to the same floats
+    as the stream decodes to."""
+    from spz_amd.synth import make_cloud_numpy
+    n = 300_000
+    c = make_cloud_numpy(n, deg, 90 + deg)
+    g = spz.GaussianCloud()
+    g.sh_degree = deg
+    for k in ("positions", "scales", "rotations", "alphas", "colors", "sh"):
+        if len(c[k]):
+            setattr(g, k, c[k])
+    o = spz.PackOptions()
+    o.from_coord = spz.RUF
+    raw = spz._pack_to_stream(g, o)
+    path = str(tmp_path / f"d{deg}.spz")
+    old = os.environ.get("SPZ_AMD_GUNZIP_DEVICE")
+    os.environ["SPZ_AMD_GUNZIP_DEVICE"] = "1"
+    try:
+        parses = spz._device_gzip_parse_count()
+        assert spz.save_spz(g, o, path)
+        assert spz._device_gzip_parse_count() == parses + 1
+        assert open(path, "rb").read() == zlib_gzip(raw)
+        u = spz.UnpackOptions()
+        u.to_coord = spz.RUF
+        back = spz.load_spz(path, u)
+        want = spz._unpack_from_stream(raw, u)
+        assert back.num_points == n and back.sh_degree == deg
+        for k in ("positions", "scales", "rotations", "alphas", "colors", "sh"):
+            assert np.array_equal(np.asarray(getattr(back, k)).view(np.uint32), np.asarray(getattr(want, k)).view(np.uint32)), k
+    finally:
+        if old is None:
+            os.environ.pop("SPZ_AMD_GUNZIP_DEVICE", None)
+        else:
+            os.environ["SPZ_AMD_GUNZIP_DEVICE"] = old
