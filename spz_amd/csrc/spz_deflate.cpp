@@ -36,6 +36,7 @@
 #include <cstring>
 #include <chrono>
 #include <cstdio>
+#include <system_error>
 #include <thread>
 
 namespace spz {
@@ -648,8 +649,24 @@ void parallel_for(size_t n, int threads, F fn) {
 // ---- self-check against the linked zlib: deflate the first `verify` input bytes with zlib itself and
 // compare every output byte that cannot depend on where that prefix ends (whole blocks that end at least
 // 1 KiB before it).  Guards against a zlib whose algorithm differs from the one restated here.
-bool verify_against_zlib(const uint8_t *data, size_t size, const std::vector<Block> &blocks, const std::vector<uint8_t> &member,
-                         size_t verify_prefix) {
+// zlib's own member for the first `verify` input bytes (empty on failure): the half of the check that needs nothing
+// from the writer, so it can run beside it.
+std::vector<uint8_t> zlib_prefix_member(const uint8_t *data, uint64_t verify) {
+  std::vector<uint8_t> z(compressBound(static_cast<uLong>(verify)) + 64);
+  z_stream zs = {};
+  if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 9, Z_DEFAULT_STRATEGY) != Z_OK) return {};
+  zs.next_in = const_cast<Bytef *>(data);
+  zs.avail_in = static_cast<uInt>(verify);
+  zs.next_out = z.data();
+  zs.avail_out = static_cast<uInt>(z.size());
+  const int rc = deflate(&zs, Z_FINISH);
+  z.resize(rc == Z_STREAM_END ? zs.total_out : 0);
+  deflateEnd(&zs);
+  return z;
+}
+
+bool matches_zlib_prefix(const std::vector<uint8_t> &z, size_t size, const std::vector<Block> &blocks,
+                         const std::vector<uint8_t> &member, size_t verify_prefix) {
   const uint64_t verify = std::min<uint64_t>(size, verify_prefix);
   uint64_t safe_bits = 0;
   for (const Block &b : blocks) {
@@ -658,18 +675,12 @@ bool verify_against_zlib(const uint8_t *data, size_t size, const std::vector<Blo
     else break;
   }
   const size_t safe_bytes = 10 + static_cast<size_t>(safe_bits / 8) + (verify == size ? 8 : 0);
-  std::vector<uint8_t> z(compressBound(static_cast<uLong>(verify)) + 64);
-  z_stream zs = {};
-  if (deflateInit2(&zs, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 16 + MAX_WBITS, 9, Z_DEFAULT_STRATEGY) != Z_OK) return false;
-  zs.next_in = const_cast<Bytef *>(data);
-  zs.avail_in = static_cast<uInt>(verify);
-  zs.next_out = z.data();
-  zs.avail_out = static_cast<uInt>(z.size());
-  const int rc = deflate(&zs, Z_FINISH);
-  const size_t zn = zs.total_out;
-  deflateEnd(&zs);
-  return rc == Z_STREAM_END && zn >= safe_bytes && member.size() >= safe_bytes &&
-         std::memcmp(z.data(), member.data(), safe_bytes) == 0;
+  return !z.empty() && z.size() >= safe_bytes && member.size() >= safe_bytes && std::memcmp(z.data(), member.data(), safe_bytes) == 0;
+}
+
+bool verify_against_zlib(const uint8_t *data, size_t size, const std::vector<Block> &blocks, const std::vector<uint8_t> &member,
+                         size_t verify_prefix) {
+  return matches_zlib_prefix(zlib_prefix_member(data, std::min<uint64_t>(size, verify_prefix)), size, blocks, member, verify_prefix);
 }
 
 // ---- serial: positions, stored / static / dynamic, bit offsets (the rest of _tr_flush_block's decision)
@@ -795,7 +806,8 @@ bool finish_member(const uint8_t *data, size_t size, int threads, const std::vec
 // made here, codes and headers go out, the finished deflate body comes back.
 template <class Lap>
 bool finish_member_on_parser(HeadParser &parser, const uint8_t *data, size_t size, int threads, uint64_t total_syms,
-                             bool tail_literal, uLong crc, std::vector<uint8_t> *out, size_t verify_prefix, Lap &lap) {
+                             bool tail_literal, uLong crc, std::vector<uint8_t> *out, size_t verify_prefix,
+                             const std::vector<uint8_t> *zlib_prefix, Lap &lap) {
   const StaticTables &T = tables();
   spz_amd_deflate_static st = {};
   std::memcpy(st.length_code, T.length_code, sizeof(st.length_code));
@@ -911,7 +923,11 @@ bool finish_member_on_parser(HeadParser &parser, const uint8_t *data, size_t siz
   uint8_t *trailer = out->data() + 10 + deflate_bytes;
   for (int k2 = 0; k2 < 4; ++k2) trailer[k2] = static_cast<uint8_t>(crc >> (8 * k2));
   for (int k2 = 0; k2 < 4; ++k2) trailer[4 + k2] = static_cast<uint8_t>((size & 0xffffffffu) >> (8 * k2));
-  if (verify_prefix > 0 && !verify_against_zlib(data, size, blocks, *out, verify_prefix)) return false;
+  if (verify_prefix > 0) {
+    const bool same = zlib_prefix ? matches_zlib_prefix(*zlib_prefix, size, blocks, *out, verify_prefix)
+                                  : verify_against_zlib(data, size, blocks, *out, verify_prefix);
+    if (!same) return false;
+  }
   lap("verify");
   return true;
 }
@@ -1035,6 +1051,17 @@ bool compressWithHeadParser(const uint8_t *data, size_t size, int threads, HeadP
       if (t.joinable()) t.join();
     }
   } joiner{crc_thread};
+  // zlib's own member of the input's first bytes, for the writer's standing self-check: computed meanwhile as well
+  std::vector<uint8_t> zprefix;
+  std::thread zlib_thread;
+  if (verify_prefix > 0) {
+    try {
+      zlib_thread = std::thread([&]() { zprefix = zlib_prefix_member(data, std::min<uint64_t>(size, verify_prefix)); });
+    } catch (const std::system_error &) {
+      // no thread to be had: computed at the end
+    }
+  }
+  Joiner zlib_joiner{zlib_thread};
 
   // the serial tail job: the last 64 ... 96 KiB, with the reads past the end of the input as zlib's window has them
   const uint64_t tail_begin = (size - 2 * W) / W * W;
@@ -1072,7 +1099,10 @@ bool compressWithHeadParser(const uint8_t *data, size_t size, int threads, HeadP
       const size_t lo = i * (size_t(4) << 20), hi = std::min(size, lo + (size_t(4) << 20));
       crc = crc32_combine(crc, crcs[i], static_cast<z_off_t>(hi - lo));
     }
-    return finish_member_on_parser(parser, data, size, threads, nhead + ntail, tj.tail_literal, crc, out, verify_prefix, lap);
+    const bool have_prefix = zlib_thread.joinable();
+    if (have_prefix) zlib_thread.join();
+    return finish_member_on_parser(parser, data, size, threads, nhead + ntail, tj.tail_literal, crc, out, verify_prefix,
+                                   have_prefix ? &zprefix : nullptr, lap);
   }
   std::vector<uint16_t> hd;
   std::vector<uint8_t> hl;
