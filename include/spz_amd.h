@@ -325,6 +325,12 @@ int spz_amd_selftest_device(int mode, uint64_t begin, uint64_t count, uint64_t r
 int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_begin, const uint32_t *h_tail_rec,
                             uint32_t n_rec, int device, void **ctx, uint64_t *num_symbols,
                             uint32_t *tail_first_symbol);
+/* The same; produce_tail_rec(arg), if given, is called on the calling thread once the input is on the device and the
+ * table and match kernels are running (~90 ms of device work for 650 MB): h_tail_rec need not be filled before it
+ * returns, so the caller's serial parse of the input's end can run there instead of before the call. */
+int spz_amd_zlib_parse_open_ex(const uint8_t *h_data, uint64_t size, uint64_t tail_begin, const uint32_t *h_tail_rec,
+                               uint32_t n_rec, int device, void **ctx, uint64_t *num_symbols,
+                               uint32_t *tail_first_symbol, void (*produce_tail_rec)(void *), void *produce_arg);
 int spz_amd_zlib_parse_fetch(void *ctx, uint16_t *h_dist, uint8_t *h_lc);
 void spz_amd_zlib_parse_close(void *ctx);
 

@@ -49,7 +49,7 @@ EXPORTS = (
     "spz_amd_rccl_available", "spz_amd_last_rccl_error", "spz_amd_rccl_unique_id", "spz_amd_rccl_comm_init",
     "spz_amd_rccl_comm_destroy", "spz_amd_gatherv_rccl", "spz_amd_scatterv_rccl",
     "spz_amd_ipc_alloc", "spz_amd_ipc_free", "spz_amd_ipc_open", "spz_amd_ipc_close",
-    "spz_amd_zlib_parse_open", "spz_amd_zlib_parse_fetch", "spz_amd_zlib_parse_close",
+    "spz_amd_zlib_parse_open", "spz_amd_zlib_parse_open_ex", "spz_amd_zlib_parse_fetch", "spz_amd_zlib_parse_close",
     "spz_amd_zlib_parse_append", "spz_amd_zlib_block_stats", "spz_amd_zlib_encode_blocks",
     "spz_amd_inflate_open", "spz_amd_inflate_crc_piece_bytes", "spz_amd_inflate_piece_crcs", "spz_amd_inflate_fetch",
     "spz_amd_inflate_device_data", "spz_amd_inflate_close",
@@ -207,6 +207,8 @@ def bind(L):
     L.spz_amd_selftest_device.argtypes = [i32, u64, u64, C.POINTER(u64 * 3), vp]
     L.spz_amd_zlib_parse_open.restype = i32
     L.spz_amd_zlib_parse_open.argtypes = [vp, u64, u64, vp, u32, i32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u32)]
+    L.spz_amd_zlib_parse_open_ex.restype = i32
+    L.spz_amd_zlib_parse_open_ex.argtypes = [vp, u64, u64, vp, u32, i32, C.POINTER(vp), C.POINTER(u64), C.POINTER(u32), vp, vp]
     L.spz_amd_zlib_parse_fetch.restype = i32
     L.spz_amd_zlib_parse_fetch.argtypes = [vp, vp, vp]
     L.spz_amd_zlib_parse_close.restype = None

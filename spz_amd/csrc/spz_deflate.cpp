@@ -1077,17 +1077,16 @@ bool compressWithHeadParser(const uint8_t *data, size_t size, int threads, HeadP
   tj.d = tail.data() - tail_lo;
   tj.rec_succ_lo = tail_begin;
   tj.rec_succ.assign(OVERLAP + MAX_MATCH + 2, TopRec{});
-  tj.run();
-  if (!tj.phase_ok) return false;
-  lap("tail job");
-
+  // the tail job runs when the parser says its records can wait no longer: beside the device's first kernels
   uint64_t nhead = 0;
   uint32_t tail_first = 0;
   const uint32_t n_rec = static_cast<uint32_t>(std::min<size_t>(tj.rec_succ.size(), spz_lz::kTailWindow));
-  if (!parser.parse(data, size, tail_begin, reinterpret_cast<const uint32_t *>(tj.rec_succ.data()), n_rec, &nhead,
-                    &tail_first)) {
+  auto run_tail = [](void *p) { static_cast<Job *>(p)->run(); };
+  if (!parser.parseLate(data, size, tail_begin, reinterpret_cast<const uint32_t *>(tj.rec_succ.data()), n_rec, run_tail, &tj,
+                        &nhead, &tail_first)) {
     return false;
   }
+  if (!tj.phase_ok) return false;
   lap("head parse");
   if (tail_first > tj.sym_lc.size() || nhead > size) return false;
   if (parser.canFinish()) {

@@ -33,6 +33,13 @@ struct HeadParser {
   // tail job's first contributed symbol.  false = declined (the caller parses on the host).
   virtual bool parse(const uint8_t *data, size_t size, uint64_t tail_begin, const uint32_t *tail_rec, uint32_t n_rec,
                      uint64_t *num_symbols, uint32_t *tail_first_symbol) = 0;
+  // The same for a caller whose tail records do not exist yet: produce(arg) fills tail_rec and is called by the
+  // parser when it has work of its own under way that does not need them (the device: its table and match kernels).
+  virtual bool parseLate(const uint8_t *data, size_t size, uint64_t tail_begin, const uint32_t *tail_rec, uint32_t n_rec,
+                         void (*produce)(void *), void *arg, uint64_t *num_symbols, uint32_t *tail_first_symbol) {
+    produce(arg);
+    return parse(data, size, tail_begin, tail_rec, n_rec, num_symbols, tail_first_symbol);
+  }
   // Copies the head symbols out: distance (0 = literal) and literal byte / match length - 3.
   virtual bool fetch(uint16_t *dist, uint8_t *lc) = 0;
   // Optional: the Huffman stage where the symbols already are (include/spz_amd.h: spz_amd_zlib_parse_append /

@@ -424,6 +424,12 @@ struct DeviceHeadParser final : exactgz::HeadParser {
                                      tail_first_symbol);
     return status == SPZ_AMD_OK;
   }
+  bool parseLate(const uint8_t *data, size_t size, uint64_t tail_begin, const uint32_t *tail_rec, uint32_t n_rec,
+                 void (*produce)(void *), void *arg, uint64_t *num_symbols, uint32_t *tail_first_symbol) override {
+    status = spz_amd_zlib_parse_open_ex(data, size, tail_begin, tail_rec, n_rec, deviceIndex(), &ctx, num_symbols,
+                                        tail_first_symbol, produce, arg);
+    return status == SPZ_AMD_OK;
+  }
   bool fetch(uint16_t *dist, uint8_t *lc) override {
     status = spz_amd_zlib_parse_fetch(ctx, dist, lc);
     return status == SPZ_AMD_OK;

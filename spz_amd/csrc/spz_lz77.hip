@@ -495,9 +495,9 @@ using namespace spz_amd_detail;
 
 extern "C" {
 
-int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_begin, const uint32_t *h_tail_rec,
-                            uint32_t n_rec, int device, void **ctx, uint64_t *num_symbols,
-                            uint32_t *tail_first_symbol) {
+int spz_amd_zlib_parse_open_ex(const uint8_t *h_data, uint64_t size, uint64_t tail_begin, const uint32_t *h_tail_rec,
+                               uint32_t n_rec, int device, void **ctx, uint64_t *num_symbols, uint32_t *tail_first_symbol,
+                               void (*produce_tail_rec)(void *), void *produce_arg) {
   if (h_data == nullptr || h_tail_rec == nullptr || ctx == nullptr || num_symbols == nullptr ||
       tail_first_symbol == nullptr) {
     return SPZ_AMD_ERR_INVALID_ARG;
@@ -579,8 +579,6 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
   SPZ_HIP_TRY(upload_adaptive(d_data, h_data, upload, st));
   if (upload < data_bytes) SPZ_HIP_TRY(hipMemsetAsync(d_data + upload, 0, data_bytes - upload, st));
   SPZ_HIP_TRY(hipMemsetAsync(d_link, 0, pos_padded * sizeof(uint16_t), st));
-  std::vector<uint32_t> tail_states(kTailWindow);
-  for (uint32_t k = 0; k < kTailWindow; ++k) tail_states[k] = h_tail_rec[2 * k];
   lap("upload");
   hipLaunchKernelGGL(lz_table_kernel<TABLE_LINK>, dim3(n_seg), dim3(kLinkThreads), 0, st, d_data, n_pos, d_link);
   SPZ_HIP_TRY(hipGetLastError());
@@ -590,6 +588,10 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
   lap("ranks");
   hipLaunchKernelGGL(lz_match_kernel, dim3(n_tiles), dim3(kMatchThreads), 0, st, d_data, d_link, d_rank, n_pos, size, d_r128, d_r32);
   SPZ_HIP_TRY(hipGetLastError());
+  // the caller's tail parse can run now, beside the kernels above: its records are not read before this point
+  if (produce_tail_rec) produce_tail_rec(produce_arg);
+  std::vector<uint32_t> tail_states(kTailWindow);
+  for (uint32_t k = 0; k < kTailWindow; ++k) tail_states[k] = h_tail_rec[2 * k];
   lap("matches");
   // stage 3, with larger jobs if two neighbours do not meet (the tables do not depend on the jobs)
   uint32_t n_jobs = 0, job_bytes = 0;
@@ -664,6 +666,13 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
   *num_symbols = total_syms;
   *tail_first_symbol = info[n_jobs].lo;
   return SPZ_AMD_OK;
+}
+
+int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_begin, const uint32_t *h_tail_rec,
+                            uint32_t n_rec, int device, void **ctx, uint64_t *num_symbols,
+                            uint32_t *tail_first_symbol) {
+  return spz_amd_zlib_parse_open_ex(h_data, size, tail_begin, h_tail_rec, n_rec, device, ctx, num_symbols, tail_first_symbol,
+                                    nullptr, nullptr);
 }
 
 int spz_amd_zlib_parse_fetch(void *ctx, uint16_t *h_dist, uint8_t *h_lc) {
