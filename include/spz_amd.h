@@ -374,6 +374,16 @@ int spz_amd_zlib_parse_append(void *ctx, const uint16_t *h_dist, const uint8_t *
 int spz_amd_zlib_block_stats(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols,
                              uint32_t num_blocks, uint16_t *h_lfreq, uint16_t *h_dfreq, uint32_t *h_bytes,
                              uint32_t *h_last_len);
+/* encode_blocks in pieces: encode_group enqueues blocks [first_block, first_block + group_blocks) of total_blocks (the
+ * arrays hold the group's entries, header_word_begin counts from the group's first header word; the first group zeroes
+ * a body of body_bytes_bound) and returns without waiting — the caller builds the next group's trees meanwhile;
+ * encode_finish waits and copies the body and every block's bit count out. */
+int spz_amd_zlib_encode_group(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols,
+                              uint32_t total_blocks, uint32_t first_block, uint32_t group_blocks,
+                              const spz_amd_deflate_block *h_blocks, const spz_amd_deflate_codes *h_codes,
+                              const uint32_t *h_header_words, uint64_t num_header_words, uint64_t body_bytes_bound);
+int spz_amd_zlib_encode_finish(void *ctx, uint32_t total_blocks, uint64_t body_bytes, uint8_t *h_body,
+                               uint64_t *h_symbol_bits);
 int spz_amd_zlib_encode_blocks(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols,
                                uint32_t num_blocks, const spz_amd_deflate_block *h_blocks,
                                const spz_amd_deflate_codes *h_codes, const uint32_t *h_header_words,

@@ -684,9 +684,10 @@ bool verify_against_zlib(const uint8_t *data, size_t size, const std::vector<Blo
 }
 
 // ---- serial: positions, stored / static / dynamic, bit offsets (the rest of _tr_flush_block's decision)
-bool layout_blocks(std::vector<Block> &blocks, size_t size, uint64_t *total_bits) {
-  uint64_t pos = 0, bit = 0;
-  for (size_t bi = 0; bi < blocks.size(); ++bi) {
+// Blocks [first, end) given where the ones before them ended (*pos_io input bytes, *bit_io output bits).
+bool layout_block_range(std::vector<Block> &blocks, size_t first, size_t end, size_t size, uint64_t *pos_io, uint64_t *bit_io) {
+  uint64_t pos = *pos_io, bit = *bit_io;
+  for (size_t bi = first; bi < end; ++bi) {
     Block &b = blocks[bi];
     b.start = pos;
     pos += b.bytes;
@@ -712,7 +713,14 @@ bool layout_blocks(std::vector<Block> &blocks, size_t size, uint64_t *total_bits
     if (b.last) b.bit_len += (8 - ((bit + b.bit_len) & 7)) & 7;  // bi_windup
     bit += b.bit_len;
   }
-  if (pos != size) return false;
+  *pos_io = pos;
+  *bit_io = bit;
+  return true;
+}
+
+bool layout_blocks(std::vector<Block> &blocks, size_t size, uint64_t *total_bits) {
+  uint64_t pos = 0, bit = 0;
+  if (!layout_block_range(blocks, 0, blocks.size(), size, &pos, &bit) || pos != size) return false;
   *total_bits = bit;
   return true;
 }
@@ -829,74 +837,91 @@ bool finish_member_on_parser(HeadParser &parser, const uint8_t *data, size_t siz
     return false;
   }
   lap("stats");
+  // Trees and codes are made group by group: while the host builds the next group's trees the device packs the bits
+  // of the one before.
   std::vector<Block> blocks(nblocks);
-  parallel_for(nblocks, threads, [&](size_t bi) {
-    Block &b = blocks[bi];
-    const uint64_t g0 = static_cast<uint64_t>(bi) * BLOCK_SYMS, g1 = std::min<uint64_t>(total_syms, g0 + BLOCK_SYMS);
-    b.nsyms = static_cast<size_t>(g1 - g0);
-    b.last = (bi + 1 == nblocks);
-    for (int i = 0; i < 286; ++i) b.lt.freq[i] = lfreq[bi * 286 + i];
-    for (int i = 0; i < 30; ++i) b.dt.freq[i] = dfreq[bi * 30 + i];
-    b.bytes = bytes[bi];
-    b.last_sym_len = last_len[bi];
-    plan_trees(b);
-  });
-  lap("trees");
-  uint64_t bit = 0;
-  if (!layout_blocks(blocks, size, &bit)) return false;
-  // codes and headers: a block's header is written on the 32-bit grid of the body, starting at the word its first bit is in
   std::vector<spz_amd_deflate_block> desc(nblocks);
   std::vector<spz_amd_deflate_codes> codes(nblocks);
-  std::vector<std::vector<uint8_t>> hdr(nblocks);
-  parallel_for(nblocks, threads, [&](size_t bi) {
-    const Block &b = blocks[bi];
-    BitWriter w;
-    const unsigned lead = static_cast<unsigned>(b.bit_start & 31);
-    for (unsigned i = 0; i < lead / 8; ++i) w.out.push_back(0);
-    w.nbits = static_cast<int>(lead & 7);
-    write_block_header(b, w);
-    spz_amd_deflate_block &d = desc[bi];
-    d.bit_start = b.bit_start;
-    d.header_bits = static_cast<uint32_t>(w.total);
-    if (w.nbits > 0) w.out.push_back(static_cast<uint8_t>(w.acc));
-    while (w.out.size() % 4 != 0) w.out.push_back(0);
-    d.header_words = static_cast<uint32_t>(w.out.size() / 4);
-    d.choice = static_cast<uint32_t>(b.choice);
-    d.input_begin = static_cast<uint32_t>(b.start);
-    d.input_bytes = static_cast<uint32_t>(b.bytes);
-    hdr[bi].swap(w.out);
-    spz_amd_deflate_codes &c = codes[bi];
-    if (b.choice == STATIC) {
-      for (int i = 0; i < 286; ++i) {
-        c.lcode[i] = T.sl_code[i];
-        c.llen[i] = static_cast<uint8_t>(T.sl_len[i]);
+  const uint64_t body_bound = static_cast<uint64_t>(size) + size / 8 + static_cast<uint64_t>(nblocks) * 512 + 4096;
+  const size_t group = std::max<size_t>(64, (nblocks + 5) / 6);
+  uint64_t pos = 0, bit = 0;
+  std::vector<std::vector<uint32_t>> group_words;  // kept until encodeFinish: the copies out of them are only enqueued
+  group_words.reserve(nblocks / group + 1);
+  for (size_t g0b = 0; g0b < nblocks; g0b += group) {
+    const size_t gn = std::min(group, nblocks - g0b);
+    parallel_for(gn, threads, [&](size_t k) {
+      const size_t bi = g0b + k;
+      Block &b = blocks[bi];
+      const uint64_t g0 = static_cast<uint64_t>(bi) * BLOCK_SYMS, g1 = std::min<uint64_t>(total_syms, g0 + BLOCK_SYMS);
+      b.nsyms = static_cast<size_t>(g1 - g0);
+      b.last = (bi + 1 == nblocks);
+      for (int i = 0; i < 286; ++i) b.lt.freq[i] = lfreq[bi * 286 + i];
+      for (int i = 0; i < 30; ++i) b.dt.freq[i] = dfreq[bi * 30 + i];
+      b.bytes = bytes[bi];
+      b.last_sym_len = last_len[bi];
+      plan_trees(b);
+    });
+    if (!layout_block_range(blocks, g0b, g0b + gn, size, &pos, &bit)) return false;
+    if (bit / 8 + 8 > body_bound) return false;
+    // codes and headers: a block's header is written on the 32-bit grid of the body, starting at the word its first bit is in
+    std::vector<std::vector<uint8_t>> hdr(gn);
+    parallel_for(gn, threads, [&](size_t k) {
+      const size_t bi = g0b + k;
+      const Block &b = blocks[bi];
+      BitWriter w;
+      const unsigned lead = static_cast<unsigned>(b.bit_start & 31);
+      for (unsigned i = 0; i < lead / 8; ++i) w.out.push_back(0);
+      w.nbits = static_cast<int>(lead & 7);
+      write_block_header(b, w);
+      spz_amd_deflate_block &d = desc[bi];
+      d.bit_start = b.bit_start;
+      d.header_bits = static_cast<uint32_t>(w.total);
+      if (w.nbits > 0) w.out.push_back(static_cast<uint8_t>(w.acc));
+      while (w.out.size() % 4 != 0) w.out.push_back(0);
+      d.header_words = static_cast<uint32_t>(w.out.size() / 4);
+      d.choice = static_cast<uint32_t>(b.choice);
+      d.input_begin = static_cast<uint32_t>(b.start);
+      d.input_bytes = static_cast<uint32_t>(b.bytes);
+      hdr[k].swap(w.out);
+      spz_amd_deflate_codes &c = codes[bi];
+      if (b.choice == STATIC) {
+        for (int i = 0; i < 286; ++i) {
+          c.lcode[i] = T.sl_code[i];
+          c.llen[i] = static_cast<uint8_t>(T.sl_len[i]);
+        }
+        for (int i = 0; i < 30; ++i) {
+          c.dcode[i] = T.sd_code[i];
+          c.dlen[i] = 5;
+        }
+      } else {
+        for (int i = 0; i < 286; ++i) {
+          c.lcode[i] = b.lt.code[i];
+          c.llen[i] = static_cast<uint8_t>(b.lt.len[i]);
+        }
+        for (int i = 0; i < 30; ++i) {
+          c.dcode[i] = b.dt.code[i];
+          c.dlen[i] = static_cast<uint8_t>(b.dt.len[i]);
+        }
       }
-      for (int i = 0; i < 30; ++i) {
-        c.dcode[i] = T.sd_code[i];
-        c.dlen[i] = 5;
-      }
-    } else {
-      for (int i = 0; i < 286; ++i) {
-        c.lcode[i] = b.lt.code[i];
-        c.llen[i] = static_cast<uint8_t>(b.lt.len[i]);
-      }
-      for (int i = 0; i < 30; ++i) {
-        c.dcode[i] = b.dt.code[i];
-        c.dlen[i] = static_cast<uint8_t>(b.dt.len[i]);
-      }
+    });
+    uint64_t nwords = 0;  // counted from the group's first header word
+    for (size_t k = 0; k < gn; ++k) {
+      desc[g0b + k].header_word_begin = static_cast<uint32_t>(nwords);
+      nwords += desc[g0b + k].header_words;
     }
-  });
-  uint64_t nwords = 0;
-  for (size_t bi = 0; bi < nblocks; ++bi) {
-    desc[bi].header_word_begin = static_cast<uint32_t>(nwords);
-    nwords += desc[bi].header_words;
+    if (nwords >= (uint64_t(1) << 32)) return false;
+    group_words.emplace_back(static_cast<size_t>(nwords) + 1);
+    std::vector<uint32_t> &words = group_words.back();
+    parallel_for(gn, threads, [&](size_t k) {
+      if (!hdr[k].empty()) std::memcpy(&words[desc[g0b + k].header_word_begin], hdr[k].data(), hdr[k].size());
+    });
+    if (!parser.encodeGroup(st, static_cast<uint32_t>(BLOCK_SYMS), static_cast<uint32_t>(nblocks), static_cast<uint32_t>(g0b),
+                            static_cast<uint32_t>(gn), &desc[g0b], &codes[g0b], words.data(), nwords, body_bound)) {
+      return false;
+    }
   }
-  if (nwords >= (uint64_t(1) << 32)) return false;
-  std::vector<uint32_t> words(static_cast<size_t>(nwords) + 1);
-  parallel_for(nblocks, threads, [&](size_t bi) {
-    if (!hdr[bi].empty()) std::memcpy(&words[desc[bi].header_word_begin], hdr[bi].data(), hdr[bi].size());
-  });
-  lap("codes");
+  if (pos != size) return false;
+  lap("trees+codes");
   const uint64_t deflate_bytes = bit / 8;
   out->clear();
   detail::resizeUninitialized(out, static_cast<size_t>(10 + deflate_bytes + 8));
@@ -909,10 +934,7 @@ bool finish_member_on_parser(HeadParser &parser, const uint8_t *data, size_t siz
   const uint8_t header[10] = {0x1f, 0x8b, 0x08, 0x00, 0, 0, 0, 0, 0x00, 0x03};
   std::memcpy(out->data(), header, 10);
   std::vector<uint64_t> symbol_bits(nblocks);
-  if (!parser.encodeBlocks(st, static_cast<uint32_t>(BLOCK_SYMS), static_cast<uint32_t>(nblocks), desc.data(), codes.data(),
-                           words.data(), nwords, deflate_bytes, out->data() + 10, symbol_bits.data())) {
-    return false;
-  }
+  if (!parser.encodeFinish(static_cast<uint32_t>(nblocks), deflate_bytes, out->data() + 10, symbol_bits.data())) return false;
   lap("encode");
   for (size_t bi = 0; bi < nblocks; ++bi) {  // what the encoder wrote against what was planned
     const Block &b = blocks[bi];

@@ -43,7 +43,7 @@ struct HeadParser {
   // Copies the head symbols out: distance (0 = literal) and literal byte / match length - 3.
   virtual bool fetch(uint16_t *dist, uint8_t *lc) = 0;
   // Optional: the Huffman stage where the symbols already are (include/spz_amd.h: spz_amd_zlib_parse_append /
-  // _block_stats / _encode_blocks have the same meaning).  canFinish() false: the caller fetches the symbols and
+  // _block_stats / _encode_group / _encode_finish have the same meaning).  canFinish() false: the caller fetches the symbols and
   // does all of it on the host.
   virtual bool canFinish() const { return false; }
   virtual bool append(const uint16_t *, const uint8_t *, size_t) { return false; }
@@ -51,10 +51,14 @@ struct HeadParser {
                           uint32_t *) {
     return false;
   }
-  virtual bool encodeBlocks(const spz_amd_deflate_static &, uint32_t, uint32_t, const spz_amd_deflate_block *,
-                            const spz_amd_deflate_codes *, const uint32_t *, uint64_t, uint64_t, uint8_t *, uint64_t *) {
+  // encodeGroup: blocks [first, first + n) of `total`, enqueued (the caller goes on to the next group's trees);
+  // encodeFinish waits for all of them and copies the body and the blocks' bit counts out.
+  virtual bool encodeGroup(const spz_amd_deflate_static &, uint32_t /*block_syms*/, uint32_t /*total*/, uint32_t /*first*/,
+                           uint32_t /*n*/, const spz_amd_deflate_block *, const spz_amd_deflate_codes *, const uint32_t *,
+                           uint64_t /*nwords*/, uint64_t /*body_bytes_bound*/) {
     return false;
   }
+  virtual bool encodeFinish(uint32_t /*total*/, uint64_t /*body_bytes*/, uint8_t *, uint64_t *) { return false; }
 };
 bool compressWithHeadParser(const uint8_t *data, size_t size, int threads, HeadParser &parser,
                             std::vector<uint8_t> *out, size_t verify_prefix = 0);

@@ -448,11 +448,14 @@ struct DeviceHeadParser final : exactgz::HeadParser {
     status = spz_amd_zlib_block_stats(ctx, &t, block_syms, nblocks, lfreq, dfreq, bytes, last_len);
     return status == SPZ_AMD_OK;
   }
-  bool encodeBlocks(const spz_amd_deflate_static &t, uint32_t block_syms, uint32_t nblocks, const spz_amd_deflate_block *blocks,
-                    const spz_amd_deflate_codes *codes, const uint32_t *words, uint64_t nwords, uint64_t body_bytes,
-                    uint8_t *body, uint64_t *symbol_bits) override {
-    status = spz_amd_zlib_encode_blocks(ctx, &t, block_syms, nblocks, blocks, codes, words, nwords, body_bytes, body,
-                                        symbol_bits);
+  bool encodeGroup(const spz_amd_deflate_static &t, uint32_t block_syms, uint32_t total, uint32_t first, uint32_t n,
+                   const spz_amd_deflate_block *blocks, const spz_amd_deflate_codes *codes, const uint32_t *words, uint64_t nwords,
+                   uint64_t body_bytes_bound) override {
+    status = spz_amd_zlib_encode_group(ctx, &t, block_syms, total, first, n, blocks, codes, words, nwords, body_bytes_bound);
+    return status == SPZ_AMD_OK;
+  }
+  bool encodeFinish(uint32_t total, uint64_t body_bytes, uint8_t *body, uint64_t *symbol_bits) override {
+    status = spz_amd_zlib_encode_finish(ctx, total, body_bytes, body, symbol_bits);
     return status == SPZ_AMD_OK;
   }
 };

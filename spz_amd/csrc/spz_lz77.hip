@@ -388,11 +388,11 @@ __global__ __launch_bounds__(256) void lz_encode_kernel(const uint16_t *__restri
                                                         const spz_amd_deflate_block *__restrict__ blocks,
                                                         const spz_amd_deflate_codes *__restrict__ codes,
                                                         const uint32_t *__restrict__ header_words, uint32_t *__restrict__ body,
-                                                        unsigned long long *__restrict__ symbol_bits) {
+                                                        unsigned long long *__restrict__ symbol_bits, uint32_t first_block) {
   __shared__ spz_amd_deflate_codes cd;
   __shared__ spz_amd_deflate_static tb;
   __shared__ uint32_t s_scan[kEncodeThreads];
-  const uint32_t tid = threadIdx.x, b = blockIdx.x;
+  const uint32_t tid = threadIdx.x, b = blockIdx.x + first_block;
   const spz_amd_deflate_block blk = blocks[b];
   // the block's header (type bits, trees, or the stored block's length words): placed by the host on the word grid
   for (uint32_t i = tid; i < blk.header_words; i += kEncodeThreads) {
@@ -747,23 +747,51 @@ int spz_amd_zlib_block_stats(void *ctx, const spz_amd_deflate_static *tables, ui
   return SPZ_AMD_OK;
 }
 
-int spz_amd_zlib_encode_blocks(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols, uint32_t num_blocks,
-                               const spz_amd_deflate_block *h_blocks, const spz_amd_deflate_codes *h_codes,
-                               const uint32_t *h_header_words, uint64_t num_header_words, uint64_t body_bytes,
-                               uint8_t *h_body, uint64_t *h_symbol_bits) {
+// Layout of the Huffman stage's device arrays in the memory the parse has left behind.
+namespace {
+struct EncodeArrays {
+  spz_amd_deflate_static *tables;
+  spz_amd_deflate_block *blocks;
+  spz_amd_deflate_codes *codes;
+  unsigned long long *bits;
+  uint32_t *header;
+  size_t header_capacity;  // words
+};
+bool encode_arrays(LzContext *c, uint32_t total_blocks, EncodeArrays *a) {
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    const size_t at = off;
+    off += round_up(bytes, 256);
+    return c->scratch_b + at;
+  };
+  a->tables = reinterpret_cast<spz_amd_deflate_static *>(carve(sizeof(spz_amd_deflate_static)));
+  a->blocks = reinterpret_cast<spz_amd_deflate_block *>(carve((size_t)total_blocks * sizeof(spz_amd_deflate_block)));
+  a->codes = reinterpret_cast<spz_amd_deflate_codes *>(carve((size_t)total_blocks * sizeof(spz_amd_deflate_codes)));
+  a->bits = reinterpret_cast<unsigned long long *>(carve((size_t)total_blocks * sizeof(unsigned long long)));
+  if (off + 4096 > c->scratch_b_bytes) return false;
+  a->header = reinterpret_cast<uint32_t *>(c->scratch_b + off);
+  a->header_capacity = (c->scratch_b_bytes - off) / sizeof(uint32_t);
+  return true;
+}
+}  // namespace
+
+int spz_amd_zlib_encode_group(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols, uint32_t total_blocks,
+                              uint32_t first_block, uint32_t group_blocks, const spz_amd_deflate_block *h_blocks,
+                              const spz_amd_deflate_codes *h_codes, const uint32_t *h_header_words,
+                              uint64_t num_header_words, uint64_t body_bytes_bound) {
   LzContext *c = static_cast<LzContext *>(ctx);
-  if (c == nullptr || tables == nullptr || block_symbols == 0 || num_blocks == 0 || h_blocks == nullptr ||
-      h_codes == nullptr || (num_header_words > 0 && h_header_words == nullptr) || h_body == nullptr ||
-      h_symbol_bits == nullptr) {
+  if (c == nullptr || tables == nullptr || block_symbols == 0 || group_blocks == 0 || h_blocks == nullptr || h_codes == nullptr ||
+      (num_header_words > 0 && h_header_words == nullptr) || (uint64_t)first_block + group_blocks > total_blocks) {
     return SPZ_AMD_ERR_INVALID_ARG;
   }
-  if ((uint64_t)num_blocks * block_symbols < c->num_symbols) return SPZ_AMD_ERR_INVALID_ARG;
-  const size_t body_words = (size_t)((body_bytes + 3) / 4) + 2;
+  if ((uint64_t)total_blocks * block_symbols < c->num_symbols) return SPZ_AMD_ERR_INVALID_ARG;
+  const size_t body_words = (size_t)((body_bytes_bound + 3) / 4) + 2;
   if (body_words * 4 > c->scratch_a_bytes) return SPZ_AMD_ERR_CAPACITY;
-  for (uint32_t b = 0; b < num_blocks; ++b) {  // nothing the kernel writes may leave the body
+  for (uint32_t b = 0; b < group_blocks; ++b) {  // nothing the kernel writes may leave the body
     const spz_amd_deflate_block &k = h_blocks[b];
     if ((uint64_t)k.header_word_begin + k.header_words > num_header_words || (k.bit_start >> 5) + k.header_words > body_words ||
-        (k.choice == 0 && (((k.bit_start + k.header_bits) & 7) != 0 || ((k.bit_start + k.header_bits) >> 3) + k.input_bytes > body_bytes ||
+        (k.choice == 0 && (((k.bit_start + k.header_bits) & 7) != 0 ||
+                           ((k.bit_start + k.header_bits) >> 3) + k.input_bytes > body_bytes_bound ||
                            (uint64_t)k.input_begin + k.input_bytes > c->size))) {
       return SPZ_AMD_ERR_INVALID_ARG;
     }
@@ -771,43 +799,60 @@ int spz_amd_zlib_encode_blocks(void *ctx, const spz_amd_deflate_static *tables, 
   DeviceGuard guard;
   int rc = guard.enter(c->device);
   if (rc != SPZ_AMD_OK) return rc;
-  size_t off = 0;
-  auto carve = [&](size_t bytes) {
-    const size_t at = off;
-    off += round_up(bytes, 256);
-    return c->scratch_b + at;
-  };
-  spz_amd_deflate_static *d_tables = reinterpret_cast<spz_amd_deflate_static *>(carve(sizeof(spz_amd_deflate_static)));
-  spz_amd_deflate_block *d_blocks = reinterpret_cast<spz_amd_deflate_block *>(carve((size_t)num_blocks * sizeof(spz_amd_deflate_block)));
-  spz_amd_deflate_codes *d_codes = reinterpret_cast<spz_amd_deflate_codes *>(carve((size_t)num_blocks * sizeof(spz_amd_deflate_codes)));
-  uint32_t *d_header = reinterpret_cast<uint32_t *>(carve((size_t)(num_header_words + 1) * sizeof(uint32_t)));
-  unsigned long long *d_bits = reinterpret_cast<unsigned long long *>(carve((size_t)num_blocks * sizeof(unsigned long long)));
-  if (off > c->scratch_b_bytes) return SPZ_AMD_ERR_CAPACITY;
+  EncodeArrays a;
+  if (!encode_arrays(c, total_blocks, &a) || num_header_words > a.header_capacity) return SPZ_AMD_ERR_CAPACITY;
   uint32_t *d_body = reinterpret_cast<uint32_t *>(c->scratch_a);
+  hipStream_t st = nullptr;
+  if (first_block == 0) {
+    SPZ_HIP_TRY(hipMemsetAsync(d_body, 0, body_words * 4, st));
+    SPZ_HIP_TRY(hipMemcpyAsync(a.tables, tables, sizeof(*tables), hipMemcpyHostToDevice, st));
+  }
+  SPZ_HIP_TRY(hipMemcpyAsync(a.blocks + first_block, h_blocks, (size_t)group_blocks * sizeof(spz_amd_deflate_block), hipMemcpyHostToDevice, st));
+  SPZ_HIP_TRY(hipMemcpyAsync(a.codes + first_block, h_codes, (size_t)group_blocks * sizeof(spz_amd_deflate_codes), hipMemcpyHostToDevice, st));
+  if (num_header_words) {
+    SPZ_HIP_TRY(hipMemcpyAsync(a.header, h_header_words, (size_t)num_header_words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+  }
+  hipLaunchKernelGGL(lz_encode_kernel, dim3(group_blocks), dim3(kEncodeThreads), 0, st, c->dense_dist, c->dense_lc,
+                     (unsigned long long)c->num_symbols, block_symbols, c->data, a.tables, a.blocks, a.codes, a.header, d_body, a.bits,
+                     first_block);
+  SPZ_HIP_TRY(hipGetLastError());
+  return SPZ_AMD_OK;  // not waited for: the next group's trees can be built meanwhile
+}
+
+int spz_amd_zlib_encode_finish(void *ctx, uint32_t total_blocks, uint64_t body_bytes, uint8_t *h_body, uint64_t *h_symbol_bits) {
+  LzContext *c = static_cast<LzContext *>(ctx);
+  if (c == nullptr || h_body == nullptr || h_symbol_bits == nullptr || total_blocks == 0) return SPZ_AMD_ERR_INVALID_ARG;
+  if (((body_bytes + 3) / 4 + 2) * 4 > c->scratch_a_bytes) return SPZ_AMD_ERR_CAPACITY;
+  DeviceGuard guard;
+  int rc = guard.enter(c->device);
+  if (rc != SPZ_AMD_OK) return rc;
+  EncodeArrays a;
+  if (!encode_arrays(c, total_blocks, &a)) return SPZ_AMD_ERR_CAPACITY;
   hipStream_t st = nullptr;
   static const bool timing = std::getenv("SPZ_AMD_LZ_TIMING") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
-  SPZ_HIP_TRY(hipMemsetAsync(d_body, 0, body_words * 4, st));
-  SPZ_HIP_TRY(hipMemcpyAsync(d_tables, tables, sizeof(*tables), hipMemcpyHostToDevice, st));
-  SPZ_HIP_TRY(hipMemcpyAsync(d_blocks, h_blocks, (size_t)num_blocks * sizeof(spz_amd_deflate_block), hipMemcpyHostToDevice, st));
-  SPZ_HIP_TRY(hipMemcpyAsync(d_codes, h_codes, (size_t)num_blocks * sizeof(spz_amd_deflate_codes), hipMemcpyHostToDevice, st));
-  if (num_header_words) {
-    SPZ_HIP_TRY(hipMemcpyAsync(d_header, h_header_words, (size_t)num_header_words * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-  }
-  hipLaunchKernelGGL(lz_encode_kernel, dim3(num_blocks), dim3(kEncodeThreads), 0, st, c->dense_dist, c->dense_lc,
-                     (unsigned long long)c->num_symbols, block_symbols, c->data, d_tables, d_blocks, d_codes, d_header, d_body, d_bits);
-  SPZ_HIP_TRY(hipGetLastError());
   if (timing) {
     (void)hipStreamSynchronize(st);
-    std::fprintf(stderr, "[lz77] encode     %.4f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    std::fprintf(stderr, "[lz77] encode (what was still running) %.4f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   }
-  SPZ_HIP_TRY(hipMemcpyAsync(h_body, d_body, body_bytes, hipMemcpyDeviceToHost, st));
-  SPZ_HIP_TRY(hipMemcpyAsync(h_symbol_bits, d_bits, (size_t)num_blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  SPZ_HIP_TRY(hipMemcpyAsync(h_body, c->scratch_a, body_bytes, hipMemcpyDeviceToHost, st));
+  SPZ_HIP_TRY(hipMemcpyAsync(h_symbol_bits, a.bits, (size_t)total_blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   SPZ_HIP_TRY(hipStreamSynchronize(st));
   if (timing) {
     std::fprintf(stderr, "[lz77] + download %.4f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   }
   return SPZ_AMD_OK;
+}
+
+int spz_amd_zlib_encode_blocks(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols, uint32_t num_blocks,
+                               const spz_amd_deflate_block *h_blocks, const spz_amd_deflate_codes *h_codes,
+                               const uint32_t *h_header_words, uint64_t num_header_words, uint64_t body_bytes,
+                               uint8_t *h_body, uint64_t *h_symbol_bits) {
+  if (h_body == nullptr || h_symbol_bits == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  const int rc = spz_amd_zlib_encode_group(ctx, tables, block_symbols, num_blocks, 0, num_blocks, h_blocks, h_codes, h_header_words,
+                                           num_header_words, body_bytes);
+  if (rc != SPZ_AMD_OK) return rc;
+  return spz_amd_zlib_encode_finish(ctx, num_blocks, body_bytes, h_body, h_symbol_bits);
 }
 
 }  // extern "C"
