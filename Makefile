@@ -32,11 +32,11 @@ python: $(ROOT)spz_amd/spz$(PYEXT)
 cli:    $(ROOT)spz_amd/bin/spz_tool $(ROOT)spz_amd/bin/dropin_user_test $(ROOT)spz_amd/bin/host_bench
 
 DEVICE_SRCS := $(CSRC)/spz_kernels.hip $(CSRC)/spz_abi.hip $(CSRC)/spz_hostpath.hip $(CSRC)/spz_ply_kernels.hip $(CSRC)/spz_median.hip $(CSRC)/spz_exchange.hip $(CSRC)/spz_lz77.hip $(CSRC)/spz_inflate_dev.hip
-$(LIBDIR)/libspz_amd.so: $(DEVICE_SRCS) $(CSRC)/spz_common.hpp $(CSRC)/spz_kernel_params.hpp $(CSRC)/spz_lz77_core.hpp $(CSRC)/spz_inflate_core.hpp $(INC)/spz_amd.h
+$(LIBDIR)/libspz_amd.so: $(DEVICE_SRCS) $(CSRC)/spz_common.hpp $(CSRC)/spz_kernel_params.hpp $(CSRC)/spz_lz77_core.hpp $(CSRC)/spz_huff_core.hpp $(CSRC)/spz_inflate_core.hpp $(INC)/spz_amd.h
 	mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(DEVICE_SRCS) -ldl
 
-$(LIBDIR)/libspz_host.so: $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp $(CSRC)/spz_deflate.cpp $(CSRC)/spz_lz77_model.cpp $(CSRC)/spz_lz77_core.hpp $(CSRC)/spz_deflate.hpp $(CSRC)/spz_inflate.cpp $(CSRC)/spz_inflate.hpp $(CSRC)/spz_inflate_core.hpp $(CSRC)/spz_host_util.hpp $(INC)/spz_amd_host.hpp $(INC)/spz_amd.h $(LIBDIR)/libspz_amd.so
+$(LIBDIR)/libspz_host.so: $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp $(CSRC)/spz_deflate.cpp $(CSRC)/spz_lz77_model.cpp $(CSRC)/spz_lz77_core.hpp $(CSRC)/spz_huff_core.hpp $(CSRC)/spz_deflate.hpp $(CSRC)/spz_inflate.cpp $(CSRC)/spz_inflate.hpp $(CSRC)/spz_inflate_core.hpp $(CSRC)/spz_host_util.hpp $(INC)/spz_amd_host.hpp $(INC)/spz_amd.h $(LIBDIR)/libspz_amd.so
 	$(CXX) $(CXXFLAGS) -shared -o $@ $(CSRC)/spz_host.cpp $(CSRC)/spz_ply.cpp $(CSRC)/spz_deflate.cpp $(CSRC)/spz_lz77_model.cpp $(CSRC)/spz_inflate.cpp -L$(LIBDIR) -lspz_amd -lz -ldl -lpthread \
 	    -Wl,-rpath,'$$ORIGIN' -Wl,-rpath,/opt/rocm/lib
 

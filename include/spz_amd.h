@@ -374,6 +374,18 @@ int spz_amd_zlib_parse_append(void *ctx, const uint16_t *h_dist, const uint8_t *
 int spz_amd_zlib_block_stats(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols,
                              uint32_t num_blocks, uint16_t *h_lfreq, uint16_t *h_dfreq, uint32_t *h_bytes,
                              uint32_t *h_last_len);
+/* The trees on the device as well (same source as the caller's: spz_huff_core.hpp).  block_trees (after block_stats,
+ * whose h_lfreq / h_dfreq may then both be NULL) builds every block's three trees and returns the two lengths
+ * _tr_flush_block chooses by; the caller lays the blocks out (bit_start, choice, stored input range; the header_*
+ * fields are filled on the device), encode_planned enqueues the writing of headers and symbols and
+ * encode_finish_ex (below) copies out the body and each block's symbol bits and header bits. */
+typedef struct {
+  int64_t opt_len;
+  int64_t static_len;
+} spz_amd_deflate_plan;
+int spz_amd_zlib_block_trees(void *ctx, uint32_t num_blocks, spz_amd_deflate_plan *h_plan);
+int spz_amd_zlib_encode_planned(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols,
+                                uint32_t num_blocks, const spz_amd_deflate_block *h_blocks, uint64_t body_bytes);
 /* encode_blocks in pieces: encode_group enqueues blocks [first_block, first_block + group_blocks) of total_blocks (the
  * arrays hold the group's entries, header_word_begin counts from the group's first header word; the first group zeroes
  * a body of body_bytes_bound) and returns without waiting — the caller builds the next group's trees meanwhile;
@@ -384,6 +396,8 @@ int spz_amd_zlib_encode_group(void *ctx, const spz_amd_deflate_static *tables, u
                               const uint32_t *h_header_words, uint64_t num_header_words, uint64_t body_bytes_bound);
 int spz_amd_zlib_encode_finish(void *ctx, uint32_t total_blocks, uint64_t body_bytes, uint8_t *h_body,
                                uint64_t *h_symbol_bits);
+int spz_amd_zlib_encode_finish_ex(void *ctx, uint32_t total_blocks, uint64_t body_bytes, uint8_t *h_body,
+                                  uint64_t *h_symbol_bits, uint32_t *h_header_bits /* may be NULL */);
 int spz_amd_zlib_encode_blocks(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols,
                                uint32_t num_blocks, const spz_amd_deflate_block *h_blocks,
                                const spz_amd_deflate_codes *h_codes, const uint32_t *h_header_words,

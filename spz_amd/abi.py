@@ -51,7 +51,7 @@ EXPORTS = (
     "spz_amd_ipc_alloc", "spz_amd_ipc_free", "spz_amd_ipc_open", "spz_amd_ipc_close",
     "spz_amd_zlib_parse_open", "spz_amd_zlib_parse_open_ex", "spz_amd_zlib_parse_fetch", "spz_amd_zlib_parse_close",
     "spz_amd_zlib_parse_append", "spz_amd_zlib_block_stats", "spz_amd_zlib_encode_blocks",
-    "spz_amd_zlib_encode_group", "spz_amd_zlib_encode_finish",
+    "spz_amd_zlib_encode_group", "spz_amd_zlib_encode_finish", "spz_amd_zlib_block_trees", "spz_amd_zlib_encode_planned", "spz_amd_zlib_encode_finish_ex",
     "spz_amd_inflate_open", "spz_amd_inflate_crc_piece_bytes", "spz_amd_inflate_piece_crcs", "spz_amd_inflate_fetch",
     "spz_amd_inflate_device_data", "spz_amd_inflate_close",
 )
@@ -236,6 +236,12 @@ def bind(L):
     L.spz_amd_zlib_encode_group.argtypes = [vp, vp, u32, u32, u32, u32, vp, vp, vp, u64, u64]
     L.spz_amd_zlib_encode_finish.restype = i32
     L.spz_amd_zlib_encode_finish.argtypes = [vp, u32, u64, vp, vp]
+    L.spz_amd_zlib_block_trees.restype = i32
+    L.spz_amd_zlib_block_trees.argtypes = [vp, u32, vp]
+    L.spz_amd_zlib_encode_planned.restype = i32
+    L.spz_amd_zlib_encode_planned.argtypes = [vp, vp, u32, u32, vp, u64]
+    L.spz_amd_zlib_encode_finish_ex.restype = i32
+    L.spz_amd_zlib_encode_finish_ex.argtypes = [vp, u32, u64, vp, vp, vp]
     L.spz_amd_zlib_encode_blocks.restype = i32
     L.spz_amd_zlib_encode_blocks.argtypes = [vp, vp, u32, u32, vp, vp, vp, u64, u64, vp, vp]
     return L

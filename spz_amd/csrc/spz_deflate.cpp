@@ -25,6 +25,7 @@
 //  * Reads past the end of the input (the matcher looks up to 258 bytes ahead) see what zlib's window
 //    holds there: the bytes 32 KiB earlier (stale upper half of the window), reproduced in a padded tail.
 #include "spz_deflate.hpp"
+#include "spz_huff_core.hpp"
 #include "spz_host_util.hpp"
 #include "spz_lz77_core.hpp"
 
@@ -311,115 +312,13 @@ const StaticTables &tables() {
   return t;
 }
 
-// ---- trees.c: build_tree / gen_bitlen / gen_codes for one tree --------------------------------------
+// ---- trees.c: build_tree / gen_bitlen / gen_codes for one tree: spz_huff_core.hpp (shared with the device) ----
 struct Tree {
   uint16_t freq[HEAP_SIZE] = {};
   uint16_t len[HEAP_SIZE] = {};
   uint16_t dad[HEAP_SIZE] = {};
   uint16_t code[HEAP_SIZE] = {};
   int max_code = 0;
-};
-
-struct TreeBuilder {
-  int heap[HEAP_SIZE];
-  uint8_t depth[HEAP_SIZE];
-  int heap_len = 0, heap_max = 0;
-  uint16_t bl_count[MAX_BITS + 1];
-  int64_t opt_len = 0, static_len = 0;
-
-  bool smaller(const Tree &t, int n, int m) const {
-    return t.freq[n] < t.freq[m] || (t.freq[n] == t.freq[m] && depth[n] <= depth[m]);
-  }
-  void pqdownheap(const Tree &t, int k) {
-    const int v = heap[k];
-    int j = k << 1;
-    while (j <= heap_len) {
-      if (j < heap_len && smaller(t, heap[j + 1], heap[j])) j++;
-      if (smaller(t, v, heap[j])) break;
-      heap[k] = heap[j];
-      k = j;
-      j <<= 1;
-    }
-    heap[k] = v;
-  }
-  // elems: number of symbols; extra/base: extra bits table; stree: static lengths (nullptr for the bl tree)
-  void build(Tree &t, int elems, const int *extra, int base, int max_length, const uint16_t *stree) {
-    heap_len = 0;
-    heap_max = HEAP_SIZE;
-    int max_code = -1;
-    for (int n = 0; n < elems; ++n) {
-      if (t.freq[n] != 0) {
-        heap[++heap_len] = max_code = n;
-        depth[n] = 0;
-      } else {
-        t.len[n] = 0;
-      }
-    }
-    while (heap_len < 2) {
-      const int node = heap[++heap_len] = (max_code < 2 ? ++max_code : 0);
-      t.freq[node] = 1;
-      depth[node] = 0;
-      opt_len--;
-      if (stree) static_len -= stree[node];
-    }
-    t.max_code = max_code;
-    for (int n = heap_len / 2; n >= 1; --n) pqdownheap(t, n);
-    int node = elems;
-    do {
-      const int n = heap[1];
-      heap[1] = heap[heap_len--];
-      pqdownheap(t, 1);
-      const int m = heap[1];
-      heap[--heap_max] = n;
-      heap[--heap_max] = m;
-      t.freq[node] = static_cast<uint16_t>(t.freq[n] + t.freq[m]);
-      depth[node] = static_cast<uint8_t>((depth[n] >= depth[m] ? depth[n] : depth[m]) + 1);
-      t.dad[n] = t.dad[m] = static_cast<uint16_t>(node);
-      heap[1] = node++;
-      pqdownheap(t, 1);
-    } while (heap_len >= 2);
-    heap[--heap_max] = heap[1];
-    // gen_bitlen
-    for (int bits = 0; bits <= MAX_BITS; ++bits) bl_count[bits] = 0;
-    int overflow = 0, h;
-    t.len[heap[heap_max]] = 0;
-    for (h = heap_max + 1; h < HEAP_SIZE; ++h) {
-      const int n = heap[h];
-      int bits = t.len[t.dad[n]] + 1;
-      if (bits > max_length) bits = max_length, overflow++;
-      t.len[n] = static_cast<uint16_t>(bits);
-      if (n > max_code) continue;
-      bl_count[bits]++;
-      int xbits = 0;
-      if (n >= base) xbits = extra[n - base];
-      const int64_t f = t.freq[n];
-      opt_len += f * (bits + xbits);
-      if (stree) static_len += f * (stree[n] + xbits);
-    }
-    if (overflow != 0) {
-      do {
-        int bits = max_length - 1;
-        while (bl_count[bits] == 0) bits--;
-        bl_count[bits]--;
-        bl_count[bits + 1] += 2;
-        bl_count[max_length]--;
-        overflow -= 2;
-      } while (overflow > 0);
-      for (int bits = max_length; bits != 0; --bits) {
-        int n = bl_count[bits];
-        while (n != 0) {
-          const int m = heap[--h];
-          if (m > max_code) continue;
-          if (t.len[m] != static_cast<unsigned>(bits)) {
-            opt_len += (static_cast<int64_t>(bits) - t.len[m]) * t.freq[m];
-            t.len[m] = static_cast<uint16_t>(bits);
-          }
-          n--;
-        }
-      }
-    }
-    StaticTables::gen_codes(t.len, t.code, max_code, bl_count);
-  }
 };
 
 // Note on freq width: zlib's Freq is 16 bits as well; a block holds at most 32767 symbols + END_BLOCK and
@@ -458,72 +357,40 @@ struct Seg {
 
 enum Choice { STORED = 0, STATIC = 1, DYNAMIC = 2 };
 
-struct Block {
-  std::vector<Seg> segs;
+struct BlockLayout {             // what the stored / static / dynamic choice and the bit offsets need
   size_t nsyms = 0;
   bool last = false;
   uint64_t bytes = 0;          // input bytes the symbols cover (stored_len)
   uint32_t last_sym_len = 0;   // input bytes of the last symbol
   uint64_t start = 0;          // absolute input position of the first byte
-  Tree lt, dt, bt;
-  int max_blindex = 0;
   int64_t opt_len = 0, static_len = 0;
   Choice choice = DYNAMIC;
   uint64_t bit_start = 0, bit_len = 0;
+};
+struct Block : BlockLayout {
+  std::vector<Seg> segs;
+  Tree lt, dt, bt;
+  int max_blindex = 0;
   std::vector<uint8_t> bits;   // encoded block, first byte holds (bit_start & 7) leading zero bits
 };
 
-// scan_tree + send_tree share this walk; `emit(code, extra_value, extra_bits)` is called per bl symbol.
 template <class F>
 void walk_lengths(const Tree &t, int max_code, F emit) {
-  int prevlen = -1, nextlen = t.len[0], count = 0, max_count = 7, min_count = 4;
-  if (nextlen == 0) max_count = 138, min_count = 3;
-  for (int n = 0; n <= max_code; ++n) {
-    const int curlen = nextlen;
-    nextlen = (n == max_code) ? 0xffff : t.len[n + 1];  // the guard zlib stores at tree[max_code + 1]
-    if (++count < max_count && curlen == nextlen) continue;
-    if (count < min_count) {
-      for (int i = 0; i < count; ++i) emit(curlen, 0, 0);
-    } else if (curlen != 0) {
-      if (curlen != prevlen) {
-        emit(curlen, 0, 0);
-        count--;
-      }
-      emit(REP_3_6, count - 3, 2);
-    } else if (count <= 10) {
-      emit(REPZ_3_10, count - 3, 3);
-    } else {
-      emit(REPZ_11_138, count - 11, 7);
-    }
-    count = 0;
-    prevlen = curlen;
-    if (nextlen == 0) max_count = 138, min_count = 3;
-    else if (curlen == nextlen) max_count = 6, min_count = 3;
-    else max_count = 7, min_count = 4;
-  }
+  huff::walk_lengths(t.len, max_code, emit);
 }
 
 void plan_trees(Block &b) {  // the first half of _tr_flush_block, from the tallied frequencies
-  const StaticTables &T = tables();
-  b.lt.freq[END_BLOCK] = 1;  // init_block
-  TreeBuilder tb;
-  tb.build(b.lt, L_CODES, kExtraL, LITERALS + 1, MAX_BITS, T.sl_len);
-  static const uint16_t kStaticDLen[D_CODES] = {5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5,
-                                                5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5, 5};
-  tb.build(b.dt, D_CODES, kExtraD, 0, MAX_BITS, kStaticDLen);
-  // build_bl_tree
-  auto count = [&](int code, int, int) { b.bt.freq[code]++; };
-  walk_lengths(b.lt, b.lt.max_code, count);
-  walk_lengths(b.dt, b.dt.max_code, count);
-  tb.build(b.bt, BL_CODES, kExtraBl, 0, MAX_BL_BITS, nullptr);
-  int max_blindex = BL_CODES - 1;
-  for (; max_blindex >= 3; --max_blindex) {
-    if (b.bt.len[kBlOrder[max_blindex]] != 0) break;
-  }
-  tb.opt_len += 3 * (static_cast<int64_t>(max_blindex) + 1) + 5 + 5 + 4;
-  b.max_blindex = max_blindex;
-  b.opt_len = tb.opt_len;
-  b.static_len = tb.static_len;
+  uint16_t heap[HEAP_SIZE], bl_count[MAX_BITS + 1], next_code[MAX_BITS + 1];
+  uint8_t depth[HEAP_SIZE];
+  huff::Work w = {heap, depth, bl_count, next_code, 0, 0, 0, 0};
+  huff::TreeRef<uint16_t> lt = {b.lt.freq, b.lt.dad, b.lt.len, b.lt.code, 0}, dt = {b.dt.freq, b.dt.dad, b.dt.len, b.dt.code, 0},
+                          bt = {b.bt.freq, b.bt.dad, b.bt.len, b.bt.code, 0};
+  b.max_blindex = huff::plan_trees(lt, dt, bt, w, static_cast<const uint16_t *>(b.lt.len), static_cast<const uint16_t *>(b.dt.len));
+  b.lt.max_code = lt.max_code;
+  b.dt.max_code = dt.max_code;
+  b.bt.max_code = bt.max_code;
+  b.opt_len = w.opt_len;
+  b.static_len = w.static_len;
 }
 
 void plan_block(Block &b) {  // the tally loop, then the trees
@@ -665,11 +532,12 @@ std::vector<uint8_t> zlib_prefix_member(const uint8_t *data, uint64_t verify) {
   return z;
 }
 
-bool matches_zlib_prefix(const std::vector<uint8_t> &z, size_t size, const std::vector<Block> &blocks,
+template <class B>
+bool matches_zlib_prefix(const std::vector<uint8_t> &z, size_t size, const std::vector<B> &blocks,
                          const std::vector<uint8_t> &member, size_t verify_prefix) {
   const uint64_t verify = std::min<uint64_t>(size, verify_prefix);
   uint64_t safe_bits = 0;
-  for (const Block &b : blocks) {
+  for (const B &b : blocks) {
     const uint64_t end_pos = b.start + b.bytes;
     if (verify == size || end_pos + 1024 <= verify) safe_bits = b.bit_start + b.bit_len;
     else break;
@@ -678,17 +546,19 @@ bool matches_zlib_prefix(const std::vector<uint8_t> &z, size_t size, const std::
   return !z.empty() && z.size() >= safe_bytes && member.size() >= safe_bytes && std::memcmp(z.data(), member.data(), safe_bytes) == 0;
 }
 
-bool verify_against_zlib(const uint8_t *data, size_t size, const std::vector<Block> &blocks, const std::vector<uint8_t> &member,
+template <class B>
+bool verify_against_zlib(const uint8_t *data, size_t size, const std::vector<B> &blocks, const std::vector<uint8_t> &member,
                          size_t verify_prefix) {
   return matches_zlib_prefix(zlib_prefix_member(data, std::min<uint64_t>(size, verify_prefix)), size, blocks, member, verify_prefix);
 }
 
 // ---- serial: positions, stored / static / dynamic, bit offsets (the rest of _tr_flush_block's decision)
 // Blocks [first, end) given where the ones before them ended (*pos_io input bytes, *bit_io output bits).
-bool layout_block_range(std::vector<Block> &blocks, size_t first, size_t end, size_t size, uint64_t *pos_io, uint64_t *bit_io) {
+template <class B>
+bool layout_block_range(std::vector<B> &blocks, size_t first, size_t end, size_t size, uint64_t *pos_io, uint64_t *bit_io) {
   uint64_t pos = *pos_io, bit = *bit_io;
   for (size_t bi = first; bi < end; ++bi) {
-    Block &b = blocks[bi];
+    B &b = blocks[bi];
     b.start = pos;
     pos += b.bytes;
     // loop top of the iteration that tallied the block's last symbol (Z_FINISH flush: the end of the input)
@@ -718,7 +588,8 @@ bool layout_block_range(std::vector<Block> &blocks, size_t first, size_t end, si
   return true;
 }
 
-bool layout_blocks(std::vector<Block> &blocks, size_t size, uint64_t *total_bits) {
+template <class B>
+bool layout_blocks(std::vector<B> &blocks, size_t size, uint64_t *total_bits) {
   uint64_t pos = 0, bit = 0;
   if (!layout_block_range(blocks, 0, blocks.size(), size, &pos, &bit) || pos != size) return false;
   *total_bits = bit;
@@ -830,13 +701,79 @@ bool finish_member_on_parser(HeadParser &parser, const uint8_t *data, size_t siz
   }
   size_t nblocks = static_cast<size_t>(total_syms / BLOCK_SYMS) + 1;
   if (total_syms > 0 && total_syms % BLOCK_SYMS == 0 && tail_literal) nblocks -= 1;
-  std::vector<uint16_t> lfreq(nblocks * 286), dfreq(nblocks * 30);
+  const bool device_trees = parser.canBuildTrees();
+  std::vector<uint16_t> lfreq(device_trees ? 0 : nblocks * 286), dfreq(device_trees ? 0 : nblocks * 30);
   std::vector<uint32_t> bytes(nblocks), last_len(nblocks);
-  if (!parser.blockStats(st, static_cast<uint32_t>(BLOCK_SYMS), static_cast<uint32_t>(nblocks), lfreq.data(), dfreq.data(),
-                         bytes.data(), last_len.data())) {
+  if (!parser.blockStats(st, static_cast<uint32_t>(BLOCK_SYMS), static_cast<uint32_t>(nblocks), device_trees ? nullptr : lfreq.data(),
+                         device_trees ? nullptr : dfreq.data(), bytes.data(), last_len.data())) {
     return false;
   }
   lap("stats");
+  auto trailer_and_check = [&](const auto &blocks, uint64_t deflate_bytes) {
+    uint8_t *trailer = out->data() + 10 + deflate_bytes;
+    for (int k2 = 0; k2 < 4; ++k2) trailer[k2] = static_cast<uint8_t>(crc >> (8 * k2));
+    for (int k2 = 0; k2 < 4; ++k2) trailer[4 + k2] = static_cast<uint8_t>((size & 0xffffffffu) >> (8 * k2));
+    if (verify_prefix == 0) return true;
+    return zlib_prefix ? matches_zlib_prefix(*zlib_prefix, size, blocks, *out, verify_prefix)
+                       : verify_against_zlib(data, size, blocks, *out, verify_prefix);
+  };
+  if (device_trees) {  // the trees are built where the counts are; the layout of the blocks is all that is left here
+    std::vector<spz_amd_deflate_plan> plan(nblocks);
+    if (!parser.blockTrees(static_cast<uint32_t>(nblocks), plan.data())) return false;
+    lap("trees");
+    std::vector<BlockLayout> blocks(nblocks);
+    for (size_t bi = 0; bi < nblocks; ++bi) {
+      BlockLayout &b = blocks[bi];
+      const uint64_t g0 = static_cast<uint64_t>(bi) * BLOCK_SYMS, g1 = std::min<uint64_t>(total_syms, g0 + BLOCK_SYMS);
+      b.nsyms = static_cast<size_t>(g1 - g0);
+      b.last = (bi + 1 == nblocks);
+      b.bytes = bytes[bi];
+      b.last_sym_len = last_len[bi];
+      b.opt_len = plan[bi].opt_len;
+      b.static_len = plan[bi].static_len;
+    }
+    uint64_t bit = 0;
+    if (!layout_blocks(blocks, size, &bit)) return false;
+    std::vector<spz_amd_deflate_block> desc(nblocks);
+    for (size_t bi = 0; bi < nblocks; ++bi) {
+      desc[bi] = {};
+      desc[bi].bit_start = blocks[bi].bit_start;
+      desc[bi].choice = static_cast<uint32_t>(blocks[bi].choice);
+      desc[bi].input_begin = static_cast<uint32_t>(blocks[bi].start);
+      desc[bi].input_bytes = static_cast<uint32_t>(blocks[bi].bytes);
+    }
+    const uint64_t deflate_bytes = bit / 8;
+    if (!parser.encodePlanned(st, static_cast<uint32_t>(BLOCK_SYMS), static_cast<uint32_t>(nblocks), desc.data(), deflate_bytes)) {
+      return false;
+    }
+    // while the device writes headers and symbols: the output buffer, its pages mapped
+    out->clear();
+    detail::resizeUninitialized(out, static_cast<size_t>(10 + deflate_bytes + 8));
+    {
+      detail::Prefault pf;
+      pf.add(out->data(), out->size());
+      pf.start();
+      pf.join();
+    }
+    const uint8_t header[10] = {0x1f, 0x8b, 0x08, 0x00, 0, 0, 0, 0, 0x00, 0x03};
+    std::memcpy(out->data(), header, 10);
+    lap("layout");
+    std::vector<uint64_t> symbol_bits(nblocks);
+    std::vector<uint32_t> header_bits(nblocks);
+    if (!parser.encodeFinish(static_cast<uint32_t>(nblocks), deflate_bytes, out->data() + 10, symbol_bits.data(), header_bits.data())) {
+      return false;
+    }
+    lap("encode");
+    for (size_t bi = 0; bi < nblocks; ++bi) {  // what the device wrote against what was planned
+      const BlockLayout &b = blocks[bi];
+      uint64_t planned = b.bit_len - header_bits[bi];
+      if (b.last) planned -= (8 - ((b.bit_start + header_bits[bi] + symbol_bits[bi]) & 7)) & 7;
+      if (header_bits[bi] > b.bit_len || symbol_bits[bi] != planned) return false;
+    }
+    if (!trailer_and_check(blocks, deflate_bytes)) return false;
+    lap("verify");
+    return true;
+  }
   // Trees and codes are made group by group: while the host builds the next group's trees the device packs the bits
   // of the one before.
   std::vector<Block> blocks(nblocks);
@@ -934,7 +871,7 @@ bool finish_member_on_parser(HeadParser &parser, const uint8_t *data, size_t siz
   const uint8_t header[10] = {0x1f, 0x8b, 0x08, 0x00, 0, 0, 0, 0, 0x00, 0x03};
   std::memcpy(out->data(), header, 10);
   std::vector<uint64_t> symbol_bits(nblocks);
-  if (!parser.encodeFinish(static_cast<uint32_t>(nblocks), deflate_bytes, out->data() + 10, symbol_bits.data())) return false;
+  if (!parser.encodeFinish(static_cast<uint32_t>(nblocks), deflate_bytes, out->data() + 10, symbol_bits.data(), nullptr)) return false;
   lap("encode");
   for (size_t bi = 0; bi < nblocks; ++bi) {  // what the encoder wrote against what was planned
     const Block &b = blocks[bi];

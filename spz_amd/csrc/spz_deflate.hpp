@@ -58,7 +58,18 @@ struct HeadParser {
                            uint64_t /*nwords*/, uint64_t /*body_bytes_bound*/) {
     return false;
   }
-  virtual bool encodeFinish(uint32_t /*total*/, uint64_t /*body_bytes*/, uint8_t *, uint64_t *) { return false; }
+  virtual bool encodeFinish(uint32_t /*total*/, uint64_t /*body_bytes*/, uint8_t *, uint64_t * /*symbol_bits*/,
+                            uint32_t * /*header_bits, may be null*/) {
+    return false;
+  }
+  // Optional: the trees there as well (spz_amd_zlib_block_trees / _encode_planned); blockStats is then called with
+  // null frequency arrays.
+  virtual bool canBuildTrees() const { return false; }
+  virtual bool blockTrees(uint32_t /*total*/, spz_amd_deflate_plan *) { return false; }
+  virtual bool encodePlanned(const spz_amd_deflate_static &, uint32_t /*block_syms*/, uint32_t /*total*/,
+                             const spz_amd_deflate_block *, uint64_t /*body_bytes*/) {  // enqueued; then encodeFinish
+    return false;
+  }
 };
 bool compressWithHeadParser(const uint8_t *data, size_t size, int threads, HeadParser &parser,
                             std::vector<uint8_t> *out, size_t verify_prefix = 0);

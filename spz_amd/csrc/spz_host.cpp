@@ -448,14 +448,27 @@ struct DeviceHeadParser final : exactgz::HeadParser {
     status = spz_amd_zlib_block_stats(ctx, &t, block_syms, nblocks, lfreq, dfreq, bytes, last_len);
     return status == SPZ_AMD_OK;
   }
+  bool canBuildTrees() const override {
+    const char *e = std::getenv("SPZ_AMD_GZIP_DEVICE_TREES");
+    return !(e && e[0] == '0');
+  }
+  bool blockTrees(uint32_t total, spz_amd_deflate_plan *plan) override {
+    status = spz_amd_zlib_block_trees(ctx, total, plan);
+    return status == SPZ_AMD_OK;
+  }
+  bool encodePlanned(const spz_amd_deflate_static &t, uint32_t block_syms, uint32_t total, const spz_amd_deflate_block *blocks,
+                     uint64_t body_bytes) override {
+    status = spz_amd_zlib_encode_planned(ctx, &t, block_syms, total, blocks, body_bytes);
+    return status == SPZ_AMD_OK;
+  }
   bool encodeGroup(const spz_amd_deflate_static &t, uint32_t block_syms, uint32_t total, uint32_t first, uint32_t n,
                    const spz_amd_deflate_block *blocks, const spz_amd_deflate_codes *codes, const uint32_t *words, uint64_t nwords,
                    uint64_t body_bytes_bound) override {
     status = spz_amd_zlib_encode_group(ctx, &t, block_syms, total, first, n, blocks, codes, words, nwords, body_bytes_bound);
     return status == SPZ_AMD_OK;
   }
-  bool encodeFinish(uint32_t total, uint64_t body_bytes, uint8_t *body, uint64_t *symbol_bits) override {
-    status = spz_amd_zlib_encode_finish(ctx, total, body_bytes, body, symbol_bits);
+  bool encodeFinish(uint32_t total, uint64_t body_bytes, uint8_t *body, uint64_t *symbol_bits, uint32_t *header_bits) override {
+    status = spz_amd_zlib_encode_finish_ex(ctx, total, body_bytes, body, symbol_bits, header_bits);
     return status == SPZ_AMD_OK;
   }
 };

@@ -37,6 +37,7 @@
 
 #include "spz_amd.h"
 #include "spz_common.hpp"
+#include "spz_huff_core.hpp"
 #include "spz_lz77_core.hpp"
 
 namespace spz_amd_detail {
@@ -379,6 +380,135 @@ struct BitSink {
   }
 };
 
+// ---- the trees on the device (spz_huff_core.hpp: the host writer's own source).  Building one block's trees is a serial
+// walk over a heap, so a lane takes a block; its working memory (4.5 KB) is in LDS, which is what makes the walk's
+// dependent accesses cheap, and only kTreeLanes lanes of a wave work so that four workgroups share a CU.
+namespace hf = spz::huff;
+constexpr int kTreeLanes = 8;
+constexpr uint32_t kHeaderStride = 144;  // words per block header: 31 lead bits + 3 + 14 + 57 + 316 * 14 bits at most
+
+struct TreeLds {
+  uint16_t lt_freq[hf::HEAP_SIZE], lt_dl[hf::HEAP_SIZE];
+  uint16_t dt_freq[2 * hf::D_CODES + 1], dt_dl[2 * hf::D_CODES + 1];
+  uint16_t bt_freq[2 * hf::BL_CODES + 1], bt_dl[2 * hf::BL_CODES + 1], bt_code[hf::BL_CODES + 1];
+  uint16_t heap[hf::HEAP_SIZE], bl_count[hf::MAX_BITS + 1], next_code[hf::MAX_BITS + 1];
+  uint8_t depth[hf::HEAP_SIZE + 1];
+};
+
+struct BlockTrees {  // what the header needs beyond the literal and distance code lengths
+  long long opt_len, static_len;
+  uint16_t bl_code[hf::BL_CODES];
+  uint8_t bl_len[hf::BL_CODES];
+  uint8_t max_blindex;
+  uint16_t lcodes, dcodes;
+};
+
+__global__ __launch_bounds__(64) void lz_tree_kernel(const uint16_t *__restrict__ lfreq, const uint16_t *__restrict__ dfreq,
+                                                     uint32_t num_blocks, spz_amd_deflate_codes *__restrict__ codes,
+                                                     BlockTrees *__restrict__ trees, spz_amd_deflate_plan *__restrict__ plan) {
+  __shared__ TreeLds lds[kTreeLanes];
+  const uint32_t lane = threadIdx.x, b = blockIdx.x * kTreeLanes + lane;
+  if (lane >= (uint32_t)kTreeLanes || b >= num_blocks) return;
+  TreeLds &m = lds[lane];
+  for (int i = 0; i < hf::L_CODES; ++i) m.lt_freq[i] = lfreq[(size_t)b * hf::L_CODES + i];
+  for (int i = 0; i < hf::D_CODES; ++i) m.dt_freq[i] = dfreq[(size_t)b * hf::D_CODES + i];
+  spz_amd_deflate_codes &cd = codes[b];
+  hf::TreeRef<uint16_t> lt = {m.lt_freq, m.lt_dl, m.lt_dl, cd.lcode, 0}, dt = {m.dt_freq, m.dt_dl, m.dt_dl, cd.dcode, 0},
+                        bt = {m.bt_freq, m.bt_dl, m.bt_dl, m.bt_code, 0};
+  hf::Work w = {m.heap, m.depth, m.bl_count, m.next_code, 0, 0, 0, 0};
+  const int max_blindex = hf::plan_trees(lt, dt, bt, w, static_cast<const uint16_t *>(m.lt_dl), static_cast<const uint16_t *>(m.dt_dl));
+  for (int i = 0; i < hf::L_CODES; ++i) {
+    const uint16_t l = m.lt_dl[i];
+    cd.llen[i] = (uint8_t)l;
+    if (l == 0) cd.lcode[i] = 0;
+  }
+  for (int i = 0; i < hf::D_CODES; ++i) {
+    const uint16_t l = m.dt_dl[i];
+    cd.dlen[i] = (uint8_t)l;
+    if (l == 0) cd.dcode[i] = 0;
+  }
+  BlockTrees &t = trees[b];
+  t.opt_len = w.opt_len;
+  t.static_len = w.static_len;
+  for (int i = 0; i < hf::BL_CODES; ++i) {
+    t.bl_len[i] = (uint8_t)m.bt_dl[i];
+    t.bl_code[i] = m.bt_dl[i] ? m.bt_code[i] : (uint16_t)0;
+  }
+  t.max_blindex = (uint8_t)max_blindex;
+  t.lcodes = (uint16_t)(lt.max_code + 1);
+  t.dcodes = (uint16_t)(dt.max_code + 1);
+  plan[b].opt_len = w.opt_len;
+  plan[b].static_len = w.static_len;
+}
+
+// What a block writes before its first symbol (trees.c: _tr_stored_block's header, the static block's type bits, or
+// send_all_trees), on the 32-bit grid of the body; a static block's codes replace the block's own.
+struct HeaderSink {
+  uint32_t *out;
+  uint32_t words;
+  unsigned long long acc;
+  uint32_t fill, total;
+  __device__ __forceinline__ void put(uint32_t value, uint32_t nbits) {
+    acc |= (unsigned long long)value << fill;
+    fill += nbits;
+    total += nbits;
+    if (fill >= 32u) {
+      out[words++] = (uint32_t)acc;
+      acc >>= 32;
+      fill -= 32u;
+    }
+  }
+};
+
+__global__ __launch_bounds__(64) void lz_header_kernel(spz_amd_deflate_block *__restrict__ blocks, spz_amd_deflate_codes *__restrict__ codes,
+                                                       const BlockTrees *__restrict__ trees, uint32_t *__restrict__ header,
+                                                       uint32_t num_blocks) {
+  const uint32_t b = blockIdx.x * 64u + threadIdx.x;
+  if (b >= num_blocks) return;
+  const spz_amd_deflate_block blk = blocks[b];
+  const uint32_t last = (b + 1u == num_blocks) ? 1u : 0u;
+  HeaderSink s = {header + (size_t)b * kHeaderStride, 0u, 0ull, (uint32_t)(blk.bit_start & 31ull), 0u};
+  if (blk.choice == 0u) {
+    s.put(last, 3);
+    const uint32_t pad = (8u - (s.fill & 7u)) & 7u;  // bi_windup
+    if (pad) s.put(0u, pad);
+    s.put(blk.input_bytes & 0xffffu, 16);
+    s.put(~blk.input_bytes & 0xffffu, 16);
+  } else if (blk.choice == 1u) {
+    s.put(2u + last, 3);
+    spz_amd_deflate_codes &cd = codes[b];
+    for (uint32_t n = 0; n < (uint32_t)hf::L_CODES; ++n) {
+      const uint32_t len = (uint32_t)hf::static_llen((int)n);
+      const uint32_t code = n <= 143u ? 0x30u + n : n <= 255u ? 0x190u + (n - 144u) : n <= 279u ? n - 256u : 0xC0u + (n - 280u);
+      cd.lcode[n] = (uint16_t)hf::bit_reverse(code, (int)len);
+      cd.llen[n] = (uint8_t)len;
+    }
+    for (uint32_t n = 0; n < (uint32_t)hf::D_CODES; ++n) {
+      cd.dcode[n] = (uint16_t)hf::bit_reverse(n, 5);
+      cd.dlen[n] = 5;
+    }
+  } else {
+    const BlockTrees &t = trees[b];
+    const spz_amd_deflate_codes &cd = codes[b];
+    s.put(4u + last, 3);
+    const uint32_t blcodes = (uint32_t)t.max_blindex + 1u;
+    s.put((uint32_t)t.lcodes - 257u, 5);
+    s.put((uint32_t)t.dcodes - 1u, 5);
+    s.put(blcodes - 4u, 4);
+    for (uint32_t rank = 0; rank < blcodes; ++rank) s.put(t.bl_len[hf::bl_order((int)rank)], 3);
+    auto send = [&](int code, int extra_value, int extra_bits) {
+      s.put(t.bl_code[code], t.bl_len[code]);
+      if (extra_bits) s.put((uint32_t)extra_value, (uint32_t)extra_bits);
+    };
+    hf::walk_lengths(static_cast<const uint8_t *>(cd.llen), (int)t.lcodes - 1, send);
+    hf::walk_lengths(static_cast<const uint8_t *>(cd.dlen), (int)t.dcodes - 1, send);
+  }
+  if (s.fill > 0u) s.out[s.words++] = (uint32_t)s.acc;
+  blocks[b].header_word_begin = b * kHeaderStride;
+  blocks[b].header_words = s.words;
+  blocks[b].header_bits = s.total;
+}
+
 constexpr uint32_t kEncodeThreads = 256;
 
 __global__ __launch_bounds__(256) void lz_encode_kernel(const uint16_t *__restrict__ dist, const uint8_t *__restrict__ lc,
@@ -711,38 +841,53 @@ int spz_amd_zlib_parse_append(void *ctx, const uint16_t *h_dist, const uint8_t *
   return SPZ_AMD_OK;
 }
 
-int spz_amd_zlib_block_stats(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols, uint32_t num_blocks,
-                             uint16_t *h_lfreq, uint16_t *h_dfreq, uint32_t *h_bytes, uint32_t *h_last_len) {
-  LzContext *c = static_cast<LzContext *>(ctx);
-  if (c == nullptr || tables == nullptr || block_symbols == 0 || num_blocks == 0 || h_lfreq == nullptr ||
-      h_dfreq == nullptr || h_bytes == nullptr || h_last_len == nullptr) {
-    return SPZ_AMD_ERR_INVALID_ARG;
-  }
-  if ((uint64_t)num_blocks * block_symbols < c->num_symbols) return SPZ_AMD_ERR_INVALID_ARG;
-  DeviceGuard guard;
-  int rc = guard.enter(c->device);
-  if (rc != SPZ_AMD_OK) return rc;
+// Layout of the block statistics in scratch_c.
+namespace {
+struct StatArrays {
+  spz_amd_deflate_static *tables;
+  uint16_t *lfreq, *dfreq;
+  uint32_t *bytes, *last;
+};
+bool stat_arrays(LzContext *c, uint32_t num_blocks, StatArrays *a) {
   size_t off = 0;
   auto carve = [&](size_t bytes) {
     const size_t at = off;
     off += round_up(bytes, 256);
     return c->scratch_c + at;
   };
-  spz_amd_deflate_static *d_tables = reinterpret_cast<spz_amd_deflate_static *>(carve(sizeof(spz_amd_deflate_static)));
-  uint16_t *d_lfreq = reinterpret_cast<uint16_t *>(carve((size_t)num_blocks * 286 * sizeof(uint16_t)));
-  uint16_t *d_dfreq = reinterpret_cast<uint16_t *>(carve((size_t)num_blocks * 30 * sizeof(uint16_t)));
-  uint32_t *d_bytes = reinterpret_cast<uint32_t *>(carve((size_t)num_blocks * sizeof(uint32_t)));
-  uint32_t *d_last = reinterpret_cast<uint32_t *>(carve((size_t)num_blocks * sizeof(uint32_t)));
-  if (off > c->scratch_c_bytes) return SPZ_AMD_ERR_CAPACITY;
+  a->tables = reinterpret_cast<spz_amd_deflate_static *>(carve(sizeof(spz_amd_deflate_static)));
+  a->lfreq = reinterpret_cast<uint16_t *>(carve((size_t)num_blocks * 286 * sizeof(uint16_t)));
+  a->dfreq = reinterpret_cast<uint16_t *>(carve((size_t)num_blocks * 30 * sizeof(uint16_t)));
+  a->bytes = reinterpret_cast<uint32_t *>(carve((size_t)num_blocks * sizeof(uint32_t)));
+  a->last = reinterpret_cast<uint32_t *>(carve((size_t)num_blocks * sizeof(uint32_t)));
+  return off <= c->scratch_c_bytes;
+}
+}  // namespace
+
+int spz_amd_zlib_block_stats(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols, uint32_t num_blocks,
+                             uint16_t *h_lfreq, uint16_t *h_dfreq, uint32_t *h_bytes, uint32_t *h_last_len) {
+  LzContext *c = static_cast<LzContext *>(ctx);
+  if (c == nullptr || tables == nullptr || block_symbols == 0 || num_blocks == 0 || h_bytes == nullptr || h_last_len == nullptr ||
+      (h_lfreq == nullptr) != (h_dfreq == nullptr)) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  if ((uint64_t)num_blocks * block_symbols < c->num_symbols) return SPZ_AMD_ERR_INVALID_ARG;
+  DeviceGuard guard;
+  int rc = guard.enter(c->device);
+  if (rc != SPZ_AMD_OK) return rc;
+  StatArrays a;
+  if (!stat_arrays(c, num_blocks, &a)) return SPZ_AMD_ERR_CAPACITY;
   hipStream_t st = nullptr;
-  SPZ_HIP_TRY(hipMemcpyAsync(d_tables, tables, sizeof(*tables), hipMemcpyHostToDevice, st));
+  SPZ_HIP_TRY(hipMemcpyAsync(a.tables, tables, sizeof(*tables), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(lz_block_stats_kernel, dim3(num_blocks), dim3(256), 0, st, c->dense_dist, c->dense_lc,
-                     (unsigned long long)c->num_symbols, block_symbols, d_tables, d_lfreq, d_dfreq, d_bytes, d_last);
+                     (unsigned long long)c->num_symbols, block_symbols, a.tables, a.lfreq, a.dfreq, a.bytes, a.last);
   SPZ_HIP_TRY(hipGetLastError());
-  SPZ_HIP_TRY(hipMemcpyAsync(h_lfreq, d_lfreq, (size_t)num_blocks * 286 * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
-  SPZ_HIP_TRY(hipMemcpyAsync(h_dfreq, d_dfreq, (size_t)num_blocks * 30 * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
-  SPZ_HIP_TRY(hipMemcpyAsync(h_bytes, d_bytes, (size_t)num_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  SPZ_HIP_TRY(hipMemcpyAsync(h_last_len, d_last, (size_t)num_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  if (h_lfreq != nullptr) {  // a caller that builds the trees itself
+    SPZ_HIP_TRY(hipMemcpyAsync(h_lfreq, a.lfreq, (size_t)num_blocks * 286 * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
+    SPZ_HIP_TRY(hipMemcpyAsync(h_dfreq, a.dfreq, (size_t)num_blocks * 30 * sizeof(uint16_t), hipMemcpyDeviceToHost, st));
+  }
+  SPZ_HIP_TRY(hipMemcpyAsync(h_bytes, a.bytes, (size_t)num_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  SPZ_HIP_TRY(hipMemcpyAsync(h_last_len, a.last, (size_t)num_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   SPZ_HIP_TRY(hipStreamSynchronize(st));
   return SPZ_AMD_OK;
 }
@@ -754,6 +899,8 @@ struct EncodeArrays {
   spz_amd_deflate_block *blocks;
   spz_amd_deflate_codes *codes;
   unsigned long long *bits;
+  BlockTrees *trees;
+  spz_amd_deflate_plan *plan;
   uint32_t *header;
   size_t header_capacity;  // words
 };
@@ -768,6 +915,8 @@ bool encode_arrays(LzContext *c, uint32_t total_blocks, EncodeArrays *a) {
   a->blocks = reinterpret_cast<spz_amd_deflate_block *>(carve((size_t)total_blocks * sizeof(spz_amd_deflate_block)));
   a->codes = reinterpret_cast<spz_amd_deflate_codes *>(carve((size_t)total_blocks * sizeof(spz_amd_deflate_codes)));
   a->bits = reinterpret_cast<unsigned long long *>(carve((size_t)total_blocks * sizeof(unsigned long long)));
+  a->trees = reinterpret_cast<BlockTrees *>(carve((size_t)total_blocks * sizeof(BlockTrees)));
+  a->plan = reinterpret_cast<spz_amd_deflate_plan *>(carve((size_t)total_blocks * sizeof(spz_amd_deflate_plan)));
   if (off + 4096 > c->scratch_b_bytes) return false;
   a->header = reinterpret_cast<uint32_t *>(c->scratch_b + off);
   a->header_capacity = (c->scratch_b_bytes - off) / sizeof(uint32_t);
@@ -819,7 +968,8 @@ int spz_amd_zlib_encode_group(void *ctx, const spz_amd_deflate_static *tables, u
   return SPZ_AMD_OK;  // not waited for: the next group's trees can be built meanwhile
 }
 
-int spz_amd_zlib_encode_finish(void *ctx, uint32_t total_blocks, uint64_t body_bytes, uint8_t *h_body, uint64_t *h_symbol_bits) {
+int spz_amd_zlib_encode_finish_ex(void *ctx, uint32_t total_blocks, uint64_t body_bytes, uint8_t *h_body, uint64_t *h_symbol_bits,
+                                  uint32_t *h_header_bits) {
   LzContext *c = static_cast<LzContext *>(ctx);
   if (c == nullptr || h_body == nullptr || h_symbol_bits == nullptr || total_blocks == 0) return SPZ_AMD_ERR_INVALID_ARG;
   if (((body_bytes + 3) / 4 + 2) * 4 > c->scratch_a_bytes) return SPZ_AMD_ERR_CAPACITY;
@@ -837,11 +987,76 @@ int spz_amd_zlib_encode_finish(void *ctx, uint32_t total_blocks, uint64_t body_b
   }
   SPZ_HIP_TRY(hipMemcpyAsync(h_body, c->scratch_a, body_bytes, hipMemcpyDeviceToHost, st));
   SPZ_HIP_TRY(hipMemcpyAsync(h_symbol_bits, a.bits, (size_t)total_blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+  if (h_header_bits != nullptr) {
+    SPZ_HIP_TRY(hipMemcpy2DAsync(h_header_bits, sizeof(uint32_t), &a.blocks[0].header_bits, sizeof(spz_amd_deflate_block),
+                                 sizeof(uint32_t), total_blocks, hipMemcpyDeviceToHost, st));
+  }
   SPZ_HIP_TRY(hipStreamSynchronize(st));
   if (timing) {
     std::fprintf(stderr, "[lz77] + download %.4f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   }
   return SPZ_AMD_OK;
+}
+
+int spz_amd_zlib_encode_finish(void *ctx, uint32_t total_blocks, uint64_t body_bytes, uint8_t *h_body, uint64_t *h_symbol_bits) {
+  return spz_amd_zlib_encode_finish_ex(ctx, total_blocks, body_bytes, h_body, h_symbol_bits, nullptr);
+}
+
+int spz_amd_zlib_block_trees(void *ctx, uint32_t num_blocks, spz_amd_deflate_plan *h_plan) {
+  LzContext *c = static_cast<LzContext *>(ctx);
+  if (c == nullptr || num_blocks == 0 || h_plan == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  DeviceGuard guard;
+  int rc = guard.enter(c->device);
+  if (rc != SPZ_AMD_OK) return rc;
+  StatArrays sa;
+  EncodeArrays a;
+  if (!stat_arrays(c, num_blocks, &sa) || !encode_arrays(c, num_blocks, &a)) return SPZ_AMD_ERR_CAPACITY;
+  hipStream_t st = nullptr;
+  hipLaunchKernelGGL(lz_tree_kernel, dim3((num_blocks + kTreeLanes - 1) / kTreeLanes), dim3(64), 0, st, sa.lfreq, sa.dfreq, num_blocks,
+                     a.codes, a.trees, a.plan);
+  SPZ_HIP_TRY(hipGetLastError());
+  SPZ_HIP_TRY(hipMemcpyAsync(h_plan, a.plan, (size_t)num_blocks * sizeof(spz_amd_deflate_plan), hipMemcpyDeviceToHost, st));
+  SPZ_HIP_TRY(hipStreamSynchronize(st));
+  return SPZ_AMD_OK;
+}
+
+int spz_amd_zlib_encode_planned(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols, uint32_t num_blocks,
+                                const spz_amd_deflate_block *h_blocks, uint64_t body_bytes) {
+  LzContext *c = static_cast<LzContext *>(ctx);
+  if (c == nullptr || tables == nullptr || block_symbols == 0 || num_blocks == 0 || h_blocks == nullptr) {
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  if ((uint64_t)num_blocks * block_symbols < c->num_symbols) return SPZ_AMD_ERR_INVALID_ARG;
+  const size_t body_words = (size_t)((body_bytes + 3) / 4) + 2;
+  if (body_words * 4 > c->scratch_a_bytes) return SPZ_AMD_ERR_CAPACITY;
+  // nothing the kernels write may leave scratch_a: a header takes at most kHeaderStride words from its block's first
+  // word, a block's symbols at most 48 bits each
+  if (body_words * 4 + kHeaderStride * 4 + (size_t)block_symbols * 6 + 64 > c->scratch_a_bytes) return SPZ_AMD_ERR_CAPACITY;
+  for (uint32_t b = 0; b < num_blocks; ++b) {
+    const spz_amd_deflate_block &k = h_blocks[b];
+    if (k.choice > 2u || (k.bit_start >> 5) >= body_words ||
+        (k.choice == 0 && ((k.bit_start >> 3) + 8 + k.input_bytes > body_bytes + 8 || (uint64_t)k.input_begin + k.input_bytes > c->size ||
+                           k.input_bytes > 0xffffu))) {
+      return SPZ_AMD_ERR_INVALID_ARG;
+    }
+  }
+  DeviceGuard guard;
+  int rc = guard.enter(c->device);
+  if (rc != SPZ_AMD_OK) return rc;
+  EncodeArrays a;
+  if (!encode_arrays(c, num_blocks, &a) || (size_t)num_blocks * kHeaderStride > a.header_capacity) return SPZ_AMD_ERR_CAPACITY;
+  uint32_t *d_body = reinterpret_cast<uint32_t *>(c->scratch_a);
+  hipStream_t st = nullptr;
+  SPZ_HIP_TRY(hipMemsetAsync(d_body, 0, body_words * 4, st));
+  SPZ_HIP_TRY(hipMemcpyAsync(a.tables, tables, sizeof(*tables), hipMemcpyHostToDevice, st));
+  SPZ_HIP_TRY(hipMemcpyAsync(a.blocks, h_blocks, (size_t)num_blocks * sizeof(spz_amd_deflate_block), hipMemcpyHostToDevice, st));
+  hipLaunchKernelGGL(lz_header_kernel, dim3((num_blocks + 63) / 64), dim3(64), 0, st, a.blocks, a.codes, a.trees, a.header, num_blocks);
+  SPZ_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(lz_encode_kernel, dim3(num_blocks), dim3(kEncodeThreads), 0, st, c->dense_dist, c->dense_lc,
+                     (unsigned long long)c->num_symbols, block_symbols, c->data, a.tables, a.blocks, a.codes, a.header, d_body, a.bits,
+                     0u);
+  SPZ_HIP_TRY(hipGetLastError());
+  return SPZ_AMD_OK;  // not waited for: the caller maps its output buffer meanwhile, then spz_amd_zlib_encode_finish_ex
 }
 
 int spz_amd_zlib_encode_blocks(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols, uint32_t num_blocks,

@@ -21,19 +21,21 @@ def force_device_parse():
     os.environ["SPZ_AMD_GZIP_DEVICE"] = "1"
     yield
     os.environ.pop("SPZ_AMD_GZIP_DEVICE_HUFFMAN", None)
+    os.environ.pop("SPZ_AMD_GZIP_DEVICE_TREES", None)
     if old is None:
         os.environ.pop("SPZ_AMD_GZIP_DEVICE", None)
     else:
         os.environ["SPZ_AMD_GZIP_DEVICE"] = old
 
 
-@pytest.mark.parametrize("huffman", ["1", "0"])
+@pytest.mark.parametrize("huffman", ["trees", "1", "0"])
 @pytest.mark.parametrize("kind", ["nibbles", "bytes", "words", "runs", "sh_like"])
 def test_device_parse_bytes_equal_zlib(kind, huffman):
     """Sizes around the job (16 KiB), tile (16 KiB), block (32767 symbols) and link-segment (512 KiB) boundaries
     of the kernels; with the Huffman stage on the device too (stored blocks: "bytes"; static and dynamic: the
-    rest) and with only the parse there."""
-    os.environ["SPZ_AMD_GZIP_DEVICE_HUFFMAN"] = huffman
+    rest) — trees included ("trees", the default) or built by the host ("1") — and with only the parse there ("0")."""
+    os.environ["SPZ_AMD_GZIP_DEVICE_HUFFMAN"] = "0" if huffman == "0" else "1"
+    os.environ["SPZ_AMD_GZIP_DEVICE_TREES"] = "1" if huffman == "trees" else "0"
     rng = np.random.default_rng(sum(kind.encode()) + 1)
     for n in ((1 << 20), (1 << 20) + 1, 1_300_001, (1 << 21) + 32768, 3_000_017):
         data = make(kind, n, rng)
