@@ -227,6 +227,14 @@ int spz_amd_convert_coordinates_device(float *d_positions, float *d_rotations, f
 int spz_amd_encode_host(const spz_amd_cloud_in *h_cloud, uint64_t num_points, int sh_degree,
                         int antialiased, int from_coord, int version, uint8_t *h_stream,
                         size_t capacity, int device);
+/* The same for a caller that goes on to the container stage (saveSpz, load-spz.cc:639-645: packGaussians then
+ * compressGzipped): *d_stream = a device copy of the stream that stays valid until spz_amd_kept_stream_release — what
+ * spz_amd_zlib_parse_open_dev takes instead of uploading the stream again — or NULL when the one such buffer per
+ * device is in use (or num_points is 0). */
+int spz_amd_encode_host_keep(const spz_amd_cloud_in *h_cloud, uint64_t num_points, int sh_degree,
+                             int antialiased, int from_coord, int version, uint8_t *h_stream,
+                             size_t capacity, int device, const uint8_t **d_stream);
+void spz_amd_kept_stream_release(int device, const uint8_t *d_stream);
 /* The same with the stream already in device memory (what spz_amd_inflate_device_data() returns): no upload, the
  * decoded floats come back to the host arrays through the same chunked pipeline.  `hdr`: the stream's header
  * (spz_amd_peek_header_device, or _ex on its first 16 bytes). */
@@ -331,6 +339,12 @@ int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_
 int spz_amd_zlib_parse_open_ex(const uint8_t *h_data, uint64_t size, uint64_t tail_begin, const uint32_t *h_tail_rec,
                                uint32_t n_rec, int device, void **ctx, uint64_t *num_symbols,
                                uint32_t *tail_first_symbol, void (*produce_tail_rec)(void *), void *produce_arg);
+/* The same for a caller whose input is what spz_amd_encode_host_keep just produced: d_copy (may be NULL) = the
+ * device copy of h_data's bytes, on `device`; the upload is then a device-to-device copy. */
+int spz_amd_zlib_parse_open_dev(const uint8_t *h_data, const uint8_t *d_copy, uint64_t size, uint64_t tail_begin,
+                                const uint32_t *h_tail_rec, uint32_t n_rec, int device, void **ctx,
+                                uint64_t *num_symbols, uint32_t *tail_first_symbol, void (*produce_tail_rec)(void *),
+                                void *produce_arg);
 int spz_amd_zlib_parse_fetch(void *ctx, uint16_t *h_dist, uint8_t *h_lc);
 void spz_amd_zlib_parse_close(void *ctx);
 

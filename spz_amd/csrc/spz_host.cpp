@@ -417,17 +417,18 @@ bool verifiedExact(const uint8_t *data, size_t size, const std::vector<uint8_t> 
 struct DeviceHeadParser final : exactgz::HeadParser {
   void *ctx = nullptr;
   int status = SPZ_AMD_OK;
+  const uint8_t *d_copy = nullptr;  // the input's bytes on the device already (saveSpz), or null
   ~DeviceHeadParser() override { spz_amd_zlib_parse_close(ctx); }
   bool parse(const uint8_t *data, size_t size, uint64_t tail_begin, const uint32_t *tail_rec, uint32_t n_rec,
              uint64_t *num_symbols, uint32_t *tail_first_symbol) override {
-    status = spz_amd_zlib_parse_open(data, size, tail_begin, tail_rec, n_rec, deviceIndex(), &ctx, num_symbols,
-                                     tail_first_symbol);
+    status = spz_amd_zlib_parse_open_dev(data, d_copy, size, tail_begin, tail_rec, n_rec, deviceIndex(), &ctx, num_symbols,
+                                         tail_first_symbol, nullptr, nullptr);
     return status == SPZ_AMD_OK;
   }
   bool parseLate(const uint8_t *data, size_t size, uint64_t tail_begin, const uint32_t *tail_rec, uint32_t n_rec,
                  void (*produce)(void *), void *arg, uint64_t *num_symbols, uint32_t *tail_first_symbol) override {
-    status = spz_amd_zlib_parse_open_ex(data, size, tail_begin, tail_rec, n_rec, deviceIndex(), &ctx, num_symbols,
-                                        tail_first_symbol, produce, arg);
+    status = spz_amd_zlib_parse_open_dev(data, d_copy, size, tail_begin, tail_rec, n_rec, deviceIndex(), &ctx, num_symbols,
+                                         tail_first_symbol, produce, arg);
     return status == SPZ_AMD_OK;
   }
   bool fetch(uint16_t *dist, uint8_t *lc) override {
@@ -487,7 +488,15 @@ std::atomic<uint64_t> g_device_parses{0};
 
 uint64_t deviceGzipParseCount() { return g_device_parses.load(); }
 
+namespace {
+bool compressGzippedWithCopy(const uint8_t *data, size_t size, std::vector<uint8_t> *out, const uint8_t *d_copy);
+}
 bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out) {
+  return compressGzippedWithCopy(data, size, out, nullptr);
+}
+namespace {
+// d_copy: the same bytes on the device (spz_amd_encode_host_keep), or null
+bool compressGzippedWithCopy(const uint8_t *data, size_t size, std::vector<uint8_t> *out, const uint8_t *d_copy) {
   // Large inputs: the writer that reproduces zlib's bytes exactly with its parse on the device or on all
   // cores (it checks itself against zlib on a prefix, and declines inputs it cannot split); zlib itself
   // otherwise and as the fallback.
@@ -503,6 +512,7 @@ bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out
         bool ok;
         {
           DeviceHeadParser parser;
+          parser.d_copy = d_copy;
           ok = exactgz::compressWithHeadParser(data, size, std::max(threads, 1), parser, out, verify);
           if (timing) {
             std::fprintf(stderr, "[exactgz] writer     %.3f s in all\n",
@@ -536,6 +546,7 @@ bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out
   }
   return compressGzippedZlib(data, size, out);
 }
+}  // namespace
 
 namespace {
 bool compressGzippedZlib(const uint8_t *data, size_t size, std::vector<uint8_t> *out) {
@@ -1010,7 +1021,16 @@ void sizeCloudArrays(GaussianCloud *r, size_t n, size_t shDim, detail::Prefault 
 }
 }  // namespace
 
+namespace {
+bool packToStreamKeep(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream, const uint8_t **d_copy);
+}
 bool packToStream(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream) {
+  return packToStreamKeep(g, o, stream, nullptr);
+}
+namespace {
+// d_copy != null: *d_copy receives the device's copy of the stream (or null), to be given back with spz_amd_kept_stream_release
+bool packToStreamKeep(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream, const uint8_t **d_copy) {
+  if (d_copy) *d_copy = nullptr;
   g_last_status = SPZ_AMD_OK;
   if (!checkSizes(g)) {
     // packGaussians returns an empty PackedGaussians{} (load-spz.cc:258-260) and saveSpz goes on
@@ -1031,10 +1051,13 @@ bool packToStream(const GaussianCloud &g, const PackOptions &o, std::vector<uint
   prefault.start();
   spz_amd_cloud_in in = {g.positions.data(), g.scales.data(), g.rotations.data(),
                          g.alphas.data(),    g.colors.data(), g.sh.empty() ? nullptr : g.sh.data()};
-  const int rc = spz_amd_encode_host(&in, static_cast<uint64_t>(g.numPoints), g.shDegree, g.antialiased ? 1 : 0,
-                                     static_cast<int>(o.from), 3, stream->data(), stream->size(), deviceIndex());
+  const int rc = d_copy ? spz_amd_encode_host_keep(&in, static_cast<uint64_t>(g.numPoints), g.shDegree, g.antialiased ? 1 : 0,
+                                                   static_cast<int>(o.from), 3, stream->data(), stream->size(), deviceIndex(), d_copy)
+                        : spz_amd_encode_host(&in, static_cast<uint64_t>(g.numPoints), g.shDegree, g.antialiased ? 1 : 0,
+                                              static_cast<int>(o.from), 3, stream->data(), stream->size(), deviceIndex());
   return !deviceFailed(rc, "encode");
 }
+}  // namespace
 
 GaussianCloud unpackFromStream(const uint8_t *stream, size_t size, const UnpackOptions &o) {
   g_last_status = SPZ_AMD_OK;
@@ -1188,12 +1211,22 @@ bool saveSpz(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> 
       if (cached && v.capacity() > (size_t(1) << 30)) std::vector<uint8_t>().swap(v);
     }
   } trim{stream, cache_lock.owns_lock()};
-  if (!packToStream(g, o, &stream)) return false;
+  // the stream stays on the device as well when its container stage is going to run there: no second upload
+  const uint8_t *d_copy = nullptr;
+  struct Kept {
+    const uint8_t **p;
+    ~Kept() { spz_amd_kept_stream_release(deviceIndex(), *p); }
+  } kept{&d_copy};
+  spz_amd_layout lay;
+  const bool keep_on_device = g.numPoints > 0 && spz_amd_stream_layout(static_cast<uint64_t>(g.numPoints), g.shDegree, 3, &lay) == SPZ_AMD_OK &&
+                              lay.total_bytes >= (size_t(1) << 20) && exactGzipThreads() >= 1 && deviceParseWanted(lay.total_bytes);
+  if (!packToStreamKeep(g, o, &stream, keep_on_device ? &d_copy : nullptr)) return false;
   if (timing) std::fprintf(stderr, "[saveSpz] pack %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   // Default: the reference's single deflate stream (byte-identical files).  SPZ_AMD_GZIP_THREADS=n>1
   // opts into the parallel container (same content, different bytes, n x faster).
   const char *e = std::getenv("SPZ_AMD_GZIP_THREADS");
   const int threads = e ? std::atoi(e) : 1;
+  if (threads <= 1) return compressGzippedWithCopy(stream.data(), stream.size(), out, d_copy);
   return compressGzippedParallel(stream.data(), stream.size(), out, threads);
 }
 

@@ -126,7 +126,9 @@ void scratch_release(int device, void *block) {
   (void)hipFree(block);
 }
 
+void kept_stream_free_idle();
 void workspace_free_all() {
+  kept_stream_free_idle();
   int prev = 0;
   if (hipGetDevice(&prev) != hipSuccess) return;
   for (int d = 0; d < kMaxDevices; ++d) {
@@ -261,10 +263,79 @@ int run_pipeline(HostPipe *pipe, int device, int chunks, Up up, Down down) {
 
 }  // namespace
 
+// A device copy of the last stream an encode produced, for a caller that goes on to the container stage
+// (spz_amd_encode_host_keep -> spz_amd_zlib_parse_open_dev): one grow-only buffer per device, handed to one caller at a time.
+namespace {
+struct KeptStream {
+  void *ptr = nullptr;
+  size_t cap = 0;
+  bool in_use = false;
+};
+KeptStream g_kept[kMaxDevices];
+std::mutex g_kept_mutex;
+
+uint8_t *kept_acquire(int device, size_t bytes) {  // the current device is `device`; nullptr: not available
+  std::lock_guard<std::mutex> lock(g_kept_mutex);
+  KeptStream &k = g_kept[device];
+  if (k.in_use) return nullptr;
+  if (k.cap < bytes) {
+    if (k.ptr) (void)hipFree(k.ptr);
+    k = KeptStream();
+    if (hipMalloc(&k.ptr, bytes) != hipSuccess) {
+      k.ptr = nullptr;
+      return nullptr;
+    }
+    k.cap = bytes;
+  }
+  k.in_use = true;
+  return static_cast<uint8_t *>(k.ptr);
+}
+
+int encode_host_impl(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int antialiased, int from_coord, int version,
+                     uint8_t *h_stream, size_t capacity, int device, const uint8_t **d_keep);
+}  // namespace
+
+namespace spz_amd_detail {
+void kept_stream_free_idle() {
+  int prev = 0;
+  if (hipGetDevice(&prev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lock(g_kept_mutex);
+  for (int d = 0; d < kMaxDevices; ++d) {
+    KeptStream &k = g_kept[d];
+    if (k.ptr && !k.in_use && hipSetDevice(d) == hipSuccess) {
+      (void)hipFree(k.ptr);
+      k = KeptStream();
+    }
+  }
+  (void)hipSetDevice(prev);
+}
+}  // namespace spz_amd_detail
+
 extern "C" {
+
+void spz_amd_kept_stream_release(int device, const uint8_t *d_stream) {
+  if (d_stream == nullptr || device < 0 || device >= kMaxDevices) return;
+  std::lock_guard<std::mutex> lock(g_kept_mutex);
+  if (g_kept[device].ptr == d_stream) g_kept[device].in_use = false;
+}
 
 int spz_amd_encode_host(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int antialiased, int from_coord,
                         int version, uint8_t *h_stream, size_t capacity, int device) {
+  return encode_host_impl(h, n, sh_degree, antialiased, from_coord, version, h_stream, capacity, device, nullptr);
+}
+
+int spz_amd_encode_host_keep(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int antialiased, int from_coord,
+                             int version, uint8_t *h_stream, size_t capacity, int device, const uint8_t **d_stream) {
+  if (d_stream == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  *d_stream = nullptr;
+  return encode_host_impl(h, n, sh_degree, antialiased, from_coord, version, h_stream, capacity, device, d_stream);
+}
+
+}  // extern "C"
+
+namespace {
+int encode_host_impl(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int antialiased, int from_coord, int version,
+                     uint8_t *h_stream, size_t capacity, int device, const uint8_t **d_keep) {
   if (h == nullptr || h_stream == nullptr || !valid_coord(from_coord)) return SPZ_AMD_ERR_INVALID_ARG;
   spz_amd_layout lay;
   int rc = spz_amd_stream_layout(n, sh_degree, version, &lay);
@@ -284,14 +355,21 @@ int spz_amd_encode_host(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, in
   if (rc != SPZ_AMD_OK) return rc;
   const size_t fpp[6] = {3, 3, 4, 1, 3, (size_t)sd * 3};  // floats per point, spz_amd_cloud_in order
   const float *src[6] = {h->positions, h->scales, h->rotations, h->alphas, h->colors, h->sh};
-  size_t total = Workspace::aligned(lay.total_bytes);
+  // the device stream: in the workspace, or — for a caller that wants it kept — in the buffer it then owns
+  uint8_t *kept = d_keep ? kept_acquire(device, Workspace::aligned(lay.total_bytes)) : nullptr;
+  struct KeptGuard {
+    int device;
+    const uint8_t *p;
+    ~KeptGuard() { spz_amd_kept_stream_release(device, p); }
+  } kept_guard{device, kept};
+  size_t total = kept ? 0 : Workspace::aligned(lay.total_bytes);
   for (int i = 0; i < 6; ++i) total += Workspace::aligned(n * fpp[i] * sizeof(float));
   Workspace ws;
   rc = ws.open(device, total);
   if (rc != SPZ_AMD_OK) return rc;
   float *fb[6];
   for (int i = 0; i < 6; ++i) fb[i] = static_cast<float *>(ws.take(n * fpp[i] * sizeof(float)));
-  uint8_t *sb = static_cast<uint8_t *>(ws.take(lay.total_bytes));
+  uint8_t *sb = kept ? kept : static_cast<uint8_t *>(ws.take(lay.total_bytes));
   HostPipe *pipe = ws.pipe();
   uint64_t cp = 0;
   const int chunks = plan_chunks(n, (14 + (size_t)sd * 3) * sizeof(float), &cp);
@@ -319,8 +397,16 @@ int spz_amd_encode_host(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, in
     }
     return SPZ_AMD_OK;
   };
-  return run_pipeline(pipe, device, chunks, up, down);
+  rc = run_pipeline(pipe, device, chunks, up, down);
+  if (rc == SPZ_AMD_OK && kept) {
+    *d_keep = kept;
+    kept_guard.p = nullptr;  // the caller's now: spz_amd_kept_stream_release
+  }
+  return rc;
 }
+}  // namespace
+
+extern "C" {
 
 int spz_amd_decode_host_ex(const uint8_t *h_stream, size_t size, uint64_t max_points, int to_coord,
                            const spz_amd_cloud_out *h, int device) {

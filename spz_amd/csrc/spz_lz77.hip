@@ -625,9 +625,9 @@ using namespace spz_amd_detail;
 
 extern "C" {
 
-int spz_amd_zlib_parse_open_ex(const uint8_t *h_data, uint64_t size, uint64_t tail_begin, const uint32_t *h_tail_rec,
-                               uint32_t n_rec, int device, void **ctx, uint64_t *num_symbols, uint32_t *tail_first_symbol,
-                               void (*produce_tail_rec)(void *), void *produce_arg) {
+int spz_amd_zlib_parse_open_dev(const uint8_t *h_data, const uint8_t *d_copy, uint64_t size, uint64_t tail_begin,
+                                const uint32_t *h_tail_rec, uint32_t n_rec, int device, void **ctx, uint64_t *num_symbols,
+                                uint32_t *tail_first_symbol, void (*produce_tail_rec)(void *), void *produce_arg) {
   if (h_data == nullptr || h_tail_rec == nullptr || ctx == nullptr || num_symbols == nullptr ||
       tail_first_symbol == nullptr) {
     return SPZ_AMD_ERR_INVALID_ARG;
@@ -706,7 +706,11 @@ int spz_amd_zlib_parse_open_ex(const uint8_t *h_data, uint64_t size, uint64_t ta
   hipStream_t st = nullptr;
   const size_t upload = std::min<size_t>(size, data_bytes);
   lap("alloc");
-  SPZ_HIP_TRY(upload_adaptive(d_data, h_data, upload, st));
+  if (d_copy != nullptr) {  // the same bytes, already on this device
+    SPZ_HIP_TRY(hipMemcpyAsync(d_data, d_copy, upload, hipMemcpyDeviceToDevice, st));
+  } else {
+    SPZ_HIP_TRY(upload_adaptive(d_data, h_data, upload, st));
+  }
   if (upload < data_bytes) SPZ_HIP_TRY(hipMemsetAsync(d_data + upload, 0, data_bytes - upload, st));
   SPZ_HIP_TRY(hipMemsetAsync(d_link, 0, pos_padded * sizeof(uint16_t), st));
   lap("upload");
@@ -796,6 +800,13 @@ int spz_amd_zlib_parse_open_ex(const uint8_t *h_data, uint64_t size, uint64_t ta
   *num_symbols = total_syms;
   *tail_first_symbol = info[n_jobs].lo;
   return SPZ_AMD_OK;
+}
+
+int spz_amd_zlib_parse_open_ex(const uint8_t *h_data, uint64_t size, uint64_t tail_begin, const uint32_t *h_tail_rec,
+                               uint32_t n_rec, int device, void **ctx, uint64_t *num_symbols, uint32_t *tail_first_symbol,
+                               void (*produce_tail_rec)(void *), void *produce_arg) {
+  return spz_amd_zlib_parse_open_dev(h_data, nullptr, size, tail_begin, h_tail_rec, n_rec, device, ctx, num_symbols, tail_first_symbol,
+                                     produce_tail_rec, produce_arg);
 }
 
 int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_begin, const uint32_t *h_tail_rec,

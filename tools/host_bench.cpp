@@ -1,6 +1,7 @@
 // host_bench — the C++ boundary users actually call (spz::packToStream / unpackFromStream / saveSpz /
 // loadSpz with host vectors in and out), timed in C++ so that no language binding's copies are counted.
 //   g++ -O2 -std=c++17 -Iinclude -o spz_amd/bin/host_bench tools/host_bench.cpp -Lspz_amd/lib -lspz_host -lspz_amd
+#include <algorithm>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
@@ -129,15 +130,29 @@ int main(int argc, char **argv) {
     printf(", \"convert_coordinates_s\": %.4f, \"convert_coordinates_round_trip_identical\": %s", best, same ? "true" : "false");
   }
   if (gzip) {
+    // the first save and load allocate what later ones reuse (device blocks, the stream buffer): both are reported
     std::vector<uint8_t> file;
-    double t0 = now();
-    if (!spz::saveSpz(g, po, &file)) return 1;
-    const double t_save = now() - t0;
-    t0 = now();
-    spz::GaussianCloud back = spz::loadSpz(file, uo);
-    const double t_load = now() - t0;
-    printf(", \"save_spz_s\": %.3f, \"load_spz_s\": %.3f, \"spz_bytes\": %zu, \"load_ok\": %s", t_save, t_load, file.size(),
-           back.numPoints == static_cast<int32_t>(n) ? "true" : "false");
+    double t_save_first = 0, t_save = 1e30, t_load_first = 0, t_load = 1e30;
+    bool load_ok = true;
+    for (int r = 0; r < std::max(reps, 2); ++r) {
+      std::vector<uint8_t> fresh;
+      double t0 = now();
+      if (!spz::saveSpz(g, po, &fresh)) return 1;
+      const double dt = now() - t0;
+      if (r == 0) t_save_first = dt;
+      t_save = std::min(t_save, dt);
+      file.swap(fresh);
+    }
+    for (int r = 0; r < std::max(reps, 2); ++r) {
+      const double t0 = now();
+      spz::GaussianCloud back = spz::loadSpz(file, uo);
+      const double dt = now() - t0;
+      if (r == 0) t_load_first = dt;
+      t_load = std::min(t_load, dt);
+      load_ok = load_ok && back.numPoints == static_cast<int32_t>(n);
+    }
+    printf(", \"save_spz_first_s\": %.3f, \"save_spz_s\": %.3f, \"load_spz_first_s\": %.3f, \"load_spz_s\": %.3f, \"spz_bytes\": %zu, \"load_ok\": %s",
+           t_save_first, t_save, t_load_first, t_load, file.size(), load_ok ? "true" : "false");
   }
   printf("}\n");
   return 0;
