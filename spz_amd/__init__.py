@@ -9,6 +9,7 @@ Layout:
   csrc/spz_exchange.hip multi-GPU exchange: native RCCL gatherv/scatterv, IPC-mapped root stream
   csrc/spz_lz77.hip     the gzip writer's stages on the device: zlib's level-6 parse (exact) and Huffman bit packing
   csrc/spz_lz77_core.hpp  ... their stage functions, shared with the serial host model (spz_lz77_model.cpp, tests)
+  csrc/spz_huff_core.hpp  ... zlib's tree construction for a deflate block, shared by the host writer and the tree kernel
   csrc/spz_inflate_dev.hip  inflate of single-stream gzip members on the device (CRC-verified)
   csrc/spz_inflate_core.hpp ... the deflate decoder shared by the host and the device reader
   csrc/spz_host.cpp     C++ drop-in layer: namespace spz saveSpz/loadSpz/... + host gzip
