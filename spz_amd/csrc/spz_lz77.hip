@@ -70,7 +70,17 @@ __global__ __launch_bounds__(512) void lz_table_kernel(const uint8_t *__restrict
   for (uint32_t i = tid; i <= HASH_MASK; i += kLinkThreads) table[i] = fresh;
   __syncthreads();
   uint16_t *slab = out + (size_t)blockIdx.x * kRankSlab;  // RANK: entry i is position s0 - W + i
+  // The workgroup is alone on its CU (the table takes 128 KiB of LDS), so nothing hides a load's latency for it: the
+  // next round's three bytes (one unaligned dword; the input is padded) are requested before this round's work.
+  auto load3 = [&](uint64_t q) -> uint32_t {
+    uint32_t v = 0;
+    if (q < s1) __builtin_memcpy(&v, d + q, 4);
+    return v;
+  };
+  uint32_t bytes_next = load3(start + tid);
   for (uint64_t P = start; P < s1; P += kLinkThreads) {
+    const uint32_t bytes = bytes_next;
+    bytes_next = load3(P + kLinkThreads + tid);
     if (MODE == TABLE_LINK && P != start && ((P - start) & (kSweepEvery - 1)) == 0) {
       // retire what no later position can reach: an entry never gets 65536 positions old
       for (uint32_t i = tid; i <= HASH_MASK; i += kLinkThreads) {
@@ -81,16 +91,20 @@ __global__ __launch_bounds__(512) void lz_table_kernel(const uint8_t *__restrict
     }
     const uint64_t p = P + tid;
     const bool valid = p < s1;
-    uint32_t h = 0x10000u + lane;  // a key of its own: equal to nobody's
-    if (valid) h = MODE == TABLE_LINK ? hash2(d[p], d[p + 1], d[p + 2]) : hash3(d[p], d[p + 1], d[p + 2]);
+    uint32_t h = 0x10000u;  // no position's key (the lanes past the end do nothing with their class)
+    if (valid) {
+      const uint8_t b0 = (uint8_t)bytes, b1 = (uint8_t)(bytes >> 8), b2 = (uint8_t)(bytes >> 16);
+      h = MODE == TABLE_LINK ? hash2(b0, b1, b2) : hash3(b0, b1, b2);
+    }
     // lanes of this wave with the same key
-    unsigned long long cls = 0;
+    // bit by bit: the lanes that agree with this one on bit b are the ballot of that bit or its complement
+    // (17 ballots instead of 64 readlane / compare rounds)
+    unsigned long long cls = ~0ull;
 #pragma unroll
-    for (int j = 0; j < 64; ++j) {
-      const uint32_t hj = (uint32_t)__builtin_amdgcn_readlane((int)h, j);
-      const bool eq = hj == h;
-      const unsigned long long m = __ballot(eq);
-      if (eq) cls = m;
+    for (int b = 0; b <= 16; ++b) {
+      const bool bit = ((h >> b) & 1u) != 0u;
+      const unsigned long long m = __ballot(bit);
+      cls &= bit ? m : ~m;
     }
     const unsigned long long below = cls & ((1ull << lane) - 1ull);
     const bool newest = (cls >> lane) == 1ull;
