@@ -14,7 +14,7 @@
 //                     thread walks link[] — positions with the same three bytes, where zlib's own chain of 128 is
 //                     mostly strangers for .spz data — and knows from two ranks how far along zlib's chain a
 //                     candidate is; it writes the two results per position (chain budget 128 and 32).
-//   lz_parse_kernel   one lane per 16 KiB job: deflate_slow's loop with the table lookup in place of the search
+//   lz_parse_kernel   one lane per 8 KiB job: deflate_slow's loop with the table lookup in place of the search
 //                     (each lane keeps the 32 entries around its position in LDS: one HBM latency per 32 positions),
 //                     recording the lazy state at every loop top (one word per input position).
 //   lz_stitch_kernel  every job continues into its successor's range until its state equals the recorded one
@@ -201,55 +201,66 @@ struct JobInfo {
 constexpr uint32_t kParseWindow = 32;  // table entries a lane fetches at a time
 
 // The loop's next position depends on the entry it has just read, so a read from HBM per loop top would be all
-// latency: each lane keeps the 32 entries around its position in LDS ([entry][lane]: conflict-free) and
-// refills them with eight 16-byte loads when it leaves them.
+// latency: each lane keeps the 32 entries from its position on in LDS ([entry][lane]: conflict-free), for both tables.
+// The refill is the wave's, not the lane's: when any lane has left its window every lane fetches anew from where it
+// is, so the 64 lanes' refills — which would otherwise fall on different steps and stall all of them each time —
+// cost one wait (measured on the 650 MB stream: 15.5 ms with per-lane refills on aligned windows).
 struct EntryWindow {
-  uint32_t *s_win;
-  const uint32_t *table;
-  uint32_t lane;
-  mutable uint32_t base;
-  __device__ __forceinline__ uint32_t operator()(uint32_t pos) const {
-    const uint32_t b = pos & ~(kParseWindow - 1u);
-    if (b != base) {
-      const uint4 *src = reinterpret_cast<const uint4 *>(table + b);
-#pragma unroll
-      for (uint32_t q = 0; q < kParseWindow / 4; ++q) {
-        const uint4 v = src[q];
-        s_win[(4 * q + 0) * 64 + lane] = v.x;
-        s_win[(4 * q + 1) * 64 + lane] = v.y;
-        s_win[(4 * q + 2) * 64 + lane] = v.z;
-        s_win[(4 * q + 3) * 64 + lane] = v.w;
-      }
-      base = b;
-    }
-    return s_win[(pos - b) * 64 + lane];
-  }
+  const uint32_t *s_win;
+  uint32_t lane, base;
+  __device__ __forceinline__ uint32_t operator()(uint32_t pos) const { return s_win[(pos - base) * 64 + lane]; }
 };
+
+__device__ __forceinline__ void fill_window(uint32_t *s_win, const uint32_t *table, uint32_t from, uint32_t lane) {
+#pragma unroll
+  for (uint32_t q = 0; q < kParseWindow / 4; ++q) {
+    uint4 v;
+    __builtin_memcpy(&v, table + from + 4 * q, sizeof(v));  // dword-aligned
+    s_win[(4 * q + 0) * 64 + lane] = v.x;
+    s_win[(4 * q + 1) * 64 + lane] = v.y;
+    s_win[(4 * q + 2) * 64 + lane] = v.z;
+    s_win[(4 * q + 3) * 64 + lane] = v.w;
+  }
+}
 
 __global__ __launch_bounds__(64) void lz_parse_kernel(const uint32_t *__restrict__ r128, const uint32_t *__restrict__ r32,
                                                       uint32_t job_bytes, uint32_t head_end, uint32_t n_jobs,
                                                       uint32_t *__restrict__ rec, uint16_t *__restrict__ sym_dist,
                                                       uint8_t *__restrict__ sym_lc, JobInfo *__restrict__ info) {
-  __shared__ uint32_t s_win[kParseWindow * 64];
+  __shared__ uint32_t s_win128[kParseWindow * 64];
+  __shared__ uint32_t s_win32[kParseWindow * 64];
   const uint32_t lane = threadIdx.x;
   const uint32_t j = blockIdx.x * 64u + lane;
-  if (j >= n_jobs) return;
-  const uint32_t begin = j * job_bytes, next = begin + job_bytes < head_end ? begin + job_bytes : head_end;
-  EntryWindow e128 = {s_win, r128, lane, 0xffffffffu};
-  auto e32 = [&](uint32_t pos) { return r32[pos]; };
+  const bool mine = j < n_jobs;
+  const uint32_t begin = mine ? j * job_bytes : 0u;
+  const uint32_t next = mine ? (begin + job_bytes < head_end ? begin + job_bytes : head_end) : 0u;
+  EntryWindow e128 = {s_win128, lane, 0u}, e32 = {s_win32, lane, 0u};
   uint16_t *od = sym_dist + (size_t)j * job_symbol_stride(job_bytes);
   uint8_t *ol = sym_lc + (size_t)j * job_symbol_stride(job_bytes);
-  uint32_t s = begin, nsym = 0;
+  uint32_t s = begin, nsym = 0, base = 0xffffffffu - kParseWindow;  // no window yet
   LazyState<uint32_t> st;
   auto emit = [&](uint32_t dist, uint32_t lc) {
     od[nsym] = (uint16_t)dist;
     ol[nsym] = (uint8_t)lc;
     ++nsym;
   };
-  while (s < next) {
-    rec[s] = pack_state(st, s);
-    lazy_step(s, st, e128, e32, emit);
+  for (;;) {
+    const bool active = s < next;
+    if (!__any(active)) break;
+    if (__any(active && s - base >= kParseWindow)) {
+      if (active) {
+        base = s;  // the tables are padded past the last position a job reads
+        fill_window(s_win128, r128, s, lane);
+        fill_window(s_win32, r32, s, lane);
+        e128.base = e32.base = s;
+      }
+    }
+    if (active) {
+      rec[s] = pack_state(st, s);
+      lazy_step(s, st, e128, e32, emit);
+    }
   }
+  if (!mine) return;
   JobInfo &o = info[j];
   o.n = nsym;
   o.end_s = s;
@@ -664,7 +675,7 @@ int spz_amd_zlib_parse_open_dev(const uint8_t *h_data, const uint8_t *d_copy, ui
     t_prev = now;
   };
 
-  const uint32_t max_jobs = (uint32_t)(tail_begin / kSmallestJob);  // tail_begin is a multiple of W = 2 of them
+  const uint32_t max_jobs = (uint32_t)(tail_begin / kSmallestJob);  // tail_begin is a multiple of W = 4 of them
   const uint32_t n_tiles = (uint32_t)((n_pos + kMatchTile - 1) / kMatchTile);
   const size_t pos_padded = (size_t)n_tiles * kMatchTile;
   // carve one allocation

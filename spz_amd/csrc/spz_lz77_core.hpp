@@ -52,8 +52,8 @@ constexpr uint32_t GOOD_MATCH = 8, MAX_LAZY = 16, NICE_MATCH = 128, MAX_CHAIN = 
 // meeting point is usually a few positions in, a few thousand after long runs, tens of thousands when long
 // stretches of the input repeat; none inside the successor's range: the stage is run again with larger jobs
 // (the tables do not depend on the jobs), and declined after the largest — the caller parses on the host instead.
-constexpr uint32_t kJobSizes[3] = {W / 2, 4 * W, 32 * W};
-constexpr uint32_t kSmallestJob = W / 2;
+constexpr uint32_t kJobSizes[4] = {W / 4, W / 2, 4 * W, 32 * W};
+constexpr uint32_t kSmallestJob = W / 4;
 constexpr uint32_t kTailWindow = W;  // loop tops of the caller's tail parse that the last job may meet
 SPZ_LZ_HD uint32_t job_symbol_stride(uint32_t job_bytes) { return job_bytes + 8; }  // at most one symbol per position
 // End of the range job j's continuation may run through: its successor's own range, or the tail parse's first loop tops.

@@ -118,8 +118,8 @@ def test_default_save_path_on_a_real_stream_equals_zlib_and_the_reference(refere
 def test_staged_parse_model_equals_zlib(kind):
     """The parse the MI355X runs (spz_lz77.hip), as its serial host model with the same stage functions and job
     geometry (spz_lz77_core.hpp / spz_lz77_model.cpp): hash2 links + zlib-chain ranks, the two match tables per
-    position, the lazy state machine over 16 KiB jobs, the stitch into the successor's recorded states and the
-    splice with the host's serial tail job.  Sizes around the 16 KiB job / 32 KiB window boundaries."""
+    position, the lazy state machine over 8 KiB jobs, the stitch into the successor's recorded states and the
+    splice with the host's serial tail job.  Sizes around the 8 KiB job / 32 KiB window boundaries."""
     rng = np.random.default_rng(sum(kind.encode()) + 2)
     for n in (524288, 524289, 540673, 700001, (1 << 20) + 12345):
         data = make(kind, n, rng)

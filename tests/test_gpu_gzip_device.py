@@ -31,7 +31,7 @@ def force_device_parse():
 @pytest.mark.parametrize("huffman", ["trees", "1", "0"])
 @pytest.mark.parametrize("kind", ["nibbles", "bytes", "words", "runs", "sh_like"])
 def test_device_parse_bytes_equal_zlib(kind, huffman):
-    """Sizes around the job (16 KiB), tile (16 KiB), block (32767 symbols) and link-segment (512 KiB) boundaries
+    """Sizes around the job (8 KiB), tile (4 KiB), block (32767 symbols) and link-segment (512 KiB) boundaries
     of the kernels; with the Huffman stage on the device too (stored blocks: "bytes"; static and dynamic: the
     rest) — trees included ("trees", the default) or built by the host ("1") — and with only the parse there ("0")."""
     os.environ["SPZ_AMD_GZIP_DEVICE_HUFFMAN"] = "0" if huffman == "0" else "1"
@@ -92,7 +92,7 @@ def test_device_declines_what_it_cannot_splice_and_the_result_is_still_zlibs():
 
 
 def test_long_repeats_need_larger_jobs_and_get_them():
-    """Pieces of up to 40 KiB that come back at distances around the 32 KiB window: with 16 KiB jobs two neighbours
+    """Pieces of up to 40 KiB that come back at distances around the 32 KiB window: with 8 and 16 KiB jobs two neighbours
     often do not meet inside the successor's range; the stage is rerun with larger jobs on the device."""
     rng = np.random.default_rng(9)
     pieces = [rng.integers(0, 256, int(rng.integers(1 << 10, 40 << 10)), dtype=np.uint8).tobytes() for _ in range(6)]
