@@ -158,7 +158,9 @@ __global__ __launch_bounds__(1024) void lz_match_kernel(const uint8_t *__restric
                                                         uint32_t *__restrict__ r128, uint32_t *__restrict__ r32) {
   __shared__ uint32_t s_link[kMatchWindowDwords];
   __shared__ uint32_t s_rank[kMatchWindowDwords];
+  __shared__ uint32_t s_next_chunk;
   const uint32_t tid = threadIdx.x;
+  if (tid == 0) s_next_chunk = 0u;
   const uint64_t t0 = (uint64_t)blockIdx.x * kMatchTile;
   const long long origin = (long long)t0 - (long long)W;  // window position 0; a multiple of 4 KiB
   const uint64_t seg = t0 / kLinkSegment;
@@ -174,8 +176,14 @@ __global__ __launch_bounds__(1024) void lz_match_kernel(const uint8_t *__restric
   const WindowData data = {d, origin};
   const WindowU16 lk = {reinterpret_cast<const uint16_t *>(s_link)};
   const WindowU16 rk = {reinterpret_cast<const uint16_t *>(s_rank)};
-  for (uint32_t it = 0; it < kMatchTile / kMatchThreads; ++it) {
-    const uint32_t local = it * kMatchThreads + tid;
+  // 64 positions at a time, taken by whichever wave is free: walks differ in length by orders of magnitude, and the
+  // workgroup — alone on its CU — lasts as long as its slowest wave
+  for (;;) {
+    uint32_t chunk = 0;
+    if ((tid & 63u) == 0u) chunk = atomicAdd(&s_next_chunk, 1u);
+    chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
+    if (chunk >= kMatchTile / 64u) break;
+    const uint32_t local = chunk * 64u + (tid & 63u);
     const uint64_t p = t0 + local;
     if (p < n_pos) {
       // the window base in window coordinates; a base below the window is out of every candidate's reach
