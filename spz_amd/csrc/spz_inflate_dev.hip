@@ -14,7 +14,7 @@
 //   inf_window_kernel   one workgroup walks the chunks in order and resolves each chunk's final 32 KiB against its
 //                       predecessor's (kept in LDS): the only serial step.
 //   inf_place_kernel    symbols -> bytes at their final offsets, references resolved from the predecessor's window.
-//   inf_crc_kernel      CRC-32 of 256 KiB pieces (the caller folds them with crc32_combine and compares with the
+//   inf_crc_kernel      CRC-32 of 256 KiB pieces, a wave each (the caller folds them with crc32_combine and compares with the
 //                       member's trailer: the result can only be right or refused).
 // Runs of stored blocks (incompressible sections) have no dynamic header to find: their blocks are found by their own
 // pattern (00 LEN ~LEN at a byte boundary, leading to another header).  Raw bytes now and then read like a block header: the chunk before such a look-alike does not end on it, so the
@@ -348,29 +348,61 @@ __global__ __launch_bounds__(256) void inf_place_kernel(const uint16_t *__restri
 }
 
 // ---- CRC-32 (IEEE 802.3, the one gzip uses) of pieces ------------------------------------------------------------
+// One wave per 256 KiB piece: lane t takes the t-th 64th of it (slice-by-4 tables in LDS), and the lanes' CRCs are
+// put together the way crc32_combine does it — crc(A || B) = crc(A) * x^(8 len B) mod P  xor  crc(B), which over all
+// 64 parts is the xor of every part's CRC times x^(8 * bytes after it).  (A thread per piece, 39 waves for a 650 MB
+// stream, took 9.3 ms.)
+constexpr uint32_t kCrcPoly = 0xedb88320u;
+
+__device__ __forceinline__ uint32_t crc_multmodp(uint32_t a, uint32_t b) {  // a * b mod P, bit-reflected (x^0 = 1 << 31)
+  uint32_t m = 1u << 31, p = 0u;
+  for (;;) {
+    if (a & m) {
+      p ^= b;
+      if ((a & (m - 1u)) == 0u) break;
+    }
+    m >>= 1;
+    b = (b & 1u) ? (b >> 1) ^ kCrcPoly : b >> 1;
+  }
+  return p;
+}
+
 __global__ __launch_bounds__(64) void inf_crc_kernel(const uint8_t *__restrict__ data, uint64_t nbytes, uint32_t piece,
                                                      uint32_t *__restrict__ crcs) {
-  __shared__ uint32_t table[256];
-  for (uint32_t i = threadIdx.x; i < 256; i += 64) {
+  __shared__ uint32_t table[4][256];
+  __shared__ uint32_t x2n[32];  // x^(2^n) mod P
+  const uint32_t lane = threadIdx.x;
+  for (uint32_t i = lane; i < 256; i += 64) {
     uint32_t c = i;
-    for (int k = 0; k < 8; ++k) c = (c & 1u) ? 0xedb88320u ^ (c >> 1) : c >> 1;
-    table[i] = c;
+    for (int k = 0; k < 8; ++k) c = (c & 1u) ? kCrcPoly ^ (c >> 1) : c >> 1;
+    table[0][i] = c;
+  }
+  if (lane == 0) {
+    uint32_t p = 1u << 30;  // x^1
+    x2n[0] = p;
+    for (int n = 1; n < 32; ++n) x2n[n] = p = crc_multmodp(p, p);
   }
   __syncthreads();
-  const uint64_t idx = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  const uint64_t lo = idx * piece;
-  if (lo >= nbytes) return;
-  const uint64_t hi = lo + piece < nbytes ? lo + piece : nbytes;
+  for (int t = 1; t < 4; ++t) {
+    for (uint32_t i = lane; i < 256; i += 64) {
+      const uint32_t c = table[t - 1][i];
+      table[t][i] = (c >> 8) ^ table[0][c & 0xffu];
+    }
+    __syncthreads();
+  }
+  const uint64_t piece_lo = (uint64_t)blockIdx.x * piece;
+  if (piece_lo >= nbytes) return;
+  const uint64_t piece_hi = piece_lo + piece < nbytes ? piece_lo + piece : nbytes;
+  const uint32_t sub = piece / 64u;  // a multiple of 64 bytes (pieces start 256-byte aligned)
+  const uint64_t lo = piece_lo + (uint64_t)lane * sub < piece_hi ? piece_lo + (uint64_t)lane * sub : piece_hi;
+  const uint64_t hi = lo + sub < piece_hi ? lo + sub : piece_hi;
   uint32_t c = 0xffffffffu;
   uint64_t p = lo;
   auto eat = [&](uint32_t w) {
     c ^= w;
-    c = table[c & 0xffu] ^ (c >> 8);
-    c = table[c & 0xffu] ^ (c >> 8);
-    c = table[c & 0xffu] ^ (c >> 8);
-    c = table[c & 0xffu] ^ (c >> 8);
+    c = table[3][c & 0xffu] ^ table[2][(c >> 8) & 0xffu] ^ table[1][(c >> 16) & 0xffu] ^ table[0][c >> 24];
   };
-  for (; p + 64 <= hi; p += 64) {  // pieces start 256-byte aligned
+  for (; p + 64 <= hi; p += 64) {
     const uint4 *q = reinterpret_cast<const uint4 *>(data + p);
     const uint4 a0 = q[0], a1 = q[1], a2 = q[2], a3 = q[3];
     eat(a0.x); eat(a0.y); eat(a0.z); eat(a0.w);
@@ -378,8 +410,20 @@ __global__ __launch_bounds__(64) void inf_crc_kernel(const uint8_t *__restrict__
     eat(a2.x); eat(a2.y); eat(a2.z); eat(a2.w);
     eat(a3.x); eat(a3.y); eat(a3.z); eat(a3.w);
   }
-  for (; p < hi; ++p) c = table[(c ^ data[p]) & 0xffu] ^ (c >> 8);
-  crcs[idx] = c ^ 0xffffffffu;
+  for (; p < hi; ++p) c = table[0][(c ^ data[p]) & 0xffu] ^ (c >> 8);
+  c ^= 0xffffffffu;
+  // this part's CRC times x^(8 * bytes after it); an empty part contributes nothing
+  uint32_t part = 0u;
+  if (hi > lo) {
+    uint64_t n = piece_hi - hi;  // bytes after this part
+    uint32_t op = 1u << 31;      // x^0
+    for (uint32_t k = 3; n != 0; n >>= 1, ++k) {
+      if (n & 1u) op = crc_multmodp(x2n[k & 31u], op);
+    }
+    part = crc_multmodp(op, c);
+  }
+  for (int off = 32; off > 0; off >>= 1) part ^= __shfl_xor(part, off, 64);
+  if (lane == 0) crcs[blockIdx.x] = part;
 }
 
 struct InfContext {
@@ -567,7 +611,7 @@ int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, 
   lap("windows");
   hipLaunchKernelGGL(inf_place_kernel, dim3(16, n), dim3(256), 0, st, d_sym, d_place, d_win, d_out, d_bad);
   SPZ_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(inf_crc_kernel, dim3((n_pieces + 63) / 64), dim3(64), 0, st, d_out, total_out, kCrcPiece, d_crcs);
+  hipLaunchKernelGGL(inf_crc_kernel, dim3(n_pieces), dim3(64), 0, st, d_out, total_out, kCrcPiece, d_crcs);
   SPZ_HIP_TRY(hipGetLastError());
   uint32_t bad = 0;
   SPZ_HIP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, st));
