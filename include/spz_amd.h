@@ -392,7 +392,9 @@ int spz_amd_zlib_block_stats(void *ctx, const spz_amd_deflate_static *tables, ui
  * whose h_lfreq / h_dfreq may then both be NULL) builds every block's three trees and returns the two lengths
  * _tr_flush_block chooses by; the caller lays the blocks out (bit_start, choice, stored input range; the header_*
  * fields are filled on the device), encode_planned enqueues the writing of headers and symbols and
- * encode_finish_ex (below) copies out the body and each block's symbol bits and header bits. */
+ * encode_finish_ex (below) copies out the body and each block's symbol bits and header bits.  The order is
+ * enforced: block_trees returns SPZ_AMD_ERR_INVALID_ARG unless block_stats has run for the same num_blocks, and
+ * encode_planned unless block_trees has. */
 typedef struct {
   int64_t opt_len;
   int64_t static_len;

@@ -486,7 +486,7 @@ struct HeaderSink {
     fill += nbits;
     total += nbits;
     if (fill >= 32u) {
-      out[words++] = (uint32_t)acc;
+      if (words < kHeaderStride) out[words++] = (uint32_t)acc;  // a header cannot be longer (the stride is its bound)
       acc >>= 32;
       fill -= 32u;
     }
@@ -536,7 +536,7 @@ __global__ __launch_bounds__(64) void lz_header_kernel(spz_amd_deflate_block *__
     hf::walk_lengths(static_cast<const uint8_t *>(cd.llen), (int)t.lcodes - 1, send);
     hf::walk_lengths(static_cast<const uint8_t *>(cd.dlen), (int)t.dcodes - 1, send);
   }
-  if (s.fill > 0u) s.out[s.words++] = (uint32_t)s.acc;
+  if (s.fill > 0u && s.words < kHeaderStride) s.out[s.words++] = (uint32_t)s.acc;
   blocks[b].header_word_begin = b * kHeaderStride;
   blocks[b].header_words = s.words;
   blocks[b].header_bits = s.total;
@@ -647,6 +647,7 @@ struct LzContext {
   // memory of the parse that the Huffman stage reuses
   char *scratch_a = nullptr, *scratch_b = nullptr, *scratch_c = nullptr;
   size_t scratch_a_bytes = 0, scratch_b_bytes = 0, scratch_c_bytes = 0;
+  uint32_t stats_blocks = 0, trees_blocks = 0;  // block counts the statistics / the trees on the device were made for
 };
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
@@ -933,6 +934,8 @@ int spz_amd_zlib_block_stats(void *ctx, const spz_amd_deflate_static *tables, ui
   SPZ_HIP_TRY(hipMemcpyAsync(h_bytes, a.bytes, (size_t)num_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   SPZ_HIP_TRY(hipMemcpyAsync(h_last_len, a.last, (size_t)num_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   SPZ_HIP_TRY(hipStreamSynchronize(st));
+  c->stats_blocks = num_blocks;
+  c->trees_blocks = 0;
   return SPZ_AMD_OK;
 }
 
@@ -1049,6 +1052,7 @@ int spz_amd_zlib_encode_finish(void *ctx, uint32_t total_blocks, uint64_t body_b
 int spz_amd_zlib_block_trees(void *ctx, uint32_t num_blocks, spz_amd_deflate_plan *h_plan) {
   LzContext *c = static_cast<LzContext *>(ctx);
   if (c == nullptr || num_blocks == 0 || h_plan == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  if (c->stats_blocks != num_blocks) return SPZ_AMD_ERR_INVALID_ARG;  // block_stats first, for the same blocks
   DeviceGuard guard;
   int rc = guard.enter(c->device);
   if (rc != SPZ_AMD_OK) return rc;
@@ -1061,6 +1065,7 @@ int spz_amd_zlib_block_trees(void *ctx, uint32_t num_blocks, spz_amd_deflate_pla
   SPZ_HIP_TRY(hipGetLastError());
   SPZ_HIP_TRY(hipMemcpyAsync(h_plan, a.plan, (size_t)num_blocks * sizeof(spz_amd_deflate_plan), hipMemcpyDeviceToHost, st));
   SPZ_HIP_TRY(hipStreamSynchronize(st));
+  c->trees_blocks = num_blocks;
   return SPZ_AMD_OK;
 }
 
@@ -1070,6 +1075,7 @@ int spz_amd_zlib_encode_planned(void *ctx, const spz_amd_deflate_static *tables,
   if (c == nullptr || tables == nullptr || block_symbols == 0 || num_blocks == 0 || h_blocks == nullptr) {
     return SPZ_AMD_ERR_INVALID_ARG;
   }
+  if (c->trees_blocks != num_blocks) return SPZ_AMD_ERR_INVALID_ARG;  // block_trees first: the codes are its output
   if ((uint64_t)num_blocks * block_symbols < c->num_symbols) return SPZ_AMD_ERR_INVALID_ARG;
   const size_t body_words = (size_t)((body_bytes + 3) / 4) + 2;
   if (body_words * 4 > c->scratch_a_bytes) return SPZ_AMD_ERR_CAPACITY;
