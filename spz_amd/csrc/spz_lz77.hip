@@ -648,7 +648,48 @@ struct LzContext {
   char *scratch_a = nullptr, *scratch_b = nullptr, *scratch_c = nullptr;
   size_t scratch_a_bytes = 0, scratch_b_bytes = 0, scratch_c_bytes = 0;
   uint32_t stats_blocks = 0, trees_blocks = 0;  // block counts the statistics / the trees on the device were made for
+  // encode_planned packs the bits in kBodyParts launches; encode_finish_ex copies each part out when its launch is done
+  static constexpr int kBodyParts = 4;
+  struct CopyLane *lane = nullptr;     // the device's copy stream and events, while this context holds them
+  uint64_t part_end[kBodyParts] = {};  // byte offsets in the body
+  int n_parts = 0;
 };
+
+// One copy stream and its events per device, made once (creating and destroying them per call cost what the overlap
+// won) and lent to one context at a time; a second writer at the same time copies its body out in one piece.
+struct CopyLane {
+  hipStream_t stream = nullptr;
+  hipEvent_t part_done[LzContext::kBodyParts] = {};
+  bool in_use = false;
+};
+CopyLane g_copy_lane[kMaxDevices];
+std::mutex g_copy_lane_mutex;
+
+CopyLane *copy_lane_acquire(int device) {  // the current device is `device`
+  if (device < 0 || device >= kMaxDevices) return nullptr;
+  std::lock_guard<std::mutex> lock(g_copy_lane_mutex);
+  CopyLane &l = g_copy_lane[device];
+  if (l.in_use) return nullptr;
+  if (l.stream == nullptr) {
+    if (hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking) != hipSuccess) {
+      l.stream = nullptr;
+      return nullptr;
+    }
+    for (hipEvent_t &e : l.part_done) {
+      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;  // asked for again next time
+    }
+  }
+  for (hipEvent_t e : l.part_done) {
+    if (e == nullptr) return nullptr;
+  }
+  l.in_use = true;
+  return &l;
+}
+void copy_lane_release(CopyLane *l) {
+  if (l == nullptr) return;
+  std::lock_guard<std::mutex> lock(g_copy_lane_mutex);
+  l->in_use = false;
+}
 
 size_t round_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
@@ -867,7 +908,11 @@ void spz_amd_zlib_parse_close(void *ctx) {
   LzContext *c = static_cast<LzContext *>(ctx);
   if (c == nullptr) return;
   DeviceGuard guard;
-  if (guard.enter(c->device) == SPZ_AMD_OK && c->block) scratch_release(c->device, c->block);
+  if (guard.enter(c->device) == SPZ_AMD_OK) {
+    if (c->n_parts > 0) (void)hipDeviceSynchronize();  // an encode_planned nobody finished: nothing may still use the block
+    copy_lane_release(c->lane);
+    if (c->block) scratch_release(c->device, c->block);
+  }
   delete c;
 }
 
@@ -1028,6 +1073,31 @@ int spz_amd_zlib_encode_finish_ex(void *ctx, uint32_t total_blocks, uint64_t bod
   hipStream_t st = nullptr;
   static const bool timing = std::getenv("SPZ_AMD_LZ_TIMING") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
+  if (c->n_parts > 0) {  // after encode_planned: every part as soon as its launch is done
+    uint64_t from = 0;
+    for (int g = 0; g < c->n_parts; ++g) {
+      const uint64_t to = c->part_end[g] < body_bytes ? c->part_end[g] : body_bytes;
+      SPZ_HIP_TRY(hipStreamWaitEvent(c->lane->stream, c->lane->part_done[g], 0));
+      if (to > from) SPZ_HIP_TRY(hipMemcpyAsync(h_body + from, c->scratch_a + from, to - from, hipMemcpyDeviceToHost, c->lane->stream));
+      if (to > from) from = to;
+    }
+    c->n_parts = 0;
+    if (from != body_bytes) {
+      (void)hipDeviceSynchronize();
+      return SPZ_AMD_ERR_INVALID_ARG;  // not the body encode_planned was given
+    }
+    SPZ_HIP_TRY(hipMemcpyAsync(h_symbol_bits, a.bits, (size_t)total_blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->lane->stream));
+    if (h_header_bits != nullptr) {
+      SPZ_HIP_TRY(hipMemcpy2DAsync(h_header_bits, sizeof(uint32_t), &a.blocks[0].header_bits, sizeof(spz_amd_deflate_block),
+                                   sizeof(uint32_t), total_blocks, hipMemcpyDeviceToHost, c->lane->stream));
+    }
+    SPZ_HIP_TRY(hipStreamSynchronize(c->lane->stream));
+    SPZ_HIP_TRY(hipStreamSynchronize(st));
+    if (timing) {
+      std::fprintf(stderr, "[lz77] encode + download %.4f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    }
+    return SPZ_AMD_OK;
+  }
   if (timing) {
     (void)hipStreamSynchronize(st);
     std::fprintf(stderr, "[lz77] encode (what was still running) %.4f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
@@ -1102,10 +1172,22 @@ int spz_amd_zlib_encode_planned(void *ctx, const spz_amd_deflate_static *tables,
   SPZ_HIP_TRY(hipMemcpyAsync(a.blocks, h_blocks, (size_t)num_blocks * sizeof(spz_amd_deflate_block), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(lz_header_kernel, dim3((num_blocks + 63) / 64), dim3(64), 0, st, a.blocks, a.codes, a.trees, a.header, num_blocks);
   SPZ_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(lz_encode_kernel, dim3(num_blocks), dim3(kEncodeThreads), 0, st, c->dense_dist, c->dense_lc,
-                     (unsigned long long)c->num_symbols, block_symbols, c->data, a.tables, a.blocks, a.codes, a.header, d_body, a.bits,
-                     0u);
-  SPZ_HIP_TRY(hipGetLastError());
+  // in a few launches, so that the body's first parts are on their way to the host while the later ones are packed
+  if (c->lane == nullptr) c->lane = copy_lane_acquire(c->device);
+  const int parts = (c->lane != nullptr && num_blocks >= 4096u) ? LzContext::kBodyParts : 1;
+  c->n_parts = 0;
+  for (int g = 0; g < parts; ++g) {
+    const uint32_t b0 = (uint32_t)((uint64_t)num_blocks * g / parts), b1 = (uint32_t)((uint64_t)num_blocks * (g + 1) / parts);
+    hipLaunchKernelGGL(lz_encode_kernel, dim3(b1 - b0), dim3(kEncodeThreads), 0, st, c->dense_dist, c->dense_lc,
+                       (unsigned long long)c->num_symbols, block_symbols, c->data, a.tables, a.blocks, a.codes, a.header, d_body, a.bits,
+                       b0);
+    SPZ_HIP_TRY(hipGetLastError());
+    if (c->lane == nullptr) break;  // one launch, copied out by encode_finish_ex in one piece
+    SPZ_HIP_TRY(hipEventRecord(c->lane->part_done[g], st));
+    // a part ends with the last whole word before the next launch's first block: that block completes the word it starts in
+    c->part_end[g] = b1 < num_blocks ? (h_blocks[b1].bit_start >> 5) * 4 : body_bytes;
+    c->n_parts = g + 1;
+  }
   return SPZ_AMD_OK;  // not waited for: the caller maps its output buffer meanwhile, then spz_amd_zlib_encode_finish_ex
 }
 
