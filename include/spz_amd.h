@@ -50,7 +50,9 @@ enum {
   SPZ_AMD_ERR_NO_DEVICE = -8,       /* no usable HIP device / runtime */
   SPZ_AMD_ERR_HIP = -9,             /* a HIP call failed (see spz_amd_last_hip_error) */
   SPZ_AMD_ERR_UNSUPPORTED = -10,    /* e.g. encode of version 1; RCCL not loadable */
-  SPZ_AMD_ERR_COMM = -11            /* an RCCL call failed (see spz_amd_last_rccl_error) */
+  SPZ_AMD_ERR_COMM = -11,           /* an RCCL call failed (see spz_amd_last_rccl_error) */
+  SPZ_AMD_ERR_VERIFY = -12          /* a result failed the library's own check (container stage: symbols that do not
+                                       reproduce their input, a member that does not inflate back to it) */
 };
 
 /* CoordinateSystem values, splat-types.h:24-34. */
@@ -414,6 +416,13 @@ int spz_amd_zlib_encode_finish(void *ctx, uint32_t total_blocks, uint64_t body_b
                                uint64_t *h_symbol_bits);
 int spz_amd_zlib_encode_finish_ex(void *ctx, uint32_t total_blocks, uint64_t body_bytes, uint8_t *h_body,
                                   uint64_t *h_symbol_bits, uint32_t *h_header_bits /* may be NULL */);
+/* Every encode_finish(_ex) returns SPZ_AMD_ERR_VERIFY instead of a body when the symbols it was coded from do not
+ * reproduce the input (checked on the device for every block, always: each literal is its input byte, each match
+ * copies equal bytes from at most 32 KiB back, each block covers exactly its input range).
+ * verify_member (after encode_finish(_ex), before close): inflates the body where it still lies in device memory with
+ * the device reader below and compares the result with the input byte for byte: SPZ_AMD_OK = equal, SPZ_AMD_ERR_VERIFY =
+ * not, SPZ_AMD_ERR_UNSUPPORTED = the device reader declines this body (the caller checks on the host). */
+int spz_amd_zlib_verify_member(void *ctx, uint64_t body_bytes);
 int spz_amd_zlib_encode_blocks(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols,
                                uint32_t num_blocks, const spz_amd_deflate_block *h_blocks,
                                const spz_amd_deflate_codes *h_codes, const uint32_t *h_header_words,
@@ -431,6 +440,9 @@ int spz_amd_zlib_encode_blocks(void *ctx, const spz_amd_deflate_static *tables, 
  *      SPZ_AMD_ERR_UNSUPPORTED = declined (no usable block starts, chunks that do not link up, a chunk that expands
  *      more than 8 x, not enough device memory): the caller's host readers take over.  Blocking. ------------------- */
 int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, void **ctx, uint64_t *out_bytes);
+/* the same for deflate data that is in device memory already; equals_device: is the result these nbytes (device memory)? */
+int spz_amd_inflate_open_device(const uint8_t *d_deflate, uint64_t nbytes, int device, void **ctx, uint64_t *out_bytes);
+int spz_amd_inflate_equals_device(void *ctx, const uint8_t *d_expected, uint64_t nbytes);
 uint32_t spz_amd_inflate_crc_piece_bytes(void);
 int spz_amd_inflate_piece_crcs(void *ctx, uint32_t *h_crcs, uint32_t capacity, uint32_t *num_pieces);
 int spz_amd_inflate_fetch(void *ctx, uint8_t *h_out);

@@ -185,6 +185,10 @@ unsigned effectiveCpuCount();
 // environment SPZ_AMD_GZIP_DEVICE = 0 never, 1 always, unset: inputs of 8 MiB and more).  The bytes are zlib's
 // whichever way the parse ran; this says which way it was.
 uint64_t deviceGzipParseCount();
+// Members of the device writer that failed one of its checks (symbols that do not reproduce the input; with
+// SPZ_AMD_GZIP_VERIFY=1 a member that does not inflate back to it) and were discarded: the caller got the host writer's
+// bytes instead, and a "[SPZ ERROR] spz_amd: the device gzip writer ..." line.  Anything but 0 is a defect to report.
+uint64_t deviceGzipRejectCount();
 // Members decompressGzipped has inflated on the device in this process (spz_inflate_dev.hip; SPZ_AMD_GUNZIP_DEVICE = 0
 // never, 1 from 1 MiB, unset: from 8 MiB); believed only after the CRC-32 and ISIZE of the trailer matched.
 uint64_t deviceInflateCount();

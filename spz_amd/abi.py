@@ -24,6 +24,7 @@ ERR_NO_DEVICE = -8
 ERR_HIP = -9
 ERR_UNSUPPORTED = -10
 ERR_COMM = -11
+ERR_VERIFY = -12
 
 UNSPECIFIED, LDB, RDB, LUB, RUB, LDF, RDF, LUF, RUF = range(9)
 NUM_SECTIONS = 6
@@ -50,10 +51,10 @@ EXPORTS = (
     "spz_amd_rccl_comm_destroy", "spz_amd_gatherv_rccl", "spz_amd_scatterv_rccl",
     "spz_amd_ipc_alloc", "spz_amd_ipc_free", "spz_amd_ipc_open", "spz_amd_ipc_close",
     "spz_amd_zlib_parse_open", "spz_amd_zlib_parse_open_ex", "spz_amd_zlib_parse_fetch", "spz_amd_zlib_parse_close",
-    "spz_amd_zlib_parse_append", "spz_amd_zlib_block_stats", "spz_amd_zlib_encode_blocks",
+    "spz_amd_zlib_parse_append", "spz_amd_zlib_block_stats", "spz_amd_zlib_encode_blocks", "spz_amd_zlib_verify_member",
     "spz_amd_zlib_encode_group", "spz_amd_zlib_encode_finish", "spz_amd_zlib_parse_open_dev", "spz_amd_encode_host_keep", "spz_amd_kept_stream_release",
     "spz_amd_zlib_block_trees", "spz_amd_zlib_encode_planned", "spz_amd_zlib_encode_finish_ex",
-    "spz_amd_inflate_open", "spz_amd_inflate_crc_piece_bytes", "spz_amd_inflate_piece_crcs", "spz_amd_inflate_fetch",
+    "spz_amd_inflate_open", "spz_amd_inflate_open_device", "spz_amd_inflate_equals_device", "spz_amd_inflate_crc_piece_bytes", "spz_amd_inflate_piece_crcs", "spz_amd_inflate_fetch",
     "spz_amd_inflate_device_data", "spz_amd_inflate_close",
 )
 

@@ -418,6 +418,7 @@ const char *spz_amd_status_string(int status) {
     case SPZ_AMD_ERR_HIP: return "HIP runtime error";
     case SPZ_AMD_ERR_UNSUPPORTED: return "unsupported operation";
     case SPZ_AMD_ERR_COMM: return "RCCL error";
+    case SPZ_AMD_ERR_VERIFY: return "self-check failed";
     default: return "unknown status";
   }
 }

@@ -131,7 +131,7 @@ namespace {
 
 // One ncclGroupStart/End moving every selected fragment between the root's global stream and the ranks' own streams:
 // toward the root (gather) or away from it (scatter).
-int exchange_rccl(bool gather, void *comm, int rank, int world, int root, const uint64_t *first, const uint64_t *count,
+static int exchange_rccl(bool gather, void *comm, int rank, int world, int root, const uint64_t *first, const uint64_t *count,
                   int sh_degree, int version, uint8_t *d_local_stream, uint8_t *d_global_stream, unsigned section_mask,
                   void *hip_stream) {
   if (comm == nullptr || first == nullptr || count == nullptr || world < 1 || rank < 0 || rank >= world || root < 0 ||

@@ -381,11 +381,17 @@ size_t availablePhysicalBytes() {
   return (pages > 0 && page > 0) ? static_cast<size_t>(pages) * static_cast<size_t>(page) : 0;
 }
 
-// SPZ_AMD_GZIP_VERIFY: 0 (default) = the writer's own 256 KiB prefix check against zlib; 1 = additionally inflate
-// the finished member and compare every byte with the input before returning it (a valid member of the right
-// content: ~0.1 s per 100 MB); 2 = additionally run zlib itself over the whole input and compare the two members
-// byte for byte (the identity claim itself, at zlib's price).  A failed check discards the parallel result and
-// returns zlib's.
+// What a member of the parallel writers has been through before it is returned:
+//   always        the first 64-256 KiB compared with zlib's own output; every Huffman block's bit count compared with the
+//                 layout's plan; and on the device route every symbol checked against the input on the device
+//                 (lz_validate_kernel: literals are their input bytes, matches copy equal bytes, blocks cover their
+//                 ranges) — the LZ77 stage can only be lossless, whatever the parse kernels did.
+//   SPZ_AMD_GZIP_VERIFY=1  additionally the finished member is inflated and compared with the input byte for byte
+//                 before it is returned: on the device route by the device reader on the body still in HBM
+//                 (spz_amd_zlib_verify_member, ~0.1 s for a 650 MB stream), otherwise by the host readers.
+//   SPZ_AMD_GZIP_VERIFY=2  additionally zlib itself runs over the whole input and the two members are compared byte for
+//                 byte (the identity claim itself, at zlib's price).
+// A failed check discards the member, logs, and the next writer down (host writer, then zlib) produces it.
 int gzipVerifyLevel() {
   const char *e = std::getenv("SPZ_AMD_GZIP_VERIFY");
   return e ? std::max(0, std::atoi(e)) : 0;
@@ -393,8 +399,8 @@ int gzipVerifyLevel() {
 
 bool compressGzippedZlib(const uint8_t *data, size_t size, std::vector<uint8_t> *out);
 
-bool verifiedExact(const uint8_t *data, size_t size, const std::vector<uint8_t> &member, int level) {
-  if (level >= 1) {
+bool verifiedExact(const uint8_t *data, size_t size, const std::vector<uint8_t> &member, int level, bool inflated_already = false) {
+  if (level >= 1 && !inflated_already) {
     std::vector<uint8_t> back;
     if (!decompressGzipped(member.data(), member.size(), &back) || back.size() != size ||
         std::memcmp(back.data(), data, size) != 0) {
@@ -411,6 +417,8 @@ bool verifiedExact(const uint8_t *data, size_t size, const std::vector<uint8_t> 
   }
   return true;
 }
+
+std::atomic<uint64_t> g_device_rejects{0};  // members of the device writer that failed a check and were not returned
 
 // The LZ77 parse of the exact writer on the MI355X (spz_lz77.hip): SPZ_AMD_GZIP_DEVICE = 0 never, 1 whenever a
 // device answers, unset: for inputs of 8 MiB and more when a device answers.
@@ -472,6 +480,8 @@ struct DeviceHeadParser final : exactgz::HeadParser {
     status = spz_amd_zlib_encode_finish_ex(ctx, total, body_bytes, body, symbol_bits, header_bits);
     return status == SPZ_AMD_OK;
   }
+  // SPZ_AMD_GZIP_VERIFY >= 1: the body, still in device memory, inflated there and compared with the input byte for byte
+  int verifyMember(uint64_t body_bytes) { return spz_amd_zlib_verify_member(ctx, body_bytes); }
 };
 
 bool deviceParseWanted(size_t size) {
@@ -487,6 +497,7 @@ std::atomic<uint64_t> g_device_parses{0};
 }  // namespace
 
 uint64_t deviceGzipParseCount() { return g_device_parses.load(); }
+uint64_t deviceGzipRejectCount() { return g_device_rejects.load(); }
 
 namespace {
 bool compressGzippedWithCopy(const uint8_t *data, size_t size, std::vector<uint8_t> *out, const uint8_t *d_copy);
@@ -510,6 +521,8 @@ bool compressGzippedWithCopy(const uint8_t *data, size_t size, std::vector<uint8
         static const bool timing = std::getenv("SPZ_AMD_EXACT_GZIP_TIMING") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
         bool ok;
+        const int level = gzipVerifyLevel();
+        bool inflated_on_device = false;
         {
           DeviceHeadParser parser;
           parser.d_copy = d_copy;
@@ -518,14 +531,32 @@ bool compressGzippedWithCopy(const uint8_t *data, size_t size, std::vector<uint8
             std::fprintf(stderr, "[exactgz] writer     %.3f s in all\n",
                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
           }
+          if (!ok && parser.status == SPZ_AMD_ERR_VERIFY) {
+            g_device_rejects.fetch_add(1);
+            logLine("[SPZ ERROR] spz_amd: the device gzip writer's symbols do not reproduce the input; using the host writer");
+          }
+          if (ok && level >= 1 && out->size() > 18) {
+            const int rc = parser.verifyMember(out->size() - 18);
+            if (rc == SPZ_AMD_OK) {
+              inflated_on_device = true;
+            } else if (rc == SPZ_AMD_ERR_VERIFY) {
+              g_device_rejects.fetch_add(1);
+              logLine("[SPZ ERROR] spz_amd: the device gzip writer's member does not inflate to its input; using the host writer");
+              ok = false;
+            }  // anything else: the device reader declined, the host inflates below
+            if (timing) {
+              std::fprintf(stderr, "[exactgz] + verify   %.3f s in all (device reader: %s)\n",
+                           std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), spz_amd_status_string(rc));
+            }
+          }
         }
         if (timing) {
           std::fprintf(stderr, "[exactgz] + release  %.3f s in all\n",
                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         }
         if (ok) {
-          const int level = gzipVerifyLevel();
-          if (level == 0 || verifiedExact(data, size, *out, level)) {
+          // level 1 is done when the device has inflated and compared; level 2 (zlib's own member) is the host's either way
+          if (level == 0 || (level == 1 && inflated_on_device) || verifiedExact(data, size, *out, inflated_on_device ? 2 : level, inflated_on_device)) {
             g_device_parses.fetch_add(1);
             return true;
           }
@@ -1304,7 +1335,12 @@ GaussianCloud loadSpz(const uint8_t *data, int32_t size, const UnpackOptions &o)
           return r;
         }
       }
-      // anything unusual about the stream: the ordinary route below produces the reference's log line and result
+      // anything unusual about the stream (bad header, short stream): the reference's log line and result come from
+      // the ordinary decode of the bytes this context already holds — the member is not inflated a second time
+      std::vector<uint8_t> inflated;
+      detail::resizeUninitialized(&inflated, static_cast<size_t>(stream_bytes));
+      if (spz_amd_inflate_fetch(ctx, inflated.data()) == SPZ_AMD_OK) return unpackFromStream(inflated.data(), inflated.size(), o);
+      device_declined = true;
     } else if (headerLen != 0 && idx.pieceBytes.empty()) {
       device_declined = true;  // not asked a second time by decompressGzipped
     }

@@ -426,6 +426,23 @@ __global__ __launch_bounds__(64) void inf_crc_kernel(const uint8_t *__restrict__
   if (lane == 0) crcs[blockIdx.x] = part;
 }
 
+// Byte equality of two device buffers (the writer's self-check: the member it has just made, inflated, against its input).
+__global__ __launch_bounds__(256) void inf_compare_kernel(const uint8_t *__restrict__ a, const uint8_t *__restrict__ b, uint64_t nbytes,
+                                                         uint32_t *__restrict__ diff) {
+  const uint64_t groups = nbytes / 16;
+  uint32_t bad = 0;
+  for (uint64_t g = (uint64_t)blockIdx.x * 256 + threadIdx.x; g < groups; g += (uint64_t)gridDim.x * 256) {
+    uint4 x, y;
+    __builtin_memcpy(&x, a + 16 * g, 16);
+    __builtin_memcpy(&y, b + 16 * g, 16);
+    if (x.x != y.x || x.y != y.y || x.z != y.z || x.w != y.w) bad = 1;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    for (uint64_t i = groups * 16; i < nbytes; ++i) bad |= a[i] != b[i];
+  }
+  if (bad) atomicAdd(diff, 1u);
+}
+
 struct InfContext {
   int device = 0;
   char *block = nullptr;
@@ -433,6 +450,7 @@ struct InfContext {
   uint64_t out_bytes = 0;
   uint32_t *crcs = nullptr;
   uint32_t n_pieces = 0;
+  uint32_t *diff = nullptr;  // equals_device's count of differing groups
 };
 
 size_t round256(size_t v) { return (v + 255) / 256 * 256; }
@@ -444,14 +462,20 @@ using namespace spz_amd_detail;
 
 extern "C" {
 
-int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, void **ctx, uint64_t *out_bytes) {
-  if (h_deflate == nullptr || ctx == nullptr || out_bytes == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+// The deflate data comes from the host (h_deflate) or is on the device already (d_deflate: the writer's own body,
+// spz_amd_zlib_verify_member).
+static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate, uint64_t nbytes, int device, void **ctx,
+                             uint64_t *out_bytes) {
+  if ((h_deflate == nullptr) == (d_deflate == nullptr) || ctx == nullptr || out_bytes == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
   *ctx = nullptr;
   if (nbytes < 4ull * kMinChunkBytes || nbytes >= (1ull << 32)) return SPZ_AMD_ERR_UNSUPPORTED;
-  if (((h_deflate[0] >> 1) & 3) == 0) return SPZ_AMD_ERR_UNSUPPORTED;  // opens with a stored block: nothing to gain
   DeviceGuard guard;
   int rc = guard.enter(device);
   if (rc != SPZ_AMD_OK) return rc;
+  uint8_t first_byte = 0;
+  if (h_deflate != nullptr) first_byte = h_deflate[0];
+  else SPZ_HIP_TRY(hipMemcpy(&first_byte, d_deflate, 1, hipMemcpyDeviceToHost));
+  if (((first_byte >> 1) & 3) == 0) return SPZ_AMD_ERR_UNSUPPORTED;  // opens with a stored block: nothing to gain
   static const bool timing = std::getenv("SPZ_AMD_LZ_TIMING") != nullptr;
   auto t_prev = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
@@ -513,7 +537,8 @@ int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, 
   uint16_t *d_sym = reinterpret_cast<uint16_t *>(block + o_sym);
   lap("alloc");
   hipStream_t st = nullptr;
-  SPZ_HIP_TRY(upload_adaptive(d_data, h_deflate, nbytes, st));
+  if (h_deflate != nullptr) SPZ_HIP_TRY(upload_adaptive(d_data, h_deflate, nbytes, st));
+  else SPZ_HIP_TRY(hipMemcpyAsync(d_data, d_deflate, nbytes, hipMemcpyDeviceToDevice, st));
   SPZ_HIP_TRY(hipMemsetAsync(d_data + nbytes, 0, kWinBytes + 64, st));
   SPZ_HIP_TRY(hipMemsetAsync(d_bad, 0, 256, st));
   lap("upload");
@@ -600,7 +625,7 @@ int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, 
   // ---- 3. windows, 4. place, 5. piece CRCs
   const uint32_t n_pieces = (uint32_t)((total_out + kCrcPiece - 1) / kCrcPiece);
   char *outblock = nullptr;
-  const size_t out_alloc = round256(total_out + 64) + round256((size_t)n_pieces * sizeof(uint32_t));
+  const size_t out_alloc = round256(total_out + 64) + round256((size_t)n_pieces * sizeof(uint32_t)) + 256;  // + equals_device's counter
   rc = scratch_acquire(device, out_alloc, reinterpret_cast<void **>(&outblock));
   if (rc != SPZ_AMD_OK) return rc;
   Free holder2{outblock, device};
@@ -627,9 +652,38 @@ int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, 
   c->out_bytes = total_out;
   c->crcs = d_crcs;
   c->n_pieces = n_pieces;
+  c->diff = reinterpret_cast<uint32_t *>(outblock + round256(total_out + 64) + round256((size_t)n_pieces * sizeof(uint32_t)));
   *ctx = c;
   *out_bytes = total_out;
   return SPZ_AMD_OK;
+}
+
+int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, void **ctx, uint64_t *out_bytes) {
+  if (h_deflate == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  return inflate_open_impl(h_deflate, nullptr, nbytes, device, ctx, out_bytes);
+}
+
+int spz_amd_inflate_open_device(const uint8_t *d_deflate, uint64_t nbytes, int device, void **ctx, uint64_t *out_bytes) {
+  if (d_deflate == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  return inflate_open_impl(nullptr, d_deflate, nbytes, device, ctx, out_bytes);
+}
+
+int spz_amd_inflate_equals_device(void *ctx, const uint8_t *d_expected, uint64_t nbytes) {
+  InfContext *c = static_cast<InfContext *>(ctx);
+  if (c == nullptr || d_expected == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  if (nbytes != c->out_bytes) return SPZ_AMD_ERR_VERIFY;
+  DeviceGuard guard;
+  int rc = guard.enter(c->device);
+  if (rc != SPZ_AMD_OK) return rc;
+  uint32_t *d_diff = c->diff;
+  hipStream_t st = nullptr;
+  SPZ_HIP_TRY(hipMemsetAsync(d_diff, 0, sizeof(uint32_t), st));
+  hipLaunchKernelGGL(inf_compare_kernel, dim3(2048), dim3(256), 0, st, c->out, d_expected, nbytes, d_diff);
+  SPZ_HIP_TRY(hipGetLastError());
+  uint32_t diff = 1;
+  SPZ_HIP_TRY(hipMemcpyAsync(&diff, d_diff, sizeof(diff), hipMemcpyDeviceToHost, st));
+  SPZ_HIP_TRY(hipStreamSynchronize(st));
+  return diff == 0 ? SPZ_AMD_OK : SPZ_AMD_ERR_VERIFY;
 }
 
 uint32_t spz_amd_inflate_crc_piece_bytes(void) { return kCrcPiece; }

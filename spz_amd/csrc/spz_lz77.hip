@@ -386,6 +386,71 @@ __global__ __launch_bounds__(256) void lz_block_stats_kernel(const uint16_t *__r
   }
 }
 
+// ---- validity of the symbol stream (always on) -------------------------------------------------------------------
+// Whatever the table, match, parse, stitch and compaction stages did, the symbols that are about to be coded must
+// reproduce the input: symbol after symbol has its input position (a scan of the lengths inside its Huffman block, the
+// block's first position from the caller's layout), a literal must be the byte there, a match must copy bytes equal to
+// the ones at its position from at most 32 KiB back and never from before the input, and the block's symbols must
+// cover exactly the input range the layout gives it.  One streaming read of the symbols and the input.  With this the
+// LZ77 stage can only be lossless; the Huffman stage is covered by the per-block bit counts the host compares with
+// its plan (and, when asked for, by inflating the finished member: SPZ_AMD_GZIP_VERIFY).
+__global__ __launch_bounds__(256) void lz_validate_kernel(const uint16_t *__restrict__ dist, const uint8_t *__restrict__ lc,
+                                                          unsigned long long total, uint32_t block_syms,
+                                                          const uint8_t *__restrict__ input, unsigned long long size,
+                                                          const spz_amd_deflate_block *__restrict__ blocks, uint32_t first_block,
+                                                          uint32_t *__restrict__ bad) {
+  __shared__ uint32_t s_wave[2][4];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6, b = blockIdx.x + first_block;
+  const unsigned long long g0 = (unsigned long long)b * block_syms;
+  const unsigned long long g1 = (g0 + block_syms < total) ? g0 + block_syms : total;
+  unsigned long long at = blocks[b].input_begin;  // input position of the round's first symbol (the same in every thread)
+  uint32_t wrong = 0, round = 0;
+  for (unsigned long long g = g0; g < g1; g += 256, ++round) {
+    const unsigned long long i = g + tid;
+    const bool have = i < g1;
+    const uint32_t d = have ? dist[i] : 0u, l = have ? lc[i] : 0u;
+    const uint32_t len = have ? (d ? l + MIN_MATCH : 1u) : 0u;
+    uint32_t incl = len;
+#pragma unroll
+    for (uint32_t off = 1; off < 64; off <<= 1) {
+      const uint32_t y = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += y;
+    }
+    uint32_t *sw = s_wave[round & 1u];  // two sets: a wave may be a round ahead of the others
+    if (lane == 63u) sw[wave] = incl;
+    __syncthreads();
+    const uint32_t w0 = sw[0], w1 = sw[1], w2 = sw[2], w3 = sw[3];
+    const uint32_t before = (wave > 0 ? w0 : 0u) + (wave > 1 ? w1 : 0u) + (wave > 2 ? w2 : 0u);
+    const unsigned long long pos = at + before + incl - len;
+    at += (unsigned long long)w0 + w1 + w2 + w3;
+    if (!have) continue;
+    if (pos + len > size) {
+      wrong = 1;
+    } else if (d == 0u) {
+      if (input[pos] != (uint8_t)l) wrong = 1;
+    } else if (d > W || d > pos) {
+      wrong = 1;
+    } else {  // the input is known whole, so an overlapping copy is just two ranges that must be equal (buffer padded by 64)
+      const uint8_t *p = input + pos, *q = p - d;
+      uint32_t k = 0;
+      for (; k + 8 <= len; k += 8) {
+        unsigned long long x, y;
+        __builtin_memcpy(&x, p + k, 8);
+        __builtin_memcpy(&y, q + k, 8);
+        if (x != y) wrong = 1;
+      }
+      if (k < len) {
+        unsigned long long x, y;
+        __builtin_memcpy(&x, p + k, 8);
+        __builtin_memcpy(&y, q + k, 8);
+        if (((x ^ y) << (8u * (8u - (len - k)))) != 0ull) wrong = 1;
+      }
+    }
+  }
+  if (tid == 0 && at != (unsigned long long)blocks[b].input_begin + blocks[b].input_bytes) wrong = 1;
+  if (wrong) atomicAdd(bad, 1u);
+}
+
 // Encode: a thread owns a contiguous run of its block's symbols; the runs' bit offsets come from a scan of their
 // lengths.  Words inside a run are the thread's own (plain stores); the first and the last word of a run may be
 // shared with the neighbours and are OR-ed into the zero-filled body.
@@ -653,6 +718,7 @@ struct LzContext {
   struct CopyLane *lane = nullptr;     // the device's copy stream and events, while this context holds them
   uint64_t part_end[kBodyParts] = {};  // byte offsets in the body
   int n_parts = 0;
+  uint32_t validated_blocks = 0;       // blocks lz_validate_kernel has been enqueued for since the body was zeroed
 };
 
 // One copy stream and its events per device, made once (creating and destroying them per call cost what the overlap
@@ -938,7 +1004,7 @@ struct StatArrays {
   uint16_t *lfreq, *dfreq;
   uint32_t *bytes, *last;
 };
-bool stat_arrays(LzContext *c, uint32_t num_blocks, StatArrays *a) {
+static bool stat_arrays(LzContext *c, uint32_t num_blocks, StatArrays *a) {
   size_t off = 0;
   auto carve = [&](size_t bytes) {
     const size_t at = off;
@@ -968,6 +1034,21 @@ int spz_amd_zlib_block_stats(void *ctx, const spz_amd_deflate_static *tables, ui
   StatArrays a;
   if (!stat_arrays(c, num_blocks, &a)) return SPZ_AMD_ERR_CAPACITY;
   hipStream_t st = nullptr;
+  // Fault injection for the tests of the symbol check (tests/test_gpu_gzip_device.py): SPZ_AMD_TEST_CORRUPT_SYMBOL=<index>
+  // changes that symbol BEFORE the statistics, so trees, plan and bit counts are all consistent with the wrong symbol
+  // and only a check against the input can notice.  A literal becomes another literal; a match moves one byte nearer
+  // (or farther, from distance 1).
+  if (const char *e = std::getenv("SPZ_AMD_TEST_CORRUPT_SYMBOL")) {
+    const uint64_t at = std::strtoull(e, nullptr, 10) % (c->num_symbols ? c->num_symbols : 1);
+    uint16_t d = 0;
+    uint8_t l = 0;
+    SPZ_HIP_TRY(hipMemcpy(&d, c->dense_dist + at, sizeof(d), hipMemcpyDeviceToHost));
+    SPZ_HIP_TRY(hipMemcpy(&l, c->dense_lc + at, sizeof(l), hipMemcpyDeviceToHost));
+    if (d == 0) l ^= 1u;
+    else d = d > 1 ? d - 1 : d + 1;
+    SPZ_HIP_TRY(hipMemcpy(c->dense_dist + at, &d, sizeof(d), hipMemcpyHostToDevice));
+    SPZ_HIP_TRY(hipMemcpy(c->dense_lc + at, &l, sizeof(l), hipMemcpyHostToDevice));
+  }
   SPZ_HIP_TRY(hipMemcpyAsync(a.tables, tables, sizeof(*tables), hipMemcpyHostToDevice, st));
   hipLaunchKernelGGL(lz_block_stats_kernel, dim3(num_blocks), dim3(256), 0, st, c->dense_dist, c->dense_lc,
                      (unsigned long long)c->num_symbols, block_symbols, a.tables, a.lfreq, a.dfreq, a.bytes, a.last);
@@ -993,10 +1074,11 @@ struct EncodeArrays {
   unsigned long long *bits;
   BlockTrees *trees;
   spz_amd_deflate_plan *plan;
+  uint32_t *invalid;       // lz_validate_kernel's count of blocks' threads that found a symbol wrong
   uint32_t *header;
   size_t header_capacity;  // words
 };
-bool encode_arrays(LzContext *c, uint32_t total_blocks, EncodeArrays *a) {
+static bool encode_arrays(LzContext *c, uint32_t total_blocks, EncodeArrays *a) {
   size_t off = 0;
   auto carve = [&](size_t bytes) {
     const size_t at = off;
@@ -1009,6 +1091,7 @@ bool encode_arrays(LzContext *c, uint32_t total_blocks, EncodeArrays *a) {
   a->bits = reinterpret_cast<unsigned long long *>(carve((size_t)total_blocks * sizeof(unsigned long long)));
   a->trees = reinterpret_cast<BlockTrees *>(carve((size_t)total_blocks * sizeof(BlockTrees)));
   a->plan = reinterpret_cast<spz_amd_deflate_plan *>(carve((size_t)total_blocks * sizeof(spz_amd_deflate_plan)));
+  a->invalid = reinterpret_cast<uint32_t *>(carve(sizeof(uint32_t)));
   if (off + 4096 > c->scratch_b_bytes) return false;
   a->header = reinterpret_cast<uint32_t *>(c->scratch_b + off);
   a->header_capacity = (c->scratch_b_bytes - off) / sizeof(uint32_t);
@@ -1045,8 +1128,10 @@ int spz_amd_zlib_encode_group(void *ctx, const spz_amd_deflate_static *tables, u
   uint32_t *d_body = reinterpret_cast<uint32_t *>(c->scratch_a);
   hipStream_t st = nullptr;
   if (first_block == 0) {
+    c->validated_blocks = 0;
     SPZ_HIP_TRY(hipMemsetAsync(d_body, 0, body_words * 4, st));
     SPZ_HIP_TRY(hipMemcpyAsync(a.tables, tables, sizeof(*tables), hipMemcpyHostToDevice, st));
+    SPZ_HIP_TRY(hipMemsetAsync(a.invalid, 0, sizeof(uint32_t), st));
   }
   SPZ_HIP_TRY(hipMemcpyAsync(a.blocks + first_block, h_blocks, (size_t)group_blocks * sizeof(spz_amd_deflate_block), hipMemcpyHostToDevice, st));
   SPZ_HIP_TRY(hipMemcpyAsync(a.codes + first_block, h_codes, (size_t)group_blocks * sizeof(spz_amd_deflate_codes), hipMemcpyHostToDevice, st));
@@ -1057,6 +1142,10 @@ int spz_amd_zlib_encode_group(void *ctx, const spz_amd_deflate_static *tables, u
                      (unsigned long long)c->num_symbols, block_symbols, c->data, a.tables, a.blocks, a.codes, a.header, d_body, a.bits,
                      first_block);
   SPZ_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(lz_validate_kernel, dim3(group_blocks), dim3(256), 0, st, c->dense_dist, c->dense_lc, (unsigned long long)c->num_symbols,
+                     block_symbols, c->data, (unsigned long long)c->size, a.blocks, first_block, a.invalid);
+  SPZ_HIP_TRY(hipGetLastError());
+  c->validated_blocks += group_blocks;
   return SPZ_AMD_OK;  // not waited for: the next group's trees can be built meanwhile
 }
 
@@ -1073,6 +1162,16 @@ int spz_amd_zlib_encode_finish_ex(void *ctx, uint32_t total_blocks, uint64_t bod
   hipStream_t st = nullptr;
   static const bool timing = std::getenv("SPZ_AMD_LZ_TIMING") != nullptr;
   const auto t0 = std::chrono::steady_clock::now();
+  // lz_validate_kernel's verdict on the symbols the body was coded from: a body is handed out only when every block
+  // was checked and none had a symbol that does not reproduce the input
+  uint32_t invalid = 1;
+  auto symbols_valid = [&]() {
+    if (c->validated_blocks != total_blocks || invalid != 0) {
+      if (timing) std::fprintf(stderr, "[lz77] symbol check FAILED: %u of %u blocks checked, %u findings\n", c->validated_blocks, total_blocks, invalid);
+      return (int)SPZ_AMD_ERR_VERIFY;
+    }
+    return (int)SPZ_AMD_OK;
+  };
   if (c->n_parts > 0) {  // after encode_planned: every part as soon as its launch is done
     uint64_t from = 0;
     for (int g = 0; g < c->n_parts; ++g) {
@@ -1092,11 +1191,12 @@ int spz_amd_zlib_encode_finish_ex(void *ctx, uint32_t total_blocks, uint64_t bod
                                    sizeof(uint32_t), total_blocks, hipMemcpyDeviceToHost, c->lane->stream));
     }
     SPZ_HIP_TRY(hipStreamSynchronize(c->lane->stream));
+    SPZ_HIP_TRY(hipMemcpyAsync(&invalid, a.invalid, sizeof(invalid), hipMemcpyDeviceToHost, st));  // behind lz_validate_kernel
     SPZ_HIP_TRY(hipStreamSynchronize(st));
     if (timing) {
       std::fprintf(stderr, "[lz77] encode + download %.4f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     }
-    return SPZ_AMD_OK;
+    return symbols_valid();
   }
   if (timing) {
     (void)hipStreamSynchronize(st);
@@ -1108,11 +1208,12 @@ int spz_amd_zlib_encode_finish_ex(void *ctx, uint32_t total_blocks, uint64_t bod
     SPZ_HIP_TRY(hipMemcpy2DAsync(h_header_bits, sizeof(uint32_t), &a.blocks[0].header_bits, sizeof(spz_amd_deflate_block),
                                  sizeof(uint32_t), total_blocks, hipMemcpyDeviceToHost, st));
   }
+  SPZ_HIP_TRY(hipMemcpyAsync(&invalid, a.invalid, sizeof(invalid), hipMemcpyDeviceToHost, st));
   SPZ_HIP_TRY(hipStreamSynchronize(st));
   if (timing) {
     std::fprintf(stderr, "[lz77] + download %.4f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   }
-  return SPZ_AMD_OK;
+  return symbols_valid();
 }
 
 int spz_amd_zlib_encode_finish(void *ctx, uint32_t total_blocks, uint64_t body_bytes, uint8_t *h_body, uint64_t *h_symbol_bits) {
@@ -1170,6 +1271,7 @@ int spz_amd_zlib_encode_planned(void *ctx, const spz_amd_deflate_static *tables,
   SPZ_HIP_TRY(hipMemsetAsync(d_body, 0, body_words * 4, st));
   SPZ_HIP_TRY(hipMemcpyAsync(a.tables, tables, sizeof(*tables), hipMemcpyHostToDevice, st));
   SPZ_HIP_TRY(hipMemcpyAsync(a.blocks, h_blocks, (size_t)num_blocks * sizeof(spz_amd_deflate_block), hipMemcpyHostToDevice, st));
+  SPZ_HIP_TRY(hipMemsetAsync(a.invalid, 0, sizeof(uint32_t), st));
   hipLaunchKernelGGL(lz_header_kernel, dim3((num_blocks + 63) / 64), dim3(64), 0, st, a.blocks, a.codes, a.trees, a.header, num_blocks);
   SPZ_HIP_TRY(hipGetLastError());
   // in a few launches, so that the body's first parts are on their way to the host while the later ones are packed
@@ -1188,7 +1290,24 @@ int spz_amd_zlib_encode_planned(void *ctx, const spz_amd_deflate_static *tables,
     c->part_end[g] = b1 < num_blocks ? (h_blocks[b1].bit_start >> 5) * 4 : body_bytes;
     c->n_parts = g + 1;
   }
+  // behind the bit packing, beside the copies of the body's parts: do the symbols reproduce the input?
+  hipLaunchKernelGGL(lz_validate_kernel, dim3(num_blocks), dim3(256), 0, st, c->dense_dist, c->dense_lc, (unsigned long long)c->num_symbols,
+                     block_symbols, c->data, (unsigned long long)c->size, a.blocks, 0u, a.invalid);
+  SPZ_HIP_TRY(hipGetLastError());
+  c->validated_blocks = num_blocks;
   return SPZ_AMD_OK;  // not waited for: the caller maps its output buffer meanwhile, then spz_amd_zlib_encode_finish_ex
+}
+
+int spz_amd_zlib_verify_member(void *ctx, uint64_t body_bytes) {
+  LzContext *c = static_cast<LzContext *>(ctx);
+  if (c == nullptr || body_bytes == 0 || body_bytes > c->scratch_a_bytes) return SPZ_AMD_ERR_INVALID_ARG;
+  void *inf = nullptr;
+  uint64_t out_bytes = 0;
+  int rc = spz_amd_inflate_open_device(reinterpret_cast<const uint8_t *>(c->scratch_a), body_bytes, c->device, &inf, &out_bytes);
+  if (rc != SPZ_AMD_OK) return rc;  // SPZ_AMD_ERR_UNSUPPORTED: the device reader declines this body; the caller checks on the host
+  rc = spz_amd_inflate_equals_device(inf, c->data, c->size);
+  spz_amd_inflate_close(inf);
+  return rc;
 }
 
 int spz_amd_zlib_encode_blocks(void *ctx, const spz_amd_deflate_static *tables, uint32_t block_symbols, uint32_t num_blocks,

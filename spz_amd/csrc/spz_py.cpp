@@ -217,14 +217,22 @@ PYBIND11_MODULE(spz, m) {
 
   m.def("load_spz",
         [](const std::string &filename, const spz::UnpackOptions &o) {
-          spz::GaussianCloud g = spz::loadSpz(filename, o);
+          spz::GaussianCloud g;
+          {
+            py::gil_scoped_release release;  // other Python threads run meanwhile (the library is re-entrant)
+            g = spz::loadSpz(filename, o);
+          }
           if (g.numPoints == 0) raiseIfDeviceUnusable();
           return g;
         },
         py::arg("filename"), py::arg("options") = spz::UnpackOptions(), "Load a *.spz* file and return a GaussianCloud.");
   m.def("save_spz",
         [](const spz::GaussianCloud &g, const spz::PackOptions &o, const std::string &filename) {
-          const bool ok = spz::saveSpz(g, o, filename);
+          bool ok;
+          {
+            py::gil_scoped_release release;
+            ok = spz::saveSpz(g, o, filename);
+          }
           if (!ok) raiseIfDeviceUnusable();
           return ok;
         },
@@ -233,9 +241,12 @@ PYBIND11_MODULE(spz, m) {
   m.def("_compress_gzipped", [](const py::bytes &data) {
     const BytesView in = viewOf(data);
     std::vector<uint8_t> out;
-    if (!spz::compressGzipped(in.p, in.n, &out)) {
-      throw std::runtime_error("compressGzipped failed");
+    bool ok;
+    {
+      py::gil_scoped_release release;
+      ok = spz::compressGzipped(in.p, in.n, &out);
     }
+    if (!ok) throw std::runtime_error("compressGzipped failed");
     return py::bytes(reinterpret_cast<const char *>(out.data()), out.size());
   }, "gzip wrapper of saveSpz (host zlib, parameters of load-spz.cc:190).");
   m.def("_compress_gzipped_parallel", [](const py::bytes &data, int threads) {
@@ -280,6 +291,8 @@ PYBIND11_MODULE(spz, m) {
         "gzip members inflated on the device so far.");
   m.def("_device_gzip_parse_count", []() { return spz::deviceGzipParseCount(); },
         "gzip members written so far with their LZ77 parse done on the device.");
+  m.def("_device_gzip_reject_count", []() { return spz::deviceGzipRejectCount(); },
+        "members of the device gzip writer discarded because one of its self-checks failed.");
   m.def("_effective_cpu_count", []() { return spz::effectiveCpuCount(); },
         "CPUs the worker pools of the container stage size themselves by (online, affinity mask, cgroup quota).");
   m.def("_parallel_inflate_count", []() { return spz::pinflate::successCount(); },
@@ -287,12 +300,22 @@ PYBIND11_MODULE(spz, m) {
   m.def("_decompress_gzipped", [](const py::bytes &data) -> py::object {
     const BytesView in = viewOf(data);
     std::vector<uint8_t> out;
-    if (!spz::decompressGzipped(in.p, in.n, &out)) return py::none();
+    bool ok;
+    {
+      py::gil_scoped_release release;
+      ok = spz::decompressGzipped(in.p, in.n, &out);
+    }
+    if (!ok) return py::none();
     return py::bytes(reinterpret_cast<const char *>(out.data()), out.size());
   }, "Inverse of _compress_gzipped; None on failure.");
   m.def("_save_spz_bytes", [](const spz::GaussianCloud &g, const spz::PackOptions &o) -> py::object {
     std::vector<uint8_t> out;
-    if (!spz::saveSpz(g, o, &out)) {
+    bool ok;
+    {
+      py::gil_scoped_release release;
+      ok = spz::saveSpz(g, o, &out);
+    }
+    if (!ok) {
       raiseIfDeviceUnusable();
       return py::none();
     }
@@ -300,7 +323,11 @@ PYBIND11_MODULE(spz, m) {
   }, py::arg("gaussians"), py::arg("options"), "saveSpz(cloud, options, &vector) -> .spz bytes in memory.");
   m.def("_load_spz_bytes", [](const py::bytes &data, const spz::UnpackOptions &o) {
     const BytesView in = viewOf(data);
-    spz::GaussianCloud g = spz::loadSpz(in.p, static_cast<int32_t>(in.n), o);
+    spz::GaussianCloud g;
+    {
+      py::gil_scoped_release release;
+      g = spz::loadSpz(in.p, static_cast<int32_t>(in.n), o);
+    }
     if (g.numPoints == 0) raiseIfDeviceUnusable();
     return g;
   }, py::arg("data"), py::arg("options") = spz::UnpackOptions(), "loadSpz(ptr, size, options) from .spz bytes.");

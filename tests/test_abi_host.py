@@ -33,6 +33,26 @@ def test_library_exports_every_declared_symbol(lib):
     assert lib.spz_amd_abi_version() == 1
 
 
+def test_library_exports_nothing_but_the_declared_functions():
+    """A drop-in library must not put unprefixed C names into a process: every function the dynamic symbol table
+    defines is one include/spz_amd.h declares (C++ symbols are mangled under namespaces and cannot collide)."""
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "spz_amd", "lib", "libspz_amd.so")],
+                         check=True, capture_output=True, text=True).stdout
+    declared = set(declared_functions())
+    stray = []
+    for line in out.splitlines():
+        parts = line.split()
+        if len(parts) != 3 or parts[1] not in "TtWw":
+            continue
+        name = parts[2]
+        if name.startswith("_Z") or name in ("_init", "_fini"):
+            continue
+        if name not in declared:
+            stray.append(name)
+    assert not stray, f"libspz_amd.so exports undeclared C symbols: {stray}"
+
+
 def test_host_library_and_python_module_load():
     host = C.CDLL(os.path.join(ROOT, "spz_amd", "lib", "libspz_host.so"))
     assert host is not None
