@@ -115,7 +115,10 @@ void workspace_free_all();                                                      
 // progress).  Returned by spz_amd_release_device_memory() like the host path's workspace.  The current device is
 // `device`.  A block of at least `bytes`; when all cached ones are in use, a plain allocation that scratch_release frees.
 int scratch_acquire(int device, size_t bytes, void **block);
-void scratch_release(int device, void *block);
+void scratch_release(int device, void *block);   // idle blocks beyond SPZ_AMD_SCRATCH_KEEP_MIB (default 32 GiB) are freed here
+// Device memory a new block can count on: what the runtime reports free plus the idle cached blocks (scratch_acquire
+// gives those up first), capped by SPZ_AMD_DEVICE_MEM_LIMIT_MIB when set.  The current device is `device`.
+int device_free_bytes(int device, size_t *free_bytes);
 
 class Workspace {
  public:
@@ -178,16 +181,30 @@ inline hipError_t upload_adaptive(void *d_dst, const void *h_src, size_t bytes, 
     }
   }
   if (left == 0) return hipSuccess;
+  // staging buffers and events belong to the device they were made on (an event of another device cannot be recorded
+  // on this one's stream): one set per device, made on first use
   static std::mutex mu;
-  static void *pinned[2] = {nullptr, nullptr};
-  static hipEvent_t done[2] = {nullptr, nullptr};
+  static void *pinned_all[kMaxDevices][2] = {};
+  static hipEvent_t done_all[kMaxDevices][2] = {};
+  int dev = 0;
+  e = hipGetDevice(&dev);
+  if (e != hipSuccess || dev < 0 || dev >= kMaxDevices) {
+    e = hipMemcpyAsync(dst, src, left, hipMemcpyHostToDevice, st);
+    return e != hipSuccess ? e : hipStreamSynchronize(st);
+  }
   std::lock_guard<std::mutex> lock(mu);
+  void **pinned = pinned_all[dev];
+  hipEvent_t *done = done_all[dev];
   for (int i = 0; i < 2; ++i) {
     if (pinned[i] == nullptr) {
       e = hipHostMalloc(&pinned[i], kStep, hipHostMallocDefault);
-      if (e == hipSuccess) e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
-      if (e != hipSuccess) {  // no pinned memory to be had: the runtime's own way
+      if (e == hipSuccess) {
+        e = hipEventCreateWithFlags(&done[i], hipEventDisableTiming);
+        if (e != hipSuccess) (void)hipHostFree(pinned[i]);
+      }
+      if (e != hipSuccess) {  // no pinned memory (or event) to be had: the runtime's own way
         pinned[i] = nullptr;
+        done[i] = nullptr;
         e = hipMemcpyAsync(dst, src, left, hipMemcpyHostToDevice, st);
         return e != hipSuccess ? e : hipStreamSynchronize(st);
       }

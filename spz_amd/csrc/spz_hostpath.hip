@@ -83,32 +83,75 @@ ScratchSlot g_scratch[kMaxDevices][kScratchSlots];
 std::mutex g_scratch_mutex;
 }  // namespace
 
+// SPZ_AMD_SCRATCH_KEEP_MIB: how much idle scratch a device may keep between calls (default 32768 = 32 GiB: the blocks of
+// one 10 M-point SH3 saveSpz + loadSpz are 15 + 8 GB; 0 = keep nothing).  Read at every release.
+static size_t scratch_keep_bytes() {
+  const char *e = std::getenv("SPZ_AMD_SCRATCH_KEEP_MIB");
+  const unsigned long long mib = e ? std::strtoull(e, nullptr, 10) : 32768ull;
+  return (size_t)mib << 20;
+}
+
+// SPZ_AMD_DEVICE_MEM_LIMIT_MIB: an artificial ceiling on what the container stage believes is free on the device (its
+// decline-to-the-host paths can then be exercised on a 288 GB card); unset: what hipMemGetInfo says.
+int device_free_bytes(int device, size_t *free_bytes) {
+  size_t free_b = 0, total_b = 0;
+  SPZ_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  {  // idle cached blocks are free for the asking: scratch_acquire gives them up before it allocates
+    std::lock_guard<std::mutex> lock(g_scratch_mutex);
+    if (device >= 0 && device < kMaxDevices) {
+      for (int i = 0; i < kScratchSlots; ++i) {
+        if (!g_scratch[device][i].in_use) free_b += g_scratch[device][i].bytes;
+      }
+    }
+  }
+  if (const char *e = std::getenv("SPZ_AMD_DEVICE_MEM_LIMIT_MIB")) {
+    const size_t cap = (size_t)std::strtoull(e, nullptr, 10) << 20;
+    if (cap < free_b) free_b = cap;
+  }
+  *free_bytes = free_b;
+  return SPZ_AMD_OK;
+}
+
 int scratch_acquire(int device, size_t bytes, void **block) {
   *block = nullptr;
   if (device < 0 || device >= kMaxDevices) return SPZ_AMD_ERR_INVALID_ARG;
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
   ScratchSlot *slots = g_scratch[device];
-  int best = -1, idle = -1;
+  int best = -1;
   for (int i = 0; i < kScratchSlots; ++i) {
     if (slots[i].in_use) continue;
     if (slots[i].ptr && slots[i].bytes >= bytes && (best < 0 || slots[i].bytes < slots[best].bytes)) best = i;
-    if (idle < 0 || slots[i].bytes < slots[idle].bytes) idle = i;   // the smallest idle one is the one to replace
   }
   if (best >= 0) {
     slots[best].in_use = true;
     *block = slots[best].ptr;
     return SPZ_AMD_OK;
   }
-  void *p = nullptr;
-  if (idle >= 0) {
-    if (slots[idle].ptr) (void)hipFree(slots[idle].ptr);
+  // nothing cached is large enough: idle blocks go (smallest first) until the new one fits beside what is left
+  int slot = -1;
+  for (;;) {
+    size_t free_b = 0, total_b = 0;
+    const bool known = hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    int idle = -1, empty = -1;
+    for (int i = 0; i < kScratchSlots; ++i) {
+      if (slots[i].in_use) continue;
+      if (slots[i].ptr == nullptr) empty = i;
+      else if (idle < 0 || slots[i].bytes < slots[idle].bytes) idle = i;
+    }
+    if (empty >= 0 && (idle < 0 || (known && free_b >= bytes + (size_t(256) << 20)))) {
+      slot = empty;
+      break;
+    }
+    if (idle < 0) break;  // every slot busy: not cached
+    (void)hipFree(slots[idle].ptr);
     slots[idle] = ScratchSlot();
-    SPZ_HIP_TRY(hipMalloc(&p, bytes));
-    slots[idle].ptr = p;
-    slots[idle].bytes = bytes;
-    slots[idle].in_use = true;
-  } else {
-    SPZ_HIP_TRY(hipMalloc(&p, bytes));  // every slot busy: not cached
+  }
+  void *p = nullptr;
+  SPZ_HIP_TRY(hipMalloc(&p, bytes));
+  if (slot >= 0) {
+    slots[slot].ptr = p;
+    slots[slot].bytes = bytes;
+    slots[slot].in_use = true;
   }
   *block = p;
   return SPZ_AMD_OK;
@@ -117,13 +160,32 @@ int scratch_acquire(int device, size_t bytes, void **block) {
 void scratch_release(int device, void *block) {
   if (block == nullptr || device < 0 || device >= kMaxDevices) return;
   std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  ScratchSlot *slots = g_scratch[device];
+  bool cached = false;
   for (int i = 0; i < kScratchSlots; ++i) {
-    if (g_scratch[device][i].ptr == block) {
-      g_scratch[device][i].in_use = false;
-      return;
+    if (slots[i].ptr == block) {
+      slots[i].in_use = false;
+      cached = true;
     }
   }
-  (void)hipFree(block);
+  if (!cached) {
+    (void)hipFree(block);
+    return;
+  }
+  // what stays idle between calls is bounded: the largest idle blocks go first until the rest is within the budget
+  const size_t keep = scratch_keep_bytes();
+  for (;;) {
+    size_t idle_total = 0;
+    int largest = -1;
+    for (int i = 0; i < kScratchSlots; ++i) {
+      if (slots[i].in_use || slots[i].ptr == nullptr) continue;
+      idle_total += slots[i].bytes;
+      if (largest < 0 || slots[i].bytes > slots[largest].bytes) largest = i;
+    }
+    if (largest < 0 || idle_total <= keep) break;
+    (void)hipFree(slots[largest].ptr);
+    slots[largest] = ScratchSlot();
+  }
 }
 
 void kept_stream_free_idle();

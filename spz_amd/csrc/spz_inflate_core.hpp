@@ -357,8 +357,11 @@ enum Outcome { FAILED, LINKED, FINAL };
 // Decodes whole blocks from `start` until a block would start at `stop` (LINKED) or the final block ends
 // (FINAL, *end = first bit after it).
 // `lit`, `dist`: the caller's table memory (14 KiB + 3 KiB).
-template <class In, class HL, class HD, class Sink>
-SPZ_INF_HD Outcome decodeBlocks(const In &in, uint64_t start, uint64_t stop, Sink &sink, uint64_t *end, HL *lit, HD *dist) {
+// `huff`: the decoder of one Huffman-coded block's symbols, (in, &pos, lit, dist, sink, stop) -> bool: decodeHuffBlock
+// above, or the device's wave-wide form of it (spz_inflate_dev.hip).
+template <class In, class HL, class HD, class Sink, class HuffFn>
+SPZ_INF_HD Outcome decodeBlocksWith(const In &in, uint64_t start, uint64_t stop, Sink &sink, uint64_t *end, HL *lit, HD *dist,
+                                    HuffFn huff) {
   uint64_t pos = start;
   for (;;) {
     if (pos == stop) return LINKED;
@@ -381,10 +384,10 @@ SPZ_INF_HD Outcome decodeBlocks(const In &in, uint64_t start, uint64_t stop, Sin
       pos += 8 * static_cast<uint64_t>(len);
     } else if (type == 1) {
       buildStatic(lit, dist);
-      if (!decodeHuffBlock(in, &pos, *lit, *dist, sink, stop)) return FAILED;
+      if (!huff(in, &pos, *lit, *dist, sink, stop)) return FAILED;
     } else if (type == 2) {
       if (!readDynamic(in, &pos, lit, dist)) return FAILED;
-      if (!decodeHuffBlock(in, &pos, *lit, *dist, sink, stop)) return FAILED;
+      if (!huff(in, &pos, *lit, *dist, sink, stop)) return FAILED;
     } else {
       return FAILED;
     }
@@ -393,6 +396,14 @@ SPZ_INF_HD Outcome decodeBlocks(const In &in, uint64_t start, uint64_t stop, Sin
       return FINAL;
     }
   }
+}
+
+template <class In, class HL, class HD, class Sink>
+SPZ_INF_HD Outcome decodeBlocks(const In &in, uint64_t start, uint64_t stop, Sink &sink, uint64_t *end, HL *lit, HD *dist) {
+  return decodeBlocksWith(in, start, stop, sink, end, lit, dist,
+                          [](const In &i, uint64_t *at, const HL &L, const HD &D, Sink &s, uint64_t limit) {
+                            return decodeHuffBlock(i, at, L, D, s, limit);
+                          });
 }
 
 // The cheap part of the block-start test at bit position p: BFINAL = 0, BTYPE = 2, code counts in range and a

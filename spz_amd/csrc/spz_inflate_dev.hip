@@ -11,8 +11,8 @@
 //                       from its block start to the next chunk's — they must link up bit-exactly — into 16-bit
 //                       symbols: a byte, or 256 + k = "byte k of the 32 KiB before this chunk", which the chunk
 //                       does not have.
-//   inf_window_kernel   one workgroup walks the chunks in order and resolves each chunk's final 32 KiB against its
-//                       predecessor's (kept in LDS): the only serial step.
+//   inf_window_*        every chunk's final 32 KiB, first symbolically (gather), then every reference followed through the
+//                       predecessors' windows to the byte it stands for (resolve: parallel over all entries).
 //   inf_place_kernel    symbols -> bytes at their final offsets, references resolved from the predecessor's window.
 //   inf_crc_kernel      CRC-32 of 256 KiB pieces, a wave each (the caller folds them with crc32_combine and compares with the
 //                       member's trailer: the result can only be right or refused).
@@ -191,6 +191,24 @@ struct WaveBits {
     if (s == 0) return reg_lo;
     return s < 64 ? (reg_lo >> s) | (reg_hi << (64u - s)) : reg_hi >> (s - 64u);  // >= 56 valid bits
   }
+  // 64 valid bits from bit position at + lane, a different one in every lane (`at` is the wave's): the lanes of a round
+  // read two or three neighbouring dwords of the window between them (broadcast reads)
+  __device__ __forceinline__ uint64_t lane_peek(uint64_t at) const {
+    const uint64_t b0 = (at >> 5) << 2;
+    if (b0 < win_lo || b0 + 32 > win_lo + kWinBytes) {   // the round's last lane reads dwords up to b0 + 8 + 12
+      win_lo = b0 & ~15ull;
+      const uint4 *src = reinterpret_cast<const uint4 *>(p + win_lo);
+      uint4 *dst = reinterpret_cast<uint4 *>(win);
+      for (uint32_t i = lane; i < kWinBytes / 16; i += 64) dst[i] = src[i];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    const uint64_t mine = at + lane;
+    const uint32_t i = (uint32_t)((((mine >> 5) << 2) - win_lo) >> 2), sh = (uint32_t)(mine & 31u);
+    const uint64_t lo = (uint64_t)win[i] | ((uint64_t)win[i + 1] << 32);
+    return sh ? (lo >> sh) | ((uint64_t)win[i + 2] << (64u - sh)) : lo;
+  }
 };
 
 // Symbols go straight to the chunk's region in HBM: literals by lane 0, matches by as many lanes as they are long
@@ -213,20 +231,24 @@ struct WaveSymbolSink {
     ++n;
     return true;
   }
+  // the `len` symbols from `at` on, copied from `dist` back
+  __device__ __forceinline__ void copy_at(uint64_t at, uint32_t len, uint32_t dist) {
+    // byte at + i is byte at + i - dist, which for an overlapping copy is byte at - dist + (i mod dist): never one of this
+    // match's own; a source before the chunk's first byte is byte W + (index) of the predecessor's final window
+    for (uint32_t base = 0; base < len; base += 64) {
+      const uint32_t i = base + lane;
+      if (i < len) {
+        const long long src = (long long)at - (long long)dist + (long long)(dist < len ? i % dist : i);
+        sym[at + i] = src >= 0 ? sym[src] : (uint16_t)(256 + W + src);
+      }
+    }
+  }
   __device__ __forceinline__ bool match(uint32_t len, uint32_t dist) {
     if (n + len > cap) {
       overflow = true;
       return false;
     }
-    // byte n + i is byte n + i - dist, which for an overlapping copy is byte n - dist + (i mod dist): never one of this
-    // match's own; a source before the chunk's first byte is byte W + (index) of the predecessor's final window
-    for (uint32_t base = 0; base < len; base += 64) {
-      const uint32_t i = base + lane;
-      if (i < len) {
-        const long long src = (long long)n - (long long)dist + (long long)(dist < len ? i % dist : i);
-        sym[n + i] = src >= 0 ? sym[src] : (uint16_t)(256 + W + src);
-      }
-    }
+    copy_at(n, len, dist);
     n += len;
     return true;
   }
@@ -262,6 +284,138 @@ struct WaveSymbolSink {
   }
 };
 
+// ---- the symbols of one Huffman-coded block, 64 bit positions at a time ---------------------------------------------
+// decodeHuffBlock (spz_inflate_core.hpp) run by a wave in lockstep spends ~85 instructions per symbol with 63 lanes
+// idle.  Here a round covers the 64 bit positions from `pos`: lane l decodes the symbol that WOULD start at pos + l
+// (fast-table lookups, extra bits, distance code: all per lane), a scalar walk then follows the real chain — position
+// 0 is a symbol start, and each start names the next through its own length — (one readlane per symbol), the output
+// offsets of the real symbols are a scan of their lengths, their literals are stored by their own lanes at once and
+// their matches copied in order by the whole wave.  A code the fast tables do not hold is decoded the old way, by all
+// lanes, when (and only when) the chain reaches it.  Same symbols as decodeHuffBlock by construction: the per-lane
+// arithmetic is that function's, applied at every position instead of one.
+constexpr uint32_t F_LIT = 1u, F_MATCH = 2u, F_EOB = 4u, F_INVALID = 8u, F_MISS = 16u;
+
+template <class HL, class HD>
+__device__ __forceinline__ bool decodeHuffBlockWave(const WaveBits &in, uint64_t *at, const HL &L, const HD &D, WaveSymbolSink &sink,
+                                                    uint64_t limit) {
+  uint64_t pos = *at;
+  const uint32_t lane = in.lane;
+  for (;;) {
+    if (pos >= in.nbits || pos > limit) return false;
+    uint64_t bits = in.lane_peek(pos);
+    const uint32_t e = L.packed[bits & ((1u << HL::fastbits) - 1u)];
+    uint32_t total = e & 15u, flags, outlen = 0, dist = 0, value = e >> 16;  // value: the literal
+    if (e == 0u) {
+      flags = F_MISS;
+    } else if (e & ENT_LITERAL) {
+      flags = F_LIT;
+      outlen = 1;
+    } else if (e & ENT_EOB) {
+      flags = F_EOB;
+    } else if (e & ENT_INVALID) {
+      flags = F_INVALID;
+    } else {
+      bits >>= total;
+      const uint32_t lextra = (e >> 4) & 15u;
+      outlen = (e >> 16) + (uint32_t)(bits & ((1u << lextra) - 1u));
+      bits >>= lextra;
+      const uint32_t d = D.packed[bits & ((1u << HD::fastbits) - 1u)];
+      if (d == 0u) {
+        flags = F_MISS;
+      } else if (d & ENT_INVALID) {
+        flags = F_INVALID;
+      } else {
+        bits >>= d & 15u;
+        const uint32_t dextra = (d >> 4) & 15u;
+        dist = (d >> 16) + (uint32_t)(bits & ((1u << dextra) - 1u));
+        total += lextra + (d & 15u) + dextra;  // <= 48
+        flags = F_MATCH;
+      }
+    }
+    uint32_t step = total | (flags << 8);
+    // the chain of real symbol starts
+    uint32_t cur = 0;
+    uint64_t starts = 0;
+    bool eob = false;
+    while (cur < 64u) {
+      uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)step, (int)cur);
+      if (st & (F_MISS << 8)) {  // a long code: all lanes decode the symbol at pos + cur, lane `cur` keeps the result
+        uint64_t b = in.peek(pos + cur);
+        const uint32_t e2 = in.uniform(L.lookup(b));
+        uint32_t t2 = e2 & 15u, f2, o2 = 0, d2 = 0;
+        if (e2 == 0u || (e2 & ENT_INVALID)) {
+          f2 = F_INVALID;
+        } else if (e2 & ENT_LITERAL) {
+          f2 = F_LIT;
+          o2 = 1;
+        } else if (e2 & ENT_EOB) {
+          f2 = F_EOB;
+        } else {
+          b >>= t2;
+          const uint32_t lextra = (e2 >> 4) & 15u;
+          o2 = (e2 >> 16) + (uint32_t)(b & ((1u << lextra) - 1u));
+          b >>= lextra;
+          const uint32_t dd = in.uniform(D.lookup(b));
+          if (dd == 0u || (dd & ENT_INVALID)) {
+            f2 = F_INVALID;
+          } else {
+            b >>= dd & 15u;
+            const uint32_t dextra = (dd >> 4) & 15u;
+            d2 = (dd >> 16) + (uint32_t)(b & ((1u << dextra) - 1u));
+            t2 += lextra + (dd & 15u) + dextra;
+            f2 = F_MATCH;
+          }
+        }
+        st = t2 | (f2 << 8);
+        if (lane == cur) {
+          flags = f2;
+          outlen = o2;
+          dist = d2;
+          value = e2 >> 16;
+        }
+      }
+      if (st & (F_INVALID << 8)) return false;
+      starts |= 1ull << cur;
+      cur += st & 255u;
+      if (st & (F_EOB << 8)) {
+        eob = true;
+        break;
+      }
+    }
+    const bool mine = (starts >> lane) & 1ull;
+    const uint32_t ol = mine ? outlen : 0u;  // the end-of-block symbol produces nothing
+    uint32_t incl = ol;
+#pragma unroll
+    for (uint32_t off = 1; off < 64u; off <<= 1) {
+      const uint32_t y = __shfl_up(incl, off, 64);
+      if (lane >= off) incl += y;
+    }
+    const uint32_t produced = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    if (sink.n + produced > sink.cap) {
+      sink.overflow = true;
+      return false;
+    }
+    const uint32_t before = incl - ol;
+    if (mine && (flags & F_LIT)) sink.sym[sink.n + before] = (uint16_t)value;
+    uint64_t matches = __ballot(mine && (flags & F_MATCH));
+    while (matches) {
+      const int l = __builtin_ctzll(matches);
+      matches &= matches - 1ull;
+      const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)outlen, l);
+      const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)dist, l);
+      const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)before, l);
+      sink.copy_at(sink.n + off, len, dst);
+    }
+    sink.n += produced;
+    pos += cur;
+    if (eob) {
+      if (pos > in.nbits) return false;
+      *at = pos;
+      return true;
+    }
+  }
+}
+
 __global__ __launch_bounds__(64, 6) void inf_decode_kernel(const uint8_t *__restrict__ d, uint64_t nbytes,
                                                            const ChunkJob *__restrict__ jobs, const uint32_t *__restrict__ run,
                                                            uint16_t *symbols, ChunkResult *__restrict__ results) {
@@ -272,7 +426,10 @@ __global__ __launch_bounds__(64, 6) void inf_decode_kernel(const uint8_t *__rest
   const WaveBits in = {d, 8ull * nbytes, (size_t)nbytes, s_win, threadIdx.x, ~0ull, 0ull, 0ull, ~0ull};
   WaveSymbolSink sink = {symbols + job.region, job.capacity, job.start_n, threadIdx.x, false, job.start_n};
   uint64_t end = 0;
-  const Outcome r = decodeBlocks(in, job.from, job.to, sink, &end, &tb.lit, &tb.dist);
+  const Outcome r = decodeBlocksWith(in, job.from, job.to, sink, &end, &tb.lit, &tb.dist,
+                                     [](const WaveBits &i, uint64_t *at, const DevLit &L, const DevDist &D, WaveSymbolSink &s, uint64_t limit) {
+                                       return decodeHuffBlockWave(i, at, L, D, s, limit);
+                                     });
   if (threadIdx.x == 0) {
     ChunkResult &o = results[j];
     o.length = sink.n;
@@ -288,51 +445,54 @@ struct ChunkPlace {
   unsigned long long region, length, offset;  // symbols at `region`, bytes at `offset`
 };
 
-__global__ __launch_bounds__(1024) void inf_window_kernel(const uint16_t *__restrict__ symbols, const ChunkPlace *__restrict__ chunks,
-                                                          uint32_t n_chunks, uint8_t *__restrict__ windows, uint32_t *__restrict__ bad) {
-  __shared__ uint8_t win[2][W];
-  const uint32_t tid = threadIdx.x;
-  uint32_t cur = 0, broken = 0;
-  for (uint32_t c = 0; c < n_chunks; ++c) {
-    const ChunkPlace ch = chunks[c];
-    const uint16_t *sym = symbols + ch.region;
-    const uint8_t *prev = win[cur ^ 1];
-    uint8_t *mine = win[cur];
-    uint32_t sy[W / 1024];
-#pragma unroll
-    for (uint32_t q = 0; q < W / 1024; ++q) {  // all loads of the step in flight together
-      const long long idx = (long long)ch.length - (long long)W + (tid + q * 1024);
-      sy[q] = idx >= 0 ? (uint32_t)sym[idx] : 0xffffffffu;
-    }
-#pragma unroll
-    for (uint32_t q = 0; q < W / 1024; ++q) {
-      const uint32_t k = tid + q * 1024;
-      const uint32_t s = sy[q];
-      uint32_t b;
-      if (s < 256) {
-        b = s;
-      } else {
-        if (c == 0) broken = 1;  // the first chunk has nothing before it
-        // a reference, or (a chunk shorter than the window) the predecessor's own bytes moving up
-        b = s != 0xffffffffu ? prev[s - 256] : prev[(uint32_t)((long long)ch.length + k)];
-      }
-      mine[k] = (uint8_t)b;
-      windows[(size_t)c * W + k] = (uint8_t)b;
-    }
-    __syncthreads();
-    cur ^= 1;
+// The final window of a chunk, symbolically: entry k is a byte, or 256 + i = "entry i of the predecessor's final window"
+// (a reference its own symbols carry, or — a chunk shorter than the window — the predecessor's bytes moving up).
+__global__ __launch_bounds__(256) void inf_window_gather_kernel(const uint16_t *__restrict__ symbols, const ChunkPlace *__restrict__ chunks,
+                                                                uint16_t *__restrict__ windows) {
+  const uint32_t c = blockIdx.x;
+  const ChunkPlace ch = chunks[c];
+  const uint16_t *sym = symbols + ch.region;
+  for (uint32_t k = threadIdx.x; k < W; k += 256) {
+    const long long idx = (long long)ch.length - (long long)W + k;
+    windows[(size_t)c * W + k] = idx >= 0 ? sym[idx] : (uint16_t)(256u + (uint32_t)((long long)ch.length + k));
   }
-  if (broken) atomicOr(bad, 1u);
+}
+
+// Resolution of the references: R_c[k] = S_c[k] if that is a byte, else R_(c-1)[S_c[k] - 256] — a chain through the
+// predecessors that ends where the byte was produced.  The maps compose associatively and almost every chain is one
+// or two chunks long, so instead of walking the chunks in order (one workgroup, a step per chunk: 21 ms for the 5.5 k
+// chunks of a 650 MB stream) every entry follows its own chain, up to kChainSteps chunks per pass, and writes the byte
+// back in place; an entry read while another thread resolves it is either still the reference or already the byte, both
+// right.  After pass p every chain of up to p * kChainSteps chunks is resolved (the entries it runs through were
+// resolved in the passes before), so input whose bytes are carried through hundreds of chunks (long runs) takes a few
+// passes more; `pending` counts what is left.
+constexpr uint32_t kChainSteps = 32;
+__global__ __launch_bounds__(256) void inf_window_resolve_kernel(uint16_t *__restrict__ windows, uint32_t n_chunks,
+                                                                 uint32_t *__restrict__ pending, uint32_t *__restrict__ bad) {
+  const uint64_t e = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+  uint32_t c = (uint32_t)(e / W);
+  if (c >= n_chunks) return;
+  uint32_t s = windows[e];
+  if (s < 256u) return;
+  uint32_t steps = 0;
+  while (s >= 256u && c > 0u && steps < kChainSteps) {
+    --c;
+    s = windows[(size_t)c * W + (s - 256u)];
+    ++steps;
+  }
+  if (s < 256u) windows[e] = (uint16_t)s;
+  else if (c == 0u) atomicOr(bad, 1u);  // the first chunk has nothing before it
+  else atomicAdd(pending, 1u);
 }
 
 // ---- place ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void inf_place_kernel(const uint16_t *__restrict__ symbols, const ChunkPlace *__restrict__ chunks,
-                                                        const uint8_t *__restrict__ windows, uint8_t *__restrict__ out,
+                                                        const uint16_t *__restrict__ windows, uint8_t *__restrict__ out,
                                                         uint32_t *__restrict__ bad) {
   const uint32_t c = blockIdx.y;
   const ChunkPlace ch = chunks[c];
   const uint16_t *sym = symbols + ch.region;
-  const uint8_t *prev = c ? windows + (size_t)(c - 1) * W : nullptr;
+  const uint16_t *prev = c ? windows + (size_t)(c - 1) * W : nullptr;  // resolved: bytes
   uint8_t *dst = out + ch.offset;
   uint32_t broken = 0;
   for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < ch.length; i += (unsigned long long)gridDim.x * 256) {
@@ -341,6 +501,7 @@ __global__ __launch_bounds__(256) void inf_place_kernel(const uint16_t *__restri
     if (s >= 256) {
       if (prev) b = prev[s - 256];
       else broken = 1;
+      if (b >= 256) broken = 1;  // a window entry the resolution left open
     }
     dst[i] = (uint8_t)b;
   }
@@ -510,11 +671,12 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
   const size_t o_place = carve((size_t)n_chunks * sizeof(ChunkPlace));
   const size_t o_bad = carve(256);
   const size_t o_run = carve((size_t)n_chunks * sizeof(uint32_t));
-  const size_t o_win = carve((size_t)n_chunks * W);
+  const size_t o_win = carve((size_t)n_chunks * W * sizeof(uint16_t));
   const size_t o_sym = carve(sym_capacity * sizeof(uint16_t));
   const size_t total = off;
-  size_t free_b = 0, total_b = 0;
-  SPZ_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  size_t free_b = 0;
+  rc = device_free_bytes(device, &free_b);
+  if (rc != SPZ_AMD_OK) return rc;
   if (total + (size_t)nbytes * kExpand + (size_t(512) << 20) > free_b) return SPZ_AMD_ERR_UNSUPPORTED;
   char *block = nullptr;
   rc = scratch_acquire(device, total, reinterpret_cast<void **>(&block));
@@ -533,7 +695,7 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
   ChunkPlace *d_place = reinterpret_cast<ChunkPlace *>(block + o_place);
   uint32_t *d_bad = reinterpret_cast<uint32_t *>(block + o_bad);
   uint32_t *d_run = reinterpret_cast<uint32_t *>(block + o_run);
-  uint8_t *d_win = reinterpret_cast<uint8_t *>(block + o_win);
+  uint16_t *d_win = reinterpret_cast<uint16_t *>(block + o_win);
   uint16_t *d_sym = reinterpret_cast<uint16_t *>(block + o_sym);
   lap("alloc");
   hipStream_t st = nullptr;
@@ -631,8 +793,22 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
   Free holder2{outblock, device};
   uint8_t *d_out = reinterpret_cast<uint8_t *>(outblock);
   uint32_t *d_crcs = reinterpret_cast<uint32_t *>(outblock + round256(total_out + 64));
-  hipLaunchKernelGGL(inf_window_kernel, dim3(1), dim3(1024), 0, st, d_sym, d_place, n, d_win, d_bad);
+  hipLaunchKernelGGL(inf_window_gather_kernel, dim3(n), dim3(256), 0, st, d_sym, d_place, d_win);
   SPZ_HIP_TRY(hipGetLastError());
+  {
+    uint32_t *d_pending = d_bad + 1;
+    uint32_t pending = 1;
+    const uint32_t resolve_blocks = (uint32_t)(((uint64_t)n * W + 255) / 256);
+    for (uint32_t pass = 0; pass < 64 && pending != 0; ++pass) {
+      SPZ_HIP_TRY(hipMemsetAsync(d_pending, 0, sizeof(uint32_t), st));
+      hipLaunchKernelGGL(inf_window_resolve_kernel, dim3(resolve_blocks), dim3(256), 0, st, d_win, n, d_pending, d_bad);
+      SPZ_HIP_TRY(hipGetLastError());
+      SPZ_HIP_TRY(hipMemcpyAsync(&pending, d_pending, sizeof(pending), hipMemcpyDeviceToHost, st));
+      SPZ_HIP_TRY(hipStreamSynchronize(st));
+      if (timing && pending) std::fprintf(stderr, "[inflate] window pass %u: %u entries still open\n", pass, pending);
+    }
+    if (pending != 0) return SPZ_AMD_ERR_UNSUPPORTED;  // bytes carried through more than 2048 chunks: the host readers
+  }
   lap("windows");
   hipLaunchKernelGGL(inf_place_kernel, dim3(16, n), dim3(256), 0, st, d_sym, d_place, d_win, d_out, d_bad);
   SPZ_HIP_TRY(hipGetLastError());

@@ -818,8 +818,9 @@ int spz_amd_zlib_parse_open_dev(const uint8_t *h_data, const uint8_t *d_copy, ui
   const size_t o_info = carve((size_t)(max_jobs + 1) * sizeof(JobInfo));
   const size_t o_goff = carve((size_t)max_jobs * sizeof(unsigned long long));
   const size_t total = off;
-  size_t free_b = 0, total_b = 0;
-  SPZ_HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+  size_t free_b = 0;
+  rc = device_free_bytes(device, &free_b);
+  if (rc != SPZ_AMD_OK) return rc;
   if (total + (size_t(256) << 20) > free_b) return SPZ_AMD_ERR_UNSUPPORTED;  // the caller parses on the host
   char *block = nullptr;
   rc = scratch_acquire(device, total, reinterpret_cast<void **>(&block));

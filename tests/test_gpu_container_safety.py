@@ -181,3 +181,49 @@ def test_three_callers_at_once_through_both_device_stages(tmp_path):
         # most calls must have gone the device's way
         assert spz._device_gzip_parse_count() - parses >= 6, "the device writer mostly stood down"
         assert spz._device_inflate_count() - inflates >= 6, "the device reader mostly stood down"
+
+
+def test_device_stages_stand_down_when_the_card_has_no_room():
+    """SPZ_AMD_DEVICE_MEM_LIMIT_MIB makes the container stage believe the card is nearly full: writer and reader must
+    decline before allocating anything and the host routes deliver the same bytes."""
+    rng = np.random.default_rng(21)
+    data = make("sh_like", 9_000_000, rng)
+    want = zlib_gzip(data)
+    with Env(SPZ_AMD_GZIP_DEVICE="1", SPZ_AMD_GUNZIP_DEVICE="1", SPZ_AMD_DEVICE_MEM_LIMIT_MIB="64"):
+        parses, inflates = spz._device_gzip_parse_count(), spz._device_inflate_count()
+        assert spz._compress_gzipped(data) == want
+        assert spz._decompress_gzipped(want) == data
+        assert spz._device_gzip_parse_count() == parses and spz._device_inflate_count() == inflates
+    with Env(SPZ_AMD_GZIP_DEVICE="1", SPZ_AMD_GUNZIP_DEVICE="1", SPZ_AMD_DEVICE_MEM_LIMIT_MIB=None):
+        assert spz._compress_gzipped(data) == want
+        assert spz._decompress_gzipped(want) == data
+        assert spz._device_gzip_parse_count() == parses + 1 and spz._device_inflate_count() == inflates + 1
+
+
+def test_idle_scratch_is_bounded_by_the_keep_budget():
+    """What the container stage leaves allocated on the card between calls is bounded by SPZ_AMD_SCRATCH_KEEP_MIB: with 0
+    a call returns everything it took; by default the blocks stay for the next call (and go with
+    spz_amd_release_device_memory)."""
+    import torch
+    from spz_amd import abi
+    rng = np.random.default_rng(22)
+    data = make("sh_like", 40_000_000, rng)      # ~23 bytes of scratch per input byte: ~0.9 GB
+    L = abi.load_library()
+
+    def free_now():
+        torch.cuda.synchronize()
+        return torch.cuda.mem_get_info()[0]
+
+    with Env(SPZ_AMD_GZIP_DEVICE="1", SPZ_AMD_SCRATCH_KEEP_MIB="0"):
+        member = spz._compress_gzipped(data)      # first call: tables, streams, ... are made
+        assert L.spz_amd_release_device_memory() == 0
+        before = free_now()
+        assert spz._compress_gzipped(data) == member
+        assert before - free_now() < (64 << 20), "scratch stayed allocated although the keep budget is 0"
+    with Env(SPZ_AMD_GZIP_DEVICE="1", SPZ_AMD_SCRATCH_KEEP_MIB=None):
+        before = free_now()
+        assert spz._compress_gzipped(data) == member
+        kept = before - free_now()
+        assert kept > (400 << 20), "the default budget keeps the block for the next call"
+        assert L.spz_amd_release_device_memory() == 0
+        assert before - free_now() < (64 << 20)

@@ -47,14 +47,15 @@ __global__ void fill_kernel(float *p, uint64_t n, float lo, float hi, uint32_t s
   }
 }
 
-__global__ __launch_bounds__(256) void write_kernel(uint4 *p, uint64_t n16) {
-  const uint4 v = {1u, 2u, 3u, 4u};
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void write_kernel(u32x4 *p, uint64_t n16) {
+  const u32x4 v = {1u, 2u, 3u, 4u};
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) __builtin_nontemporal_store(v, p + i);
 }
-__global__ __launch_bounds__(256) void read_kernel(const uint4 *p, uint64_t n16, uint32_t *sink) {
+__global__ __launch_bounds__(256) void read_kernel(const u32x4 *p, uint64_t n16, uint32_t *sink) {
   uint32_t acc = 0;
   for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n16; i += (uint64_t)gridDim.x * 256) {
-    const uint4 v = __builtin_nontemporal_load(p + i);
+    const u32x4 v = __builtin_nontemporal_load(p + i);
     acc ^= v.x ^ v.y ^ v.z ^ v.w;
   }
   if (acc == 0x12345678u) *sink = acc;
@@ -414,13 +415,13 @@ int main(int argc, char **argv) {
           for (int rep = 0; rep < 4; ++rep) {
             float ms;
             CHECK(hipEventRecord(e0, nullptr));
-            hipLaunchKernelGGL(write_kernel, dim3(8192), dim3(256), 0, nullptr, reinterpret_cast<uint4 *>(chunk[i]), n16);
+            hipLaunchKernelGGL(write_kernel, dim3(8192), dim3(256), 0, nullptr, reinterpret_cast<u32x4 *>(chunk[i]), n16);
             CHECK(hipEventRecord(e1, nullptr));
             CHECK(hipEventSynchronize(e1));
             CHECK(hipEventElapsedTime(&ms, e0, e1));
             if (rep && ms < w) w = ms;
             CHECK(hipEventRecord(e0, nullptr));
-            hipLaunchKernelGGL(read_kernel, dim3(8192), dim3(256), 0, nullptr, reinterpret_cast<const uint4 *>(chunk[i]), n16, sink);
+            hipLaunchKernelGGL(read_kernel, dim3(8192), dim3(256), 0, nullptr, reinterpret_cast<const u32x4 *>(chunk[i]), n16, sink);
             CHECK(hipEventRecord(e1, nullptr));
             CHECK(hipEventSynchronize(e1));
             CHECK(hipEventElapsedTime(&ms, e0, e1));
@@ -431,6 +432,34 @@ int main(int argc, char **argv) {
         }
       }
       std::fflush(stdout);
+      for (int i = 0; i < K; ++i) CHECK(hipFree(chunk[i]));
+      continue;
+    }
+    if (kind.rfind("spread", 0) == 0) {  // "spread<K>": K chunks of 3 GiB; the seven arrays in one chunk, in two, or each in its own
+      const int K = std::atoi(kind.c_str() + 6) > 0 ? std::atoi(kind.c_str() + 6) : 48;
+      std::vector<uint8_t *> chunk(K);
+      for (int i = 0; i < K; ++i) CHECK(hipMalloc(reinterpret_cast<void **>(&chunk[i]), 3 * GiB));
+      const Layout base = packed_layout(g_stream_bytes, 2 * MiB);
+      for (int trial = 0; trial < 60; ++trial) {
+        int where[7];
+        const int mode = trial % 3;  // 0: all in one chunk; 1: sh alone, the rest together; 2: every array its own chunk
+        const int a = (int)(rng() % K);
+        int b = (int)(rng() % K);
+        if (b == a) b = (a + 1) % K;
+        std::vector<int> perm(K);
+        for (int i = 0; i < K; ++i) perm[i] = i;
+        std::shuffle(perm.begin(), perm.end(), rng);
+        uint8_t *ptr[7];
+        for (int k = 0; k < 7; ++k) {
+          where[k] = mode == 0 ? a : mode == 1 ? (k == 5 ? a : b) : perm[k];
+          ptr[k] = chunk[where[k]] + base.off[k];
+        }
+        const Timing t = measure_ptrs(ptr, reps);
+        std::printf("{\"kind\": \"spread\", \"exp\": \"fresh\", \"param_mib\": %d, \"where\": [%d, %d, %d, %d, %d, %d, %d], "
+                    "\"dec_seq_ms\": %.4f, \"dec_il_ms\": %.4f, \"enc_ms\": %.4f}\n",
+                    mode, where[0], where[1], where[2], where[3], where[4], where[5], where[6], t.dec_seq, t.dec_il, t.enc);
+        std::fflush(stdout);
+      }
       for (int i = 0; i < K; ++i) CHECK(hipFree(chunk[i]));
       continue;
     }
