@@ -256,6 +256,11 @@ int spz_amd_convert_coordinates_host(float *h_positions, float *h_rotations, flo
 int spz_amd_decode_gather_host(const uint8_t *h_stream, size_t size, uint64_t max_points,
                                const uint32_t *h_indices, uint64_t count, int to_coord,
                                const spz_amd_cloud_out *h_cloud, int device);
+/* The same for a stream that is in device memory already (spz_amd_inflate_device_data): only the index list goes
+ * up and the `count` decoded points come down.  `hdr`: the stream's header. */
+int spz_amd_decode_gather_host_from_device(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr,
+                                           const uint32_t *h_indices, uint64_t count, int to_coord,
+                                           const spz_amd_cloud_out *h_cloud, int device);
 
 /* ---- GaussianCloud::medianVolume's selection step (splat-types.h:170-185): the
  *      element of rank num_points/2 among the per-point sums (s0 + s1) + s2 of the log scales, found by
@@ -443,6 +448,11 @@ int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, 
 /* the same for deflate data that is in device memory already; equals_device: is the result these nbytes (device memory)? */
 int spz_amd_inflate_open_device(const uint8_t *d_deflate, uint64_t nbytes, int device, void **ctx, uint64_t *out_bytes);
 int spz_amd_inflate_equals_device(void *ctx, const uint8_t *d_expected, uint64_t nbytes);
+/* A context of the same kind around a stream the CALLER has inflated (a member the device reader declines, a raw
+ * stream): the bytes are uploaded and stay in device memory until spz_amd_inflate_close; device_data / piece_crcs /
+ * fetch work as after inflate_open.  With it "file -> packed sections left in HBM" (loadSpzPacked for renderers,
+ * load-spz.cc:609-632) has one shape whichever reader inflated the member. */
+int spz_amd_stream_to_device(const uint8_t *h_stream, uint64_t nbytes, int device, void **ctx);
 uint32_t spz_amd_inflate_crc_piece_bytes(void);
 int spz_amd_inflate_piece_crcs(void *ctx, uint32_t *h_crcs, uint32_t capacity, uint32_t *num_pieces);
 int spz_amd_inflate_fetch(void *ctx, uint8_t *h_out);

@@ -9,11 +9,19 @@
 //   (everything by value / caller-owned vectors) and error behaviour (never throws; save ->
 //   false, load -> default-constructed cloud plus one "[SPZ ERROR] ..." line on stdout).
 //
-// The per-Gaussian quantise / dequantise work runs on the GPU through libspz_amd.so; gzip
-// stays on the host (zlib, same deflate parameters as load-spz.cc:186-214, so the .spz bytes
-// are identical).  There is no CPU fallback: without a usable HIP device saveSpz returns
+// The per-Gaussian quantise / dequantise work runs on the GPU through libspz_amd.so.  The gzip container
+// (load-spz.cc:141-214) keeps zlib's bytes and zlib's verdicts, but where it runs depends on the size: streams of
+// 8 MiB and more are deflated and inflated ON THE DEVICE by default (spz_lz77.hip / spz_inflate_dev.hip: zlib
+// 1.2.11's level-6 output reproduced bit for bit, every member's symbols checked against the input on the device;
+// SPZ_AMD_GZIP_DEVICE / SPZ_AMD_GUNZIP_DEVICE = 0 keep the stage on the host), smaller ones and every case the device
+// declines on the host (multi-threaded exact writer / parallel reader from 1 / 4 MiB, zlib itself below and as the last
+// resort).  BASELINE.json's north_star kept gzip on the host; SURVEY §8(f)-2 is the row this widening belongs to.
+// There is no CPU fallback for the quantise step: without a usable HIP device saveSpz returns
 // false and loadSpz returns an empty cloud, each after logging
 // "[SPZ ERROR] spz_amd: <status>".  The device used is $SPZ_AMD_DEVICE (default 0).
+// Between calls the library keeps device memory (the host path's workspace, up to 32 GiB of container-stage scratch:
+// SPZ_AMD_SCRATCH_KEEP_MIB) and one host buffer (<= 1 GiB); spz_amd_release_device_memory() and
+// spz::releaseHostMemory() return them.  INTEGRATION.md "Memory the library keeps" has the figures.
 #pragma once
 
 #include <array>
@@ -143,13 +151,66 @@ PackedGaussians loadSpzPacked(const std::vector<uint8_t> &data);
 bool saveSplatToPly(const GaussianCloud &gaussians, const PackOptions &options, const std::string &filename);
 GaussianCloud loadSplatFromPly(const std::string &filename, const UnpackOptions &options);
 void serializePackedGaussians(const PackedGaussians &packed, std::ostream *out);
-// load-spz.cc:186-214.  The bytes are zlib's (level 6, one deflate stream, gzip wrapper): for inputs of
-// 1 MiB and more they are produced by a multi-threaded writer that reproduces zlib 1.2.11's output exactly
-// (SPZ_AMD_GZIP_EXACT_THREADS, default min(usable CPUs, 32); 1 = zlib itself), otherwise by zlib — and by zlib
-// too when the machine has less free memory than 4.5 x the input (the writer holds ~3 bytes per input byte
-// until it assembles the member).  SPZ_AMD_GZIP_VERIFY=1 inflates the finished member and compares it with the
-// input before returning it, =2 also compares it byte for byte with zlib's own member; a failed check returns zlib's.
+// load-spz.cc:186-214.  The bytes are zlib's (level 6, one deflate stream, gzip wrapper), whoever writes them:
+//   >= 8 MiB and a device answers   the device writer (spz_lz77.hip; SPZ_AMD_GZIP_DEVICE=0 never, =1 from 1 MiB).  Every
+//                                   symbol it codes is checked against the input on the device before the member is
+//                                   handed out (always on); a member that fails is discarded, logged and counted
+//                                   (deviceGzipRejectCount) and the next writer down produces it.
+//   >= 1 MiB                        the multi-threaded host writer that reproduces zlib 1.2.11's output exactly
+//                                   (SPZ_AMD_GZIP_EXACT_THREADS, default min(usable CPUs, 32); 1 = zlib itself)
+//   otherwise, or when the machine has less free memory than 4.5 x the input, or for another zlib version: zlib.
+// SPZ_AMD_GZIP_VERIFY=1 additionally inflates the finished member (device route: on the device, where the body still
+// lies) and compares it with the input byte for byte before returning it; =2 also compares it with zlib's own member.
 bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out);
+
+// ---- device-resident packed load (second half) ----------------------------------------------------
+// loadSpzPacked (load-spz.cc:609-632) hands a renderer the packed sections in HOST vectors.  A renderer on the GPU wants
+// them where it draws: loadSpzPackedDevice inflates the file (on the device when the device reader takes the member,
+// otherwise on the host followed by one upload), applies deserializePackedGaussians' header checks with the reference's
+// log lines (load-spz.cc:553-568,591-594) and leaves the stream IN DEVICE MEMORY.  The object owns that memory
+// (move-only; release() or the destructor returns it) and exposes the six section pointers of
+// deserializePackedGaussians' slicing (:569-590), the whole stream and its header — exactly the arguments of
+// spz_amd_decode_device / spz_amd_decode_gather_device (spz_amd.h), so a caller decodes what it needs, when it needs it,
+// without the bytes ever crossing PCIe again.  An empty object (numPoints == 0, null pointers) is the failure result,
+// as the empty PackedGaussians is for loadSpzPacked.
+class DevicePackedGaussians {
+ public:
+  DevicePackedGaussians() = default;
+  DevicePackedGaussians(DevicePackedGaussians &&o) noexcept;
+  DevicePackedGaussians &operator=(DevicePackedGaussians &&o) noexcept;
+  DevicePackedGaussians(const DevicePackedGaussians &) = delete;
+  DevicePackedGaussians &operator=(const DevicePackedGaussians &) = delete;
+  ~DevicePackedGaussians();
+
+  int32_t numPoints = 0;
+  int32_t shDegree = 0;
+  int32_t fractionalBits = 0;
+  bool antialiased = false;
+  bool usesQuaternionSmallestThree = true;
+  uint32_t version = 0;                 // of the stream: 1, 2 or 3
+  bool usesFloat16() const { return version == 1; }
+  // device pointers into `stream` (null when the section is empty), section sizes as in PackedGaussians
+  const uint8_t *positions = nullptr, *alphas = nullptr, *colors = nullptr, *scales = nullptr, *rotations = nullptr, *sh = nullptr;
+  size_t positionsBytes = 0, alphasBytes = 0, colorsBytes = 0, scalesBytes = 0, rotationsBytes = 0, shBytes = 0;
+  const uint8_t *stream = nullptr;      // header + sections, device memory
+  size_t streamBytes = 0;
+  int device = 0;
+  bool inflatedOnDevice = false;        // which reader produced the stream (the bytes are the same)
+
+  bool valid() const { return stream != nullptr; }
+  void release();                       // returns the device memory; the object becomes the empty one
+  // unpackGaussians (load-spz.cc:467-531) of all points / of an index list, from where the stream lies: only the
+  // floats cross PCIe.  Same results as loadSpz / unpackIndices on the same file.
+  GaussianCloud unpack(const UnpackOptions &o) const;
+  GaussianCloud unpackIndices(const std::vector<uint32_t> &indices, const UnpackOptions &o) const;
+
+ private:
+  void *owner_ = nullptr;               // the C ABI's inflate context (spz_amd_inflate_close)
+  friend DevicePackedGaussians loadSpzPackedDevice(const uint8_t *data, int32_t size);
+};
+DevicePackedGaussians loadSpzPackedDevice(const std::string &filename);
+DevicePackedGaussians loadSpzPackedDevice(const uint8_t *data, int32_t size);
+DevicePackedGaussians loadSpzPackedDevice(const std::vector<uint8_t> &data);
 
 // External-linkage internals of the reference (load-spz.cc:257,467,548), kept because
 // downstream code forward-declares them to skip gzip.

@@ -55,7 +55,7 @@ EXPORTS = (
     "spz_amd_zlib_encode_group", "spz_amd_zlib_encode_finish", "spz_amd_zlib_parse_open_dev", "spz_amd_encode_host_keep", "spz_amd_kept_stream_release",
     "spz_amd_zlib_block_trees", "spz_amd_zlib_encode_planned", "spz_amd_zlib_encode_finish_ex",
     "spz_amd_inflate_open", "spz_amd_inflate_open_device", "spz_amd_inflate_equals_device", "spz_amd_inflate_crc_piece_bytes", "spz_amd_inflate_piece_crcs", "spz_amd_inflate_fetch",
-    "spz_amd_inflate_device_data", "spz_amd_inflate_close",
+    "spz_amd_inflate_device_data", "spz_amd_inflate_close", "spz_amd_stream_to_device", "spz_amd_decode_gather_host_from_device",
 )
 
 RCCL_UNIQUE_ID_BYTES = 128

@@ -10,6 +10,10 @@
 // `deflate_slow` + `longest_match`, trees.c's block writer) and is pinned by byte comparison with the
 // system zlib in tests/test_exact_gzip.py and by a self-check against zlib at run time.
 //
+// Acknowledgement: longest_match / deflate_slow / the block writer below follow deflate.c and trees.c of zlib 1.2.11,
+// (C) 1995-2017 Jean-loup Gailly and Mark Adler (zlib licence), closely enough to give identical output; this is an
+// altered restatement, plainly marked as such, not the original software.
+//
 // How it can be parallel and exact:
 //  * zlib's LZ77 parse at a position depends only on (a) the previous 32 KiB of input, through hash
 //    chains that contain EVERY earlier position (level >= 4 inserts all of them), (b) the phase of its

@@ -579,14 +579,12 @@ int spz_amd_decode_host(const uint8_t *h_stream, size_t size, int to_coord, cons
   return spz_amd_decode_host_ex(h_stream, size, SPZ_AMD_REFERENCE_MAX_POINTS, to_coord, h, device);
 }
 
-int spz_amd_decode_gather_host(const uint8_t *h_stream, size_t size, uint64_t max_points, const uint32_t *h_indices,
-                               uint64_t count, int to_coord, const spz_amd_cloud_out *h, int device) {
-  if (h_stream == nullptr || h == nullptr || !valid_coord(to_coord)) return SPZ_AMD_ERR_INVALID_ARG;
-  spz_amd_header hdr;
-  int rc = spz_amd_peek_header_ex(h_stream, size, max_points, &hdr);
-  if (rc != SPZ_AMD_OK) return rc;
+// The gather decode for host index lists and host outputs; the stream comes from the host (h_stream, uploaded) or lies on
+// the device already (d_stream).
+static int decode_gather_host_impl(const uint8_t *h_stream, const uint8_t *d_stream, size_t size, const spz_amd_header &hdr,
+                                   const uint32_t *h_indices, uint64_t count, int to_coord, const spz_amd_cloud_out *h, int device) {
   spz_amd_layout lay;
-  rc = spz_amd_stream_layout(hdr.num_points, hdr.sh_degree, (int)hdr.version, &lay);
+  int rc = spz_amd_stream_layout(hdr.num_points, hdr.sh_degree, (int)hdr.version, &lay);
   if (rc != SPZ_AMD_OK) return rc;
   if (size < lay.total_bytes) return SPZ_AMD_ERR_SHORT_STREAM;
   if (count == 0) return SPZ_AMD_OK;
@@ -603,13 +601,17 @@ int spz_amd_decode_gather_host(const uint8_t *h_stream, size_t size, uint64_t ma
   if (rc != SPZ_AMD_OK) return rc;
   const size_t cnt[6] = {count * 3, count * 3, count * 4, count, count * 3, count * (size_t)sd * 3};
   float *dst[6] = {h->positions, h->scales, h->rotations, h->alphas, h->colors, h->sh};
-  size_t total = Workspace::aligned(lay.total_bytes) + Workspace::aligned(count * sizeof(uint32_t));
+  size_t total = (d_stream ? 0 : Workspace::aligned(lay.total_bytes)) + Workspace::aligned(count * sizeof(uint32_t));
   for (int i = 0; i < 6; ++i) total += Workspace::aligned(cnt[i] * sizeof(float));
   Workspace ws;
   rc = ws.open(device, total);
   if (rc != SPZ_AMD_OK) return rc;
-  void *sb = ws.take(lay.total_bytes);
-  SPZ_HIP_TRY(hipMemcpyAsync(sb, h_stream, lay.total_bytes, hipMemcpyHostToDevice, nullptr));
+  const void *sb = d_stream;
+  if (d_stream == nullptr) {
+    void *up = ws.take(lay.total_bytes);
+    SPZ_HIP_TRY(hipMemcpyAsync(up, h_stream, lay.total_bytes, hipMemcpyHostToDevice, nullptr));
+    sb = up;
+  }
   void *ib = ws.take(count * sizeof(uint32_t));
   SPZ_HIP_TRY(hipMemcpyAsync(ib, h_indices, count * sizeof(uint32_t), hipMemcpyHostToDevice, nullptr));
   void *fb[6];
@@ -623,6 +625,23 @@ int spz_amd_decode_gather_host(const uint8_t *h_stream, size_t size, uint64_t ma
   }
   SPZ_HIP_TRY(hipStreamSynchronize(nullptr));
   return SPZ_AMD_OK;
+}
+
+int spz_amd_decode_gather_host(const uint8_t *h_stream, size_t size, uint64_t max_points, const uint32_t *h_indices,
+                               uint64_t count, int to_coord, const spz_amd_cloud_out *h, int device) {
+  if (h_stream == nullptr || h == nullptr || !valid_coord(to_coord)) return SPZ_AMD_ERR_INVALID_ARG;
+  spz_amd_header hdr;
+  const int rc = spz_amd_peek_header_ex(h_stream, size, max_points, &hdr);
+  if (rc != SPZ_AMD_OK) return rc;
+  return decode_gather_host_impl(h_stream, nullptr, size, hdr, h_indices, count, to_coord, h, device);
+}
+
+int spz_amd_decode_gather_host_from_device(const uint8_t *d_stream, size_t size, const spz_amd_header *hdr, const uint32_t *h_indices,
+                                           uint64_t count, int to_coord, const spz_amd_cloud_out *h, int device) {
+  if (d_stream == nullptr || hdr == nullptr || h == nullptr || !valid_coord(to_coord)) return SPZ_AMD_ERR_INVALID_ARG;
+  if (hdr->version < 1 || hdr->version > 3) return SPZ_AMD_ERR_VERSION;
+  if (hdr->sh_degree > 3) return SPZ_AMD_ERR_SH_DEGREE;
+  return decode_gather_host_impl(nullptr, d_stream, size, *hdr, h_indices, count, to_coord, h, device);
 }
 
 int spz_amd_convert_coordinates_host(float *h_positions, float *h_rotations, float *h_sh, uint64_t n,

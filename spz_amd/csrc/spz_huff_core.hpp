@@ -5,6 +5,12 @@
 // gen_bitlen and the run-length walk of the code lengths are all kept as they are there.
 // Storage is handed in by pointer: the host keeps a tree in its Block, the device keeps it in LDS (where dad[] and
 // len[] are the same array, as in zlib's ct_data union: a node's length replaces its parent link once that is read).
+//
+// Acknowledgement: this file follows the structure of trees.c of zlib 1.2.11, (C) 1995-2017 Jean-loup Gailly and Mark
+// Adler, statement by statement where the tie-breaks decide the output, and keeps its function names so that the two
+// can be read side by side.  zlib is distributed under the zlib licence ("This software is provided 'as-is' ...
+// altered source versions must be plainly marked as such, and must not be misrepresented as being the original
+// software"); this is such an altered restatement, not the original software.
 #pragma once
 
 #include <cstdint>

@@ -155,6 +155,7 @@ struct ChunkResult {
   uint32_t outcome;                 // Outcome
   uint32_t overflow;
   unsigned long long mark_n;        // FAILED: symbols before the block that did not work out (end_bit: where it begins)
+  uint32_t n_rounds, n_matches, n_miss, pad;
 };
 // The wave's view of the deflate data: all 64 lanes run the decoder in lockstep (same bits, same decisions), the
 // compressed bytes around the current position are kept in LDS and refilled by all lanes (16 bytes each).
@@ -221,6 +222,8 @@ struct WaveSymbolSink {
   uint32_t lane;
   bool overflow;
   uint64_t mark_n;
+  uint32_t n_rounds = 0, n_matches = 0, n_miss = 0;  // what the wave met (SPZ_AMD_LZ_TIMING prints the totals)
+  bool skip_copies = false;                          // experiment: matches are counted, not copied (wrong output)
   __device__ __forceinline__ void mark() { mark_n = n; }
   __device__ __forceinline__ bool lit(uint8_t b) {
     if (n >= cap) {
@@ -235,10 +238,14 @@ struct WaveSymbolSink {
   __device__ __forceinline__ void copy_at(uint64_t at, uint32_t len, uint32_t dist) {
     // byte at + i is byte at + i - dist, which for an overlapping copy is byte at - dist + (i mod dist): never one of this
     // match's own; a source before the chunk's first byte is byte W + (index) of the predecessor's final window
+    // i mod dist for i < 258 without an integer division: (i + 0.5) / dist is at least 0.5 / 258 away from every
+    // integer, far more than the error of the reciprocal, so the truncated product is the exact quotient
+    const float rd = __builtin_amdgcn_rcpf((float)dist);
     for (uint32_t base = 0; base < len; base += 64) {
       const uint32_t i = base + lane;
       if (i < len) {
-        const long long src = (long long)at - (long long)dist + (long long)(dist < len ? i % dist : i);
+        const uint32_t q = dist < len ? (uint32_t)(((float)i + 0.5f) * rd) : 0u;
+        const long long src = (long long)at - (long long)dist + (long long)(i - q * dist);
         sym[at + i] = src >= 0 ? sym[src] : (uint16_t)(256 + W + src);
       }
     }
@@ -295,16 +302,23 @@ struct WaveSymbolSink {
 // arithmetic is that function's, applied at every position instead of one.
 constexpr uint32_t F_LIT = 1u, F_MATCH = 2u, F_EOB = 4u, F_INVALID = 8u, F_MISS = 16u;
 
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {  // a value all lanes agree on, moved to scalar registers
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+  return (uint64_t)lo | ((uint64_t)hi << 32);
+}
+
 template <class HL, class HD>
 __device__ __forceinline__ bool decodeHuffBlockWave(const WaveBits &in, uint64_t *at, const HL &L, const HD &D, WaveSymbolSink &sink,
                                                     uint64_t limit) {
-  uint64_t pos = *at;
+  uint64_t pos = uniform64(*at);
   const uint32_t lane = in.lane;
   for (;;) {
     if (pos >= in.nbits || pos > limit) return false;
     uint64_t bits = in.lane_peek(pos);
     const uint32_t e = L.packed[bits & ((1u << HL::fastbits) - 1u)];
-    uint32_t total = e & 15u, flags, outlen = 0, dist = 0, value = e >> 16;  // value: the literal
+    uint32_t total = e & 15u, flags, outlen = 0, dist = 0;
+    const uint32_t value = e >> 16;  // the literal
     if (e == 0u) {
       flags = F_MISS;
     } else if (e & ENT_LITERAL) {
@@ -332,58 +346,20 @@ __device__ __forceinline__ bool decodeHuffBlockWave(const WaveBits &in, uint64_t
         flags = F_MATCH;
       }
     }
-    uint32_t step = total | (flags << 8);
-    // the chain of real symbol starts
+    // The chain of real symbol starts: position 0 is one, and each names the next through its own length.  A symbol
+    // that ends the round's ordinary processing (end of block, a code the fast tables do not hold, an invalid code)
+    // steps out of the round, and is looked at afterwards.
+    const bool stops = (flags & (F_EOB | F_MISS | F_INVALID)) != 0u;
+    const uint32_t step = stops ? 64u : total;
     uint32_t cur = 0;
     uint64_t starts = 0;
-    bool eob = false;
-    while (cur < 64u) {
-      uint32_t st = (uint32_t)__builtin_amdgcn_readlane((int)step, (int)cur);
-      if (st & (F_MISS << 8)) {  // a long code: all lanes decode the symbol at pos + cur, lane `cur` keeps the result
-        uint64_t b = in.peek(pos + cur);
-        const uint32_t e2 = in.uniform(L.lookup(b));
-        uint32_t t2 = e2 & 15u, f2, o2 = 0, d2 = 0;
-        if (e2 == 0u || (e2 & ENT_INVALID)) {
-          f2 = F_INVALID;
-        } else if (e2 & ENT_LITERAL) {
-          f2 = F_LIT;
-          o2 = 1;
-        } else if (e2 & ENT_EOB) {
-          f2 = F_EOB;
-        } else {
-          b >>= t2;
-          const uint32_t lextra = (e2 >> 4) & 15u;
-          o2 = (e2 >> 16) + (uint32_t)(b & ((1u << lextra) - 1u));
-          b >>= lextra;
-          const uint32_t dd = in.uniform(D.lookup(b));
-          if (dd == 0u || (dd & ENT_INVALID)) {
-            f2 = F_INVALID;
-          } else {
-            b >>= dd & 15u;
-            const uint32_t dextra = (dd >> 4) & 15u;
-            d2 = (dd >> 16) + (uint32_t)(b & ((1u << dextra) - 1u));
-            t2 += lextra + (dd & 15u) + dextra;
-            f2 = F_MATCH;
-          }
-        }
-        st = t2 | (f2 << 8);
-        if (lane == cur) {
-          flags = f2;
-          outlen = o2;
-          dist = d2;
-          value = e2 >> 16;
-        }
-      }
-      if (st & (F_INVALID << 8)) return false;
+    do {
       starts |= 1ull << cur;
-      cur += st & 255u;
-      if (st & (F_EOB << 8)) {
-        eob = true;
-        break;
-      }
-    }
-    const bool mine = (starts >> lane) & 1ull;
-    const uint32_t ol = mine ? outlen : 0u;  // the end-of-block symbol produces nothing
+      cur += (uint32_t)__builtin_amdgcn_readlane((int)step, (int)cur);
+    } while (cur < 64u);
+    const uint64_t stopped = __ballot(stops) & starts;  // at most the chain's last start
+    const bool mine = ((starts >> lane) & 1ull) != 0ull && !stops;
+    const uint32_t ol = mine ? outlen : 0u;
     uint32_t incl = ol;
 #pragma unroll
     for (uint32_t off = 1; off < 64u; off <<= 1) {
@@ -391,12 +367,13 @@ __device__ __forceinline__ bool decodeHuffBlockWave(const WaveBits &in, uint64_t
       if (lane >= off) incl += y;
     }
     const uint32_t produced = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-    if (sink.n + produced > sink.cap) {
+    uint64_t n = uniform64(sink.n);
+    if (n + produced > sink.cap) {
       sink.overflow = true;
       return false;
     }
     const uint32_t before = incl - ol;
-    if (mine && (flags & F_LIT)) sink.sym[sink.n + before] = (uint16_t)value;
+    if (mine && (flags & F_LIT)) sink.sym[n + before] = (uint16_t)value;
     uint64_t matches = __ballot(mine && (flags & F_MATCH));
     while (matches) {
       const int l = __builtin_ctzll(matches);
@@ -404,27 +381,67 @@ __device__ __forceinline__ bool decodeHuffBlockWave(const WaveBits &in, uint64_t
       const uint32_t len = (uint32_t)__builtin_amdgcn_readlane((int)outlen, l);
       const uint32_t dst = (uint32_t)__builtin_amdgcn_readlane((int)dist, l);
       const uint32_t off = (uint32_t)__builtin_amdgcn_readlane((int)before, l);
-      sink.copy_at(sink.n + off, len, dst);
+      ++sink.n_matches;
+      if (!sink.skip_copies) sink.copy_at(n + off, len, dst);
     }
-    sink.n += produced;
-    pos += cur;
-    if (eob) {
+    ++sink.n_rounds;
+    n += produced;
+    sink.n = n;
+    if (stopped == 0ull) {
+      pos += cur;
+      continue;
+    }
+    // the symbol the chain stopped at, decoded the serial way (all lanes, same bits): the end of the block almost always
+    const uint32_t sl = (uint32_t)__builtin_ctzll(stopped);
+    pos += sl;
+    uint64_t b = in.peek(pos);
+    const uint32_t e2 = in.uniform(L.lookup(b));
+    if (e2 == 0u || (e2 & ENT_INVALID)) return false;
+    uint32_t used = e2 & 15u;
+    if (e2 & ENT_EOB) {
+      pos += used;
       if (pos > in.nbits) return false;
       *at = pos;
       return true;
+    }
+    ++sink.n_miss;
+    if (e2 & ENT_LITERAL) {
+      if (!sink.lit((uint8_t)(e2 >> 16))) return false;
+      pos += used;
+      continue;
+    }
+    b >>= used;
+    const uint32_t lextra = (e2 >> 4) & 15u;
+    const uint32_t length = (e2 >> 16) + (uint32_t)(b & ((1u << lextra) - 1u));
+    b >>= lextra;
+    used += lextra;
+    const uint32_t dd = in.uniform(D.lookup(b));
+    if (dd == 0u || (dd & ENT_INVALID)) return false;
+    b >>= dd & 15u;
+    const uint32_t dextra = (dd >> 4) & 15u;
+    const uint32_t distance = (dd >> 16) + (uint32_t)(b & ((1u << dextra) - 1u));
+    used += (dd & 15u) + dextra;
+    pos += used;
+    if (pos > in.nbits) return false;
+    ++sink.n_matches;
+    if (sink.skip_copies) {
+      sink.n += length;
+    } else if (!sink.match(length, distance)) {
+      return false;
     }
   }
 }
 
 __global__ __launch_bounds__(64, 6) void inf_decode_kernel(const uint8_t *__restrict__ d, uint64_t nbytes,
                                                            const ChunkJob *__restrict__ jobs, const uint32_t *__restrict__ run,
-                                                           uint16_t *symbols, ChunkResult *__restrict__ results) {
+                                                           uint16_t *symbols, ChunkResult *__restrict__ results, uint32_t experiment) {
   __shared__ Tables tb;
   __shared__ uint32_t s_win[kWinBytes / 4 + 4];
   const uint32_t j = run[blockIdx.x];
   const ChunkJob job = jobs[j];
   const WaveBits in = {d, 8ull * nbytes, (size_t)nbytes, s_win, threadIdx.x, ~0ull, 0ull, 0ull, ~0ull};
   WaveSymbolSink sink = {symbols + job.region, job.capacity, job.start_n, threadIdx.x, false, job.start_n};
+  sink.skip_copies = (experiment & 1u) != 0u;
   uint64_t end = 0;
   const Outcome r = decodeBlocksWith(in, job.from, job.to, sink, &end, &tb.lit, &tb.dist,
                                      [](const WaveBits &i, uint64_t *at, const DevLit &L, const DevDist &D, WaveSymbolSink &s, uint64_t limit) {
@@ -437,6 +454,9 @@ __global__ __launch_bounds__(64, 6) void inf_decode_kernel(const uint8_t *__rest
     o.outcome = (uint32_t)r;
     o.overflow = sink.overflow ? 1u : 0u;
     o.mark_n = sink.mark_n;
+    o.n_rounds = sink.n_rounds;
+    o.n_matches = sink.n_matches;
+    o.n_miss = sink.n_miss;
   }
 }
 
@@ -638,6 +658,10 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
   else SPZ_HIP_TRY(hipMemcpy(&first_byte, d_deflate, 1, hipMemcpyDeviceToHost));
   if (((first_byte >> 1) & 3) == 0) return SPZ_AMD_ERR_UNSUPPORTED;  // opens with a stored block: nothing to gain
   static const bool timing = std::getenv("SPZ_AMD_LZ_TIMING") != nullptr;
+  // SPZ_AMD_INFLATE_EXPERIMENT (measurements only; bit 0: matches are counted but not copied — the result is wrong and
+  // the CRC check sends the caller to the host readers)
+  const char *exp_env = std::getenv("SPZ_AMD_INFLATE_EXPERIMENT");
+  const uint32_t experiment = exp_env ? (uint32_t)std::atoi(exp_env) : 0u;
   auto t_prev = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
     if (!timing) return;
@@ -741,7 +765,8 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
   for (uint32_t round = 0; round < 8 && !linked; ++round) {
     SPZ_HIP_TRY(hipMemcpyAsync(d_jobs, jobs.data(), (size_t)n * sizeof(ChunkJob), hipMemcpyHostToDevice, st));
     SPZ_HIP_TRY(hipMemcpyAsync(d_run, todo.data(), todo.size() * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(inf_decode_kernel, dim3((unsigned)todo.size()), dim3(64), 0, st, d_data, nbytes, d_jobs, d_run, d_sym, d_res);
+    hipLaunchKernelGGL(inf_decode_kernel, dim3((unsigned)todo.size()), dim3(64), 0, st, d_data, nbytes, d_jobs, d_run, d_sym, d_res,
+                       experiment);
     SPZ_HIP_TRY(hipGetLastError());
     SPZ_HIP_TRY(hipMemcpyAsync(res.data(), d_res, (size_t)n * sizeof(ChunkResult), hipMemcpyDeviceToHost, st));
     SPZ_HIP_TRY(hipStreamSynchronize(st));
@@ -772,6 +797,16 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
   }
   if (!linked) return SPZ_AMD_ERR_UNSUPPORTED;
   lap("decode");
+  if (timing) {
+    unsigned long long rounds = 0, matches = 0, miss = 0, syms = 0;
+    for (uint32_t j : live) {
+      rounds += res[j].n_rounds;
+      matches += res[j].n_matches;
+      miss += res[j].n_miss;
+      syms += res[j].length;
+    }
+    std::fprintf(stderr, "[inflate] %llu bytes out, %llu rounds of 64 bit positions, %llu matches, %llu long codes\n", syms, rounds, matches, miss);
+  }
   n = (uint32_t)live.size();
   std::vector<ChunkPlace> place(n);
   unsigned long long offset = 0;
@@ -842,6 +877,43 @@ int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, 
 int spz_amd_inflate_open_device(const uint8_t *d_deflate, uint64_t nbytes, int device, void **ctx, uint64_t *out_bytes) {
   if (d_deflate == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
   return inflate_open_impl(nullptr, d_deflate, nbytes, device, ctx, out_bytes);
+}
+
+int spz_amd_stream_to_device(const uint8_t *h_stream, uint64_t nbytes, int device, void **ctx) {
+  if (h_stream == nullptr || ctx == nullptr || nbytes == 0) return SPZ_AMD_ERR_INVALID_ARG;
+  *ctx = nullptr;
+  DeviceGuard guard;
+  int rc = guard.enter(device);
+  if (rc != SPZ_AMD_OK) return rc;
+  const uint32_t n_pieces = (uint32_t)((nbytes + kCrcPiece - 1) / kCrcPiece);
+  const size_t bytes = round256(nbytes + 64) + round256((size_t)n_pieces * sizeof(uint32_t)) + 256;
+  char *block = nullptr;
+  rc = scratch_acquire(device, bytes, reinterpret_cast<void **>(&block));
+  if (rc != SPZ_AMD_OK) return rc;
+  hipStream_t st = nullptr;
+  hipError_t e = upload_adaptive(block, h_stream, nbytes, st);
+  if (e == hipSuccess) e = hipMemsetAsync(block + nbytes, 0, 64, st);
+  uint32_t *d_crcs = reinterpret_cast<uint32_t *>(block + round256(nbytes + 64));
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(inf_crc_kernel, dim3(n_pieces), dim3(64), 0, st, reinterpret_cast<const uint8_t *>(block), nbytes, kCrcPiece, d_crcs);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipStreamSynchronize(st);
+  InfContext *c = e == hipSuccess ? new (std::nothrow) InfContext() : nullptr;
+  if (c == nullptr) {
+    scratch_release(device, block);
+    if (e != hipSuccess) g_last_hip_error = (int)e;
+    return SPZ_AMD_ERR_HIP;
+  }
+  c->device = device;
+  c->block = block;
+  c->out = reinterpret_cast<uint8_t *>(block);
+  c->out_bytes = nbytes;
+  c->crcs = d_crcs;
+  c->n_pieces = n_pieces;
+  c->diff = reinterpret_cast<uint32_t *>(block + round256(nbytes + 64) + round256((size_t)n_pieces * sizeof(uint32_t)));
+  *ctx = c;
+  return SPZ_AMD_OK;
 }
 
 int spz_amd_inflate_equals_device(void *ctx, const uint8_t *d_expected, uint64_t nbytes) {

@@ -215,6 +215,64 @@ PYBIND11_MODULE(spz, m) {
              return v;
            }, "Return the median Gaussian volume.");
 
+  // Device-resident packed load (an extra of this implementation): the stream stays in HBM.
+  py::class_<spz::DevicePackedGaussians>(m, "DevicePackedGaussians",
+                                         "A .spz file's packed sections left in device memory (spz::loadSpzPackedDevice). "
+                                         "Pointers are device addresses (ints); the object owns the memory until release().")
+      .def_readonly("num_points", &spz::DevicePackedGaussians::numPoints)
+      .def_readonly("sh_degree", &spz::DevicePackedGaussians::shDegree)
+      .def_readonly("fractional_bits", &spz::DevicePackedGaussians::fractionalBits)
+      .def_readonly("antialiased", &spz::DevicePackedGaussians::antialiased)
+      .def_readonly("version", &spz::DevicePackedGaussians::version)
+      .def_readonly("uses_quaternion_smallest_three", &spz::DevicePackedGaussians::usesQuaternionSmallestThree)
+      .def_readonly("device", &spz::DevicePackedGaussians::device)
+      .def_readonly("inflated_on_device", &spz::DevicePackedGaussians::inflatedOnDevice)
+      .def_property_readonly("uses_float16", [](const spz::DevicePackedGaussians &d) { return d.usesFloat16(); })
+      .def_property_readonly("valid", [](const spz::DevicePackedGaussians &d) { return d.valid(); })
+      .def_property_readonly("stream_ptr", [](const spz::DevicePackedGaussians &d) { return reinterpret_cast<uintptr_t>(d.stream); })
+      .def_property_readonly("stream_bytes", [](const spz::DevicePackedGaussians &d) { return d.streamBytes; })
+      .def_property_readonly("sections", [](const spz::DevicePackedGaussians &d) {
+             py::dict r;
+             auto put = [&](const char *name, const uint8_t *p, size_t n) { r[name] = py::make_tuple(reinterpret_cast<uintptr_t>(p), n); };
+             put("positions", d.positions, d.positionsBytes);
+             put("alphas", d.alphas, d.alphasBytes);
+             put("colors", d.colors, d.colorsBytes);
+             put("scales", d.scales, d.scalesBytes);
+             put("rotations", d.rotations, d.rotationsBytes);
+             put("sh", d.sh, d.shBytes);
+             return r;
+           }, "name -> (device address, bytes) of the six sections, in PackedGaussians' naming.")
+      .def("release", &spz::DevicePackedGaussians::release, "Return the device memory; the object becomes empty.")
+      .def("unpack", [](const spz::DevicePackedGaussians &d, const spz::UnpackOptions &o) {
+             spz::GaussianCloud g;
+             {
+               py::gil_scoped_release release;
+               g = d.unpack(o);
+             }
+             if (g.numPoints == 0) raiseIfDeviceUnusable();
+             return g;
+           }, py::arg("options") = spz::UnpackOptions(), "unpackGaussians of all points, from where the stream lies.")
+      .def("unpack_indices", [](const spz::DevicePackedGaussians &d, const std::vector<uint32_t> &indices, const spz::UnpackOptions &o) {
+             spz::GaussianCloud g = d.unpackIndices(indices, o);
+             if (g.numPoints == 0 && !indices.empty()) raiseIfDeviceUnusable();
+             return g;
+           }, py::arg("indices"), py::arg("options") = spz::UnpackOptions(), "One gather launch over the resident stream.");
+  m.def("load_spz_packed_device", [](const std::string &filename) {
+          spz::DevicePackedGaussians d;
+          {
+            py::gil_scoped_release release;
+            d = spz::loadSpzPackedDevice(filename);
+          }
+          if (!d.valid()) raiseIfDeviceUnusable();
+          return d;
+        }, py::arg("filename"), "loadSpzPacked with the packed sections left in device memory.");
+  m.def("_load_spz_packed_device_bytes", [](const py::bytes &data) {
+          const BytesView in = viewOf(data);
+          spz::DevicePackedGaussians d = spz::loadSpzPackedDevice(in.p, static_cast<int32_t>(in.n));
+          if (!d.valid()) raiseIfDeviceUnusable();
+          return d;
+        }, py::arg("data"), "The same from .spz bytes in memory.");
+
   m.def("load_spz",
         [](const std::string &filename, const spz::UnpackOptions &o) {
           spz::GaussianCloud g;

@@ -214,16 +214,25 @@ def test_idle_scratch_is_bounded_by_the_keep_budget():
         torch.cuda.synchronize()
         return torch.cuda.mem_get_info()[0]
 
+    def returned(before, slack=64 << 20):
+        # the driver finishes a large free in the background: give it a moment
+        import time
+        for _ in range(40):
+            if before - free_now() < slack:
+                return True
+            time.sleep(0.05)
+        return False
+
     with Env(SPZ_AMD_GZIP_DEVICE="1", SPZ_AMD_SCRATCH_KEEP_MIB="0"):
         member = spz._compress_gzipped(data)      # first call: tables, streams, ... are made
         assert L.spz_amd_release_device_memory() == 0
         before = free_now()
         assert spz._compress_gzipped(data) == member
-        assert before - free_now() < (64 << 20), "scratch stayed allocated although the keep budget is 0"
+        assert returned(before), "scratch stayed allocated although the keep budget is 0"
     with Env(SPZ_AMD_GZIP_DEVICE="1", SPZ_AMD_SCRATCH_KEEP_MIB=None):
         before = free_now()
         assert spz._compress_gzipped(data) == member
         kept = before - free_now()
         assert kept > (400 << 20), "the default budget keeps the block for the next call"
         assert L.spz_amd_release_device_memory() == 0
-        assert before - free_now() < (64 << 20)
+        assert returned(before)

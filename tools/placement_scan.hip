@@ -13,6 +13,8 @@
 //   hipcc --offload-arch=gfx950 -O2 -std=c++17 -Iinclude -o build/placement_scan tools/placement_scan.hip -Lspz_amd/lib -lspz_amd -Wl,-rpath,$PWD/spz_amd/lib
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cstdint>
 #include <cstdio>
@@ -150,12 +152,23 @@ Layout packed_layout(uint64_t stream_bytes, uint64_t align) {
   return l;
 }
 
+uint64_t base_rest_bytes();
+
 struct Timing {
   float dec_seq, dec_il, enc;
 };
 
 spz_amd_cloud_in g_in;
 uint64_t g_stream_bytes;
+
+uint64_t base_rest_bytes() {  // positions, scales, rotations, alphas, colours and the stream, each begun at a 2 MiB multiple
+  uint64_t at = 0;
+  for (int k = 0; k < 7; ++k) {
+    if (k == 5) continue;
+    at = up(at + (k < 6 ? kFloats[k] * 4 : g_stream_bytes), 2 * MiB);
+  }
+  return at;
+}
 
 Timing measure_ptrs(uint8_t *const ptr[7], int reps);
 
@@ -461,6 +474,115 @@ int main(int argc, char **argv) {
         std::fflush(stdout);
       }
       for (int i = 0; i < K; ++i) CHECK(hipFree(chunk[i]));
+      continue;
+    }
+    if (kind == "variants") {  // build/variants/libspz_amd_<name>.so (tools/tune.py build), $VARIANTS: a slow and a fast placement each
+      const char *ve = std::getenv("VARIANTS");
+      std::vector<std::string> names;
+      for (std::string v = ve ? ve : "seq,il_g8"; !v.empty();) {
+        const size_t q = v.find(',');
+        names.push_back(v.substr(0, q));
+        v = q == std::string::npos ? "" : v.substr(q + 1);
+      }
+      const int K = 12;
+      std::vector<uint8_t *> chunk(K);
+      for (int i = 0; i < K; ++i) CHECK(hipMalloc(reinterpret_cast<void **>(&chunk[i]), 3 * GiB));
+      const Layout base = packed_layout(g_stream_bytes, 2 * MiB);
+      // placements: "same" = all seven arrays in chunk 0; "apart k" = sh in chunk 0, the rest in chunk k
+      struct Place { std::string name; uint8_t *ptr[7]; };
+      std::vector<Place> places;
+      for (int k = 0; k < K; ++k) {
+        Place pl;
+        pl.name = k == 0 ? "same" : "apart" + std::to_string(k);
+        for (int a = 0; a < 7; ++a) pl.ptr[a] = (a == 5 ? chunk[0] : chunk[k]) + base.off[a];
+        places.push_back(pl);
+      }
+      typedef int (*enc_fn)(const spz_amd_cloud_in *, uint64_t, int, int, int, int, uint8_t *, size_t, void *);
+      typedef int (*dec_fn)(const uint8_t *, size_t, const spz_amd_header *, int, const spz_amd_cloud_out *, void *);
+      unsetenv("SPZ_AMD_GRID_ORDER");
+      hipEvent_t e0, e1;
+      CHECK(hipEventCreate(&e0));
+      CHECK(hipEventCreate(&e1));
+      spz_amd_header hdr = {3, (uint32_t)kN, (uint8_t)kDeg, 12, 0, 0};
+      for (const std::string &name : names) {
+        const std::string path = std::string("build/variants/libspz_amd_") + name + ".so";
+        void *h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+        if (!h) {
+          std::fprintf(stderr, "skip %s: %s\n", name.c_str(), dlerror());
+          continue;
+        }
+        enc_fn enc = reinterpret_cast<enc_fn>(dlsym(h, "spz_amd_encode_device"));
+        dec_fn dec = reinterpret_cast<dec_fn>(dlsym(h, "spz_amd_decode_device"));
+        for (const Place &pl : places) {
+          spz_amd_cloud_out out = {reinterpret_cast<float *>(pl.ptr[0]), reinterpret_cast<float *>(pl.ptr[1]), reinterpret_cast<float *>(pl.ptr[2]),
+                                   reinterpret_cast<float *>(pl.ptr[3]), reinterpret_cast<float *>(pl.ptr[4]), reinterpret_cast<float *>(pl.ptr[5])};
+          std::vector<float> te, td;
+          for (int r = 0; r < reps + 2; ++r) {
+            float ms;
+            CHECK(hipEventRecord(e0, nullptr));
+            if (enc(&g_in, kN, kDeg, 0, SPZ_AMD_RDF, 3, pl.ptr[6], g_stream_bytes, nullptr) != SPZ_AMD_OK) return 3;
+            CHECK(hipEventRecord(e1, nullptr));
+            CHECK(hipEventSynchronize(e1));
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (r >= 2) te.push_back(ms);
+            CHECK(hipEventRecord(e0, nullptr));
+            if (dec(pl.ptr[6], g_stream_bytes, &hdr, SPZ_AMD_RDF, &out, nullptr) != SPZ_AMD_OK) return 3;
+            CHECK(hipEventRecord(e1, nullptr));
+            CHECK(hipEventSynchronize(e1));
+            CHECK(hipEventElapsedTime(&ms, e0, e1));
+            if (r >= 2) td.push_back(ms);
+          }
+          std::sort(te.begin(), te.end());
+          std::sort(td.begin(), td.end());
+          std::printf("{\"kind\": \"variants\", \"exp\": \"variant\", \"variant\": \"%s\", \"place\": \"%s\", \"enc_ms\": %.4f, \"dec_ms\": %.4f}\n", name.c_str(),
+                      pl.name.c_str(), te[te.size() / 2], td[td.size() / 2]);
+          std::fflush(stdout);
+        }
+      }
+      for (int i = 0; i < K; ++i) CHECK(hipFree(chunk[i]));
+      continue;
+    }
+    if (kind == "pick") {  // the selection procedure: reference = sh inside the block of the rest (always the slow kind);
+                           // candidates = separate sh allocations, spacers in between; how often is a fast one found, how soon?
+      const uint64_t rest_bytes = up(base_rest_bytes(), 2 * MiB), sh_bytes = up(kFloats[5] * 4, 2 * MiB);
+      for (int trial = 0; trial < 12; ++trial) {
+        uint8_t *T = nullptr;
+        CHECK(hipMalloc(reinterpret_cast<void **>(&T), rest_bytes + sh_bytes));
+        auto rest_ptrs = [&](uint8_t *blk, uint8_t *shp, uint8_t *ptr[7]) {
+          uint64_t at = 0;
+          for (int k = 0; k < 7; ++k) {
+            if (k == 5) continue;
+            ptr[k] = blk + at;
+            at = up(at + (k < 6 ? kFloats[k] * 4 : g_stream_bytes), 2 * MiB);
+          }
+          ptr[5] = shp;
+        };
+        uint8_t *ptr[7];
+        rest_ptrs(T, T + rest_bytes, ptr);
+        const Timing ref = measure_ptrs(ptr, 3);
+        CHECK(hipDeviceSynchronize());
+        CHECK(hipFree(T));
+        uint8_t *R = nullptr;
+        CHECK(hipMalloc(reinterpret_cast<void **>(&R), rest_bytes));
+        std::vector<void *> held;
+        std::printf("{\"kind\": \"pick\", \"exp\": \"pick\", \"trial\": %d, \"ref_il_ms\": %.4f, \"ref_enc_ms\": %.4f, \"cand_il_ms\": [", trial, ref.dec_il, ref.enc);
+        for (int c = 0; c < 6; ++c) {
+          uint8_t *shp = nullptr;
+          CHECK(hipMalloc(reinterpret_cast<void **>(&shp), sh_bytes));
+          rest_ptrs(R, shp, ptr);
+          const Timing t = measure_ptrs(ptr, 3);
+          std::printf("%s%.4f", c ? ", " : "", t.dec_il);
+          held.push_back(shp);
+          void *sp = nullptr;
+          CHECK(hipMalloc(&sp, (uint64_t)(c + 1) * 6 * GiB));
+          held.push_back(sp);
+        }
+        std::printf("]}\n");
+        std::fflush(stdout);
+        CHECK(hipDeviceSynchronize());
+        for (void *h : held) CHECK(hipFree(h));
+        CHECK(hipFree(R));
+      }
       continue;
     }
     if (kind == "slabs") {  // a fresh slab per trial, packed layout

@@ -12,7 +12,18 @@ for r in rows:
 for r in rows:
     if r["exp"] == "bw":
         print(r["pass"], r["chunk"], r["ptr"], r["write_GBps"], r["read_GBps"])
-rows = [r for r in rows if r["exp"] not in ("row", "bw")]
+for r in rows:
+    if r["exp"] == "pick":
+        print("pick", r["trial"], "ref", r["ref_il_ms"], "cands", " ".join(f"{x:.3f}" for x in r["cand_il_ms"]))
+rows = [r for r in rows if r["exp"] != "pick"]
+vr = [r for r in rows if r["exp"] == "variant"]
+if vr:
+    places = sorted({r["place"] for r in vr}, key=lambda x: (x != "same", len(x), x))
+    print("variant      " + " ".join(f"{p:>13s}" for p in places) + "   (dec ms / enc ms)")
+    for name in dict.fromkeys(r["variant"] for r in vr):
+        cells = {r["place"]: r for r in vr if r["variant"] == name}
+        print(f"{name:12s} " + " ".join(f"{cells[p]['dec_ms']:.3f}/{cells[p]['enc_ms']:.3f}  " if p in cells else " " * 13 for p in places))
+rows = [r for r in rows if r["exp"] not in ("row", "bw", "variant")]
 for r in rows:
     if r["exp"] == "fresh":
         print(r["kind"], r["param_mib"], r["dec_seq_ms"], r["dec_il_ms"], r["enc_ms"])

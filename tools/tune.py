@@ -38,6 +38,9 @@ VARIANTS = {
     "il_g16": {"enc": "interleaved, runs of 16 tiles", "dec": "same", "defs": dict(_IL, SPZ_IL_GROUP=16)},
     "il_g64": {"enc": "interleaved, runs of 64 tiles", "dec": "same", "defs": dict(_IL, SPZ_IL_GROUP=64)},
     "il_rot_g8": {"enc": "rotation tiles only, runs of 8", "dec": "same", "defs": dict(_IL, SPZ_IL_ONLY_ROT=1, SPZ_IL_GROUP=8)},
+    "il_rot_g64": {"enc": "rotation tiles only, runs of 64", "dec": "same", "defs": dict(_IL, SPZ_IL_ONLY_ROT=1, SPZ_IL_GROUP=64)},
+    "il_g256": {"enc": "interleaved, runs of 256 tiles", "dec": "same", "defs": dict(_IL, SPZ_IL_GROUP=256)},
+    "il_g512": {"enc": "interleaved, runs of 512 tiles", "dec": "same", "defs": dict(_IL, SPZ_IL_GROUP=512)},
     "policy": {"enc": "shipped: interleave by policy, runs of 8", "dec": "same", "defs": {}},
     "policy_b": {"enc": "shipped, second copy (noise floor)", "dec": "same", "defs": {}},
     "mw1": {"enc": "policy, no minimum-waves bound (89 VGPRs, 5 waves per SIMD)", "dec": "policy", "defs": {"SPZ_ENC_MIN_WAVES": 1}},
