@@ -31,7 +31,7 @@ host:   $(LIBDIR)/libspz_host.so
 python: $(ROOT)spz_amd/spz$(PYEXT)
 cli:    $(ROOT)spz_amd/bin/spz_tool $(ROOT)spz_amd/bin/dropin_user_test $(ROOT)spz_amd/bin/host_bench
 
-DEVICE_SRCS := $(CSRC)/spz_kernels.hip $(CSRC)/spz_abi.hip $(CSRC)/spz_hostpath.hip $(CSRC)/spz_ply_kernels.hip $(CSRC)/spz_median.hip $(CSRC)/spz_exchange.hip $(CSRC)/spz_lz77.hip $(CSRC)/spz_inflate_dev.hip
+DEVICE_SRCS := $(CSRC)/spz_kernels.hip $(CSRC)/spz_abi.hip $(CSRC)/spz_hostpath.hip $(CSRC)/spz_ply_kernels.hip $(CSRC)/spz_median.hip $(CSRC)/spz_exchange.hip $(CSRC)/spz_lz77.hip $(CSRC)/spz_inflate_dev.hip $(CSRC)/spz_place.hip
 $(LIBDIR)/libspz_amd.so: $(DEVICE_SRCS) $(CSRC)/spz_common.hpp $(CSRC)/spz_kernel_params.hpp $(CSRC)/spz_lz77_core.hpp $(CSRC)/spz_huff_core.hpp $(CSRC)/spz_inflate_core.hpp $(INC)/spz_amd.h
 	mkdir -p $(LIBDIR)
 	$(HIPCC) $(HIPFLAGS) -shared -o $@ $(DEVICE_SRCS) -ldl

@@ -51,6 +51,9 @@ def parse():
                          "while sh is still encoding); torch = torch.distributed batch_isend_irecv; ipc = peers encode "
                          "straight into the root's stream over an IPC mapping.  auto = rccl on the nccl backend "
                          "(falls back to torch if the communicator cannot be made), torch on gloo")
+    ap.add_argument("--placement", default="probe", choices=["probe", "plain"],
+                    help="probe (default): the resident buffers come from spz_amd_cloud_buffers_alloc, which times a few "
+                         "placements of the sh arrays and keeps the fast kind (DESIGN §10); plain: torch allocations as they fall")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-whole-file", action="store_true", help="skip the saveSpz / loadSpz figure (outside the timed region)")
     ap.add_argument("--cpu-sample-points", type=int, default=0, help="0 = the whole per-GPU workload")
@@ -250,17 +253,38 @@ def main():
 
     n, deg, ver = args.points, args.sh_degree, args.version
     frm, to = COORD[args.from_coord], COORD[args.to_coord]
-    cloud = make_cloud_torch(n, deg, 3 + 47 * rank, dev)           # seeds 3, 50, 97, ... per rank
     lay = abi.stream_layout(n, deg, ver)
-    out = D.alloc_cloud(n, deg, dev)
     hdr = D.make_header(n, deg, ver)
-
     use_coll = distributed and not args.no_collective
     plan = shard.plan_from_counts([n] * world, deg, ver) if distributed else None
     # With the collective, stream buffers are double-buffered so that the gatherv of step k (link-bound,
     # on RCCL's own stream) overlaps the encode and decode kernels of steps k+1 and k+2.
     nbuf = 2 if use_coll else 1
-    streams = [torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
+    placement = {"method": "plain", "note": "torch allocations as they fall: which placement kind the sh arrays get is luck (DESIGN §10)"}
+    placed = []
+    if args.placement == "probe" and not use_coll:
+        # Where the sh arrays lie relative to the other buffers of a launch decides +-10 % of both kernels (DESIGN §10,
+        # profiles/r03_placement_*): the library makes the resident buffers and keeps, of a few placements it times with
+        # the launch itself, one of the fast kind.  Done once, before the data exists; not part of any timed region.
+        p_out = D.alloc_placed(n, deg, dev, ver, None, "decode")
+        p_in = D.alloc_placed(n, deg, dev, ver, p_out.stream, "encode")
+        placed = [p_out, p_in]
+        streams = [p_out.stream[:lay.total_bytes]]
+        out = p_out.cloud
+        cloud = p_in.cloud
+        gen = make_cloud_torch(n, deg, 3 + 47 * rank, dev)           # seeds 3, 50, 97, ... per rank
+        for k in FIELDS:
+            cloud[k].copy_(gen[k])
+        del gen
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        placement = {"method": "probe", "decode_buffers": p_out.report, "encode_buffers": p_in.report,
+                     "note": "spz_amd_cloud_buffers_alloc: the sh array in an allocation of its own, chosen among up to 6 by timing "
+                             "the launch on zeroed buffers before the data was made; outside every timed region"}
+    else:
+        cloud = make_cloud_torch(n, deg, 3 + 47 * rank, dev)           # seeds 3, 50, 97, ... per rank
+        out = D.alloc_cloud(n, deg, dev)
+        streams = [torch.empty(lay.total_bytes, dtype=torch.uint8, device=dev) for _ in range(nbuf)]
     stream = streams[0]
     global_streams = [None] * nbuf
     route = None
@@ -553,6 +577,7 @@ def main():
             "exchange_route": route, "exchange_route_note": route_note,
             "shards_only": shards_only,
             "config4_fused_vs_two_pass": two_pass,
+            "placement": placement,
         }
         if world == 1 and not args.no_cpu_baseline:
             def gpu_stream_fn(m):

@@ -212,6 +212,27 @@ int spz_amd_decode_gather_device(const uint8_t *d_stream, size_t size, const spz
                                  const uint32_t *d_indices, uint64_t count, int to_coord,
                                  const spz_amd_cloud_out *d_cloud, void *hip_stream);
 
+/* ---- device buffers for a resident cloud, placed for speed (spz_place.hip).  Whether an sh3 decode runs
+ *      at 0.46 ms or at 0.55 ms is decided by whether the sh float array shares a physical region of HBM with the other
+ *      arrays of the launch; that cannot be asked for, but it shows in one launch.  alloc: the five small arrays (and a
+ *      stream buffer, unless d_stream brings one) in one block, the sh array in an allocation of its own, chosen among
+ *      up to max_candidates (1 = the first) by timing the launch the buffers are for — probe 1: a decode (d_stream
+ *      read, cloud written), 2: an encode (cloud read, the stream OVERWRITTEN), 0: no timing — on `hip_stream`, with the
+ *      buffers' contents zeroed.  Blocking; tens of milliseconds, once per set of long-lived buffers.  The reference has
+ *      no counterpart (it holds clouds in host vectors); callers of the *_device entry points own their buffers and
+ *      may use this to make them. ------------------------------------------------------------------------------- */
+typedef struct {
+  spz_amd_cloud_out cloud;      /* six float arrays in device memory (sh NULL for degree 0) */
+  uint8_t *stream;              /* the stream buffer: this call's (stream_capacity bytes) or the caller's d_stream */
+  size_t stream_capacity;
+  void *owner;                  /* what spz_amd_cloud_buffers_free releases */
+  int32_t candidates;           /* sh placements timed (1 when nothing was timed) */
+  float probe_ms_first, probe_ms_chosen, probe_ms_worst;
+} spz_amd_cloud_buffers;
+int spz_amd_cloud_buffers_alloc(uint64_t num_points, int sh_degree, int version, uint8_t *d_stream, int probe,
+                                int max_candidates, void *hip_stream, spz_amd_cloud_buffers *out);
+int spz_amd_cloud_buffers_free(spz_amd_cloud_buffers *b);
+
 /* ---- GaussianCloud::convertCoordinates (splat-types.h:134-164) as a standalone in-place
  *      device pass (the reference-shaped, un-fused second pass; kept for API parity and
  *      for the fused-vs-unfused measurement).  Any of the three pointers may be NULL. ------- */
@@ -454,6 +475,10 @@ int spz_amd_inflate_equals_device(void *ctx, const uint8_t *d_expected, uint64_t
  * load-spz.cc:609-632) has one shape whichever reader inflated the member. */
 int spz_amd_stream_to_device(const uint8_t *h_stream, uint64_t nbytes, int device, void **ctx);
 uint32_t spz_amd_inflate_crc_piece_bytes(void);
+/* Why the last inflate_open(_device) of this thread returned SPZ_AMD_ERR_UNSUPPORTED ("" when it did not): one of
+ * size, stored-first, memory, no-block-starts, symbol-budget, expansion, no-final-block, not-linked, trailing-bytes,
+ * empty, window-chains, bad-reference.  The caller's host readers give the same bytes; this tells a slowdown's cause. */
+const char *spz_amd_inflate_last_decline(void);
 int spz_amd_inflate_piece_crcs(void *ctx, uint32_t *h_crcs, uint32_t capacity, uint32_t *num_pieces);
 int spz_amd_inflate_fetch(void *ctx, uint8_t *h_out);
 const uint8_t *spz_amd_inflate_device_data(void *ctx);

@@ -253,6 +253,9 @@ uint64_t deviceGzipRejectCount();
 // Members decompressGzipped has inflated on the device in this process (spz_inflate_dev.hip; SPZ_AMD_GUNZIP_DEVICE = 0
 // never, 1 from 1 MiB, unset: from 8 MiB); believed only after the CRC-32 and ISIZE of the trailer matched.
 uint64_t deviceInflateCount();
+// Why the device reader stood down the last time this thread asked it ("" = it did not, or was not asked): the names
+// spz_amd_inflate_last_decline() documents, or "crc" when it inflated something the trailer does not confirm.
+const char *deviceInflateLastDecline();
 // saveSpz keeps its transient stream buffer (65 bytes per Gaussian, at most 1 GiB) for the next save, because returning
 // memory that device copies have pinned costs ~80 ms per GB; this drops it.  (The device side: spz_amd_release_device_memory().)
 void releaseHostMemory();

@@ -55,7 +55,8 @@ EXPORTS = (
     "spz_amd_zlib_encode_group", "spz_amd_zlib_encode_finish", "spz_amd_zlib_parse_open_dev", "spz_amd_encode_host_keep", "spz_amd_kept_stream_release",
     "spz_amd_zlib_block_trees", "spz_amd_zlib_encode_planned", "spz_amd_zlib_encode_finish_ex",
     "spz_amd_inflate_open", "spz_amd_inflate_open_device", "spz_amd_inflate_equals_device", "spz_amd_inflate_crc_piece_bytes", "spz_amd_inflate_piece_crcs", "spz_amd_inflate_fetch",
-    "spz_amd_inflate_device_data", "spz_amd_inflate_close", "spz_amd_stream_to_device", "spz_amd_decode_gather_host_from_device",
+    "spz_amd_inflate_device_data", "spz_amd_inflate_close", "spz_amd_stream_to_device", "spz_amd_inflate_last_decline",
+    "spz_amd_cloud_buffers_alloc", "spz_amd_cloud_buffers_free", "spz_amd_decode_gather_host_from_device",
 )
 
 RCCL_UNIQUE_ID_BYTES = 128
@@ -82,6 +83,13 @@ class Layout(C.Structure):
 class CloudPtrs(C.Structure):
     """spz_amd_cloud_in / spz_amd_cloud_out (same layout: six pointers)."""
     _fields_ = [(k, C.c_void_p) for k in ("positions", "scales", "rotations", "alphas", "colors", "sh")]
+
+
+class CloudBuffers(C.Structure):
+    """spz_amd_cloud_buffers: device buffers made (and placed) by spz_amd_cloud_buffers_alloc."""
+    _fields_ = [("cloud", CloudPtrs), ("stream", C.c_void_p), ("stream_capacity", C.c_size_t), ("owner", C.c_void_p),
+                ("candidates", C.c_int32), ("probe_ms_first", C.c_float), ("probe_ms_chosen", C.c_float),
+                ("probe_ms_worst", C.c_float)]
 
 
 class PlyColumns(C.Structure):
@@ -157,6 +165,10 @@ def bind(L):
     L.spz_amd_median_scale_sum_device.argtypes = [vp, u64, vp, vp, vp]
     L.spz_amd_median_scale_sum_host.restype = i32
     L.spz_amd_median_scale_sum_host.argtypes = [vp, u64, vp, i32]
+    L.spz_amd_cloud_buffers_alloc.restype = i32
+    L.spz_amd_cloud_buffers_alloc.argtypes = [u64, i32, i32, vp, i32, i32, vp, C.POINTER(CloudBuffers)]
+    L.spz_amd_cloud_buffers_free.restype = i32
+    L.spz_amd_cloud_buffers_free.argtypes = [C.POINTER(CloudBuffers)]
     L.spz_amd_decode_gather_host.restype = i32
     L.spz_amd_decode_gather_host.argtypes = [vp, sz, u64, vp, u64, i32, C.POINTER(CloudPtrs), i32]
     L.spz_amd_convert_coordinates_device.restype = i32

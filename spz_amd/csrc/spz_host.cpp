@@ -865,6 +865,8 @@ namespace {
 // of 8 MiB and more on hosts with fewer than 32 usable CPUs.  The result is believed only when its length matches ISIZE and its CRC-32 the trailer's.
 std::atomic<uint64_t> g_device_inflates{0};
 
+thread_local const char *g_inflate_decline = "";  // deviceInflateLastDecline()
+
 // Inflates the member on the device and checks length and CRC-32 against its trailer; nullptr: declined or wrong.
 void *openVerifiedDeviceInflate(const uint8_t *gz, size_t size, size_t header_len, uint64_t *out_bytes) {
   const char *e = std::getenv("SPZ_AMD_GUNZIP_DEVICE");
@@ -881,7 +883,12 @@ void *openVerifiedDeviceInflate(const uint8_t *gz, size_t size, size_t header_le
   };
   const uint32_t want_crc = le32(gz + size - 8), isize = le32(gz + size - 4);
   void *ctx = nullptr;
-  if (spz_amd_inflate_open(gz + header_len, nbytes, deviceIndex(), &ctx, out_bytes) != SPZ_AMD_OK) return nullptr;
+  g_inflate_decline = "";
+  const int open_rc = spz_amd_inflate_open(gz + header_len, nbytes, deviceIndex(), &ctx, out_bytes);
+  if (open_rc != SPZ_AMD_OK) {
+    g_inflate_decline = open_rc == SPZ_AMD_ERR_UNSUPPORTED ? spz_amd_inflate_last_decline() : spz_amd_status_string(open_rc);
+    return nullptr;
+  }
   bool ok = static_cast<uint32_t>(*out_bytes & 0xffffffffull) == isize;
   if (ok) {
     const uint32_t piece = spz_amd_inflate_crc_piece_bytes();
@@ -899,6 +906,7 @@ void *openVerifiedDeviceInflate(const uint8_t *gz, size_t size, size_t header_le
     }
   }
   if (!ok) {
+    g_inflate_decline = "crc";
     spz_amd_inflate_close(ctx);
     return nullptr;
   }
@@ -929,6 +937,7 @@ bool inflateOnDevice(const uint8_t *gz, size_t size, size_t header_len, std::vec
 }  // namespace
 
 uint64_t deviceInflateCount() { return g_device_inflates.load(); }
+const char *deviceInflateLastDecline() { return g_inflate_decline; }
 
 namespace {
 bool decompressGzippedWith(const uint8_t *compressed, size_t size, std::vector<uint8_t> *out, bool try_device);

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <condition_variable>
 #include <cstdint>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <system_error>
@@ -183,7 +184,13 @@ void scratch_release(int device, void *block) {
       if (largest < 0 || slots[i].bytes > slots[largest].bytes) largest = i;
     }
     if (largest < 0 || idle_total <= keep) break;
-    (void)hipFree(slots[largest].ptr);
+    (void)hipDeviceSynchronize();  // nothing of the call that used the block may still be queued when it goes
+    const hipError_t e = hipFree(slots[largest].ptr);
+    if (std::getenv("SPZ_AMD_LZ_TIMING")) {
+      std::fprintf(stderr, "[scratch] idle %zu MiB > budget %zu MiB: freed a block of %zu MiB (%s)\n", idle_total >> 20, keep >> 20,
+                   slots[largest].bytes >> 20, hipGetErrorString(e));
+    }
+    if (e != hipSuccess) g_last_hip_error = (int)e;
     slots[largest] = ScratchSlot();
   }
 }

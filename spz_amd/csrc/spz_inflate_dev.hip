@@ -636,6 +636,15 @@ struct InfContext {
 
 size_t round256(size_t v) { return (v + 255) / 256 * 256; }
 
+// Why the device reader last stood down on this thread ("" = it did not): the caller's host readers produce the same
+// bytes, so a decline shows only as time — spz_amd_inflate_last_decline() says what to look at.
+thread_local const char *g_last_decline = "";
+int decline(const char *reason) {
+  g_last_decline = reason;
+  if (std::getenv("SPZ_AMD_LZ_TIMING")) std::fprintf(stderr, "[inflate] declined: %s\n", reason);
+  return SPZ_AMD_ERR_UNSUPPORTED;
+}
+
 }  // namespace
 }  // namespace spz_amd_detail
 
@@ -649,14 +658,15 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
                              uint64_t *out_bytes) {
   if ((h_deflate == nullptr) == (d_deflate == nullptr) || ctx == nullptr || out_bytes == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
   *ctx = nullptr;
-  if (nbytes < 4ull * kMinChunkBytes || nbytes >= (1ull << 32)) return SPZ_AMD_ERR_UNSUPPORTED;
+  g_last_decline = "";
+  if (nbytes < 4ull * kMinChunkBytes || nbytes >= (1ull << 32)) return decline("size");  // under 256 KiB of deflate data, or 4 GiB and more
   DeviceGuard guard;
   int rc = guard.enter(device);
   if (rc != SPZ_AMD_OK) return rc;
   uint8_t first_byte = 0;
   if (h_deflate != nullptr) first_byte = h_deflate[0];
   else SPZ_HIP_TRY(hipMemcpy(&first_byte, d_deflate, 1, hipMemcpyDeviceToHost));
-  if (((first_byte >> 1) & 3) == 0) return SPZ_AMD_ERR_UNSUPPORTED;  // opens with a stored block: nothing to gain
+  if (((first_byte >> 1) & 3) == 0) return decline("stored-first");  // opens with a stored block: nothing to gain
   static const bool timing = std::getenv("SPZ_AMD_LZ_TIMING") != nullptr;
   // SPZ_AMD_INFLATE_EXPERIMENT (measurements only; bit 0: matches are counted but not copied — the result is wrong and
   // the CRC check sends the caller to the host readers)
@@ -701,7 +711,7 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
   size_t free_b = 0;
   rc = device_free_bytes(device, &free_b);
   if (rc != SPZ_AMD_OK) return rc;
-  if (total + (size_t)nbytes * kExpand + (size_t(512) << 20) > free_b) return SPZ_AMD_ERR_UNSUPPORTED;
+  if (total + (size_t)nbytes * kExpand + (size_t(512) << 20) > free_b) return decline("memory");
   char *block = nullptr;
   rc = scratch_acquire(device, total, reinterpret_cast<void **>(&block));
   if (rc != SPZ_AMD_OK) return rc;
@@ -744,7 +754,7 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
     jobs.push_back({starts[i], NONE, 0, 0, 0});
   }
   uint32_t n = (uint32_t)jobs.size();
-  if (n < 2) return SPZ_AMD_ERR_UNSUPPORTED;
+  if (n < 2) return decline("no-block-starts");
   if (timing) std::fprintf(stderr, "[inflate] %u of %u chunks have a block start\n", n, n_chunks);
   unsigned long long region = 0;
   for (uint32_t j = 0; j < n; ++j) {
@@ -754,7 +764,7 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
     jobs[j].capacity = ((span_bits / 8 + 1) * kExpand + 32 + 63) / 64 * 64;  // regions stay 128-byte aligned
     region += jobs[j].capacity;
   }
-  if (region > sym_capacity) return SPZ_AMD_ERR_UNSUPPORTED;
+  if (region > sym_capacity) return decline("symbol-budget");
   // ---- 2. decode.  A chunk that does not end exactly at its successor's block start has met a look-alike (raw bytes
   // of a stored block that read like a header): the successor is dropped, the chunk takes its range and region and
   // is decoded again.  Chunk 0 starts at a true block start, so this is sound by induction.
@@ -776,12 +786,12 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
     for (size_t k = 0; k < live.size(); ++k) {
       const uint32_t j = live[k];
       const bool last = k + 1 == live.size();
-      if (res[j].overflow) return SPZ_AMD_ERR_UNSUPPORTED;
+      if (res[j].overflow) return decline("expansion");  // a chunk that expands more than 8 x
       if (res[j].outcome == (uint32_t)(last ? FINAL : LINKED)) {
         next_live.push_back(j);
         continue;
       }
-      if (last) return SPZ_AMD_ERR_UNSUPPORTED;  // the final block was not reached: not this reader's case
+      if (last) return decline("no-final-block");  // the final block was not reached: not this reader's case (or damage)
       const uint32_t drop = live[k + 1];           // its block start was not one
       jobs[j].to = jobs[drop].to;
       jobs[j].capacity += jobs[drop].capacity;     // regions are adjacent
@@ -795,7 +805,7 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
     linked = todo.empty();
     if (timing && !linked) std::fprintf(stderr, "[inflate] round %u: %zu chunks decoded again\n", round, todo.size());
   }
-  if (!linked) return SPZ_AMD_ERR_UNSUPPORTED;
+  if (!linked) return decline("not-linked");  // look-alike block starts left after 8 rounds
   lap("decode");
   if (timing) {
     unsigned long long rounds = 0, matches = 0, miss = 0, syms = 0;
@@ -815,9 +825,9 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
     place[k] = {jobs[j].region, res[j].length, offset};
     offset += res[j].length;
   }
-  if (((res[live[n - 1]].end_bit + 7) >> 3) != nbytes) return SPZ_AMD_ERR_UNSUPPORTED;  // the stream must end exactly at the trailer
+  if (((res[live[n - 1]].end_bit + 7) >> 3) != nbytes) return decline("trailing-bytes");  // the stream must end exactly at the trailer
   const uint64_t total_out = offset;
-  if (total_out == 0) return SPZ_AMD_ERR_UNSUPPORTED;
+  if (total_out == 0) return decline("empty");
   SPZ_HIP_TRY(hipMemcpyAsync(d_place, place.data(), (size_t)n * sizeof(ChunkPlace), hipMemcpyHostToDevice, st));
   // ---- 3. windows, 4. place, 5. piece CRCs
   const uint32_t n_pieces = (uint32_t)((total_out + kCrcPiece - 1) / kCrcPiece);
@@ -842,7 +852,7 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
       SPZ_HIP_TRY(hipStreamSynchronize(st));
       if (timing && pending) std::fprintf(stderr, "[inflate] window pass %u: %u entries still open\n", pass, pending);
     }
-    if (pending != 0) return SPZ_AMD_ERR_UNSUPPORTED;  // bytes carried through more than 2048 chunks: the host readers
+    if (pending != 0) return decline("window-chains");  // bytes carried through more than 2048 chunks: the host readers
   }
   lap("windows");
   hipLaunchKernelGGL(inf_place_kernel, dim3(16, n), dim3(256), 0, st, d_sym, d_place, d_win, d_out, d_bad);
@@ -853,7 +863,7 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
   SPZ_HIP_TRY(hipMemcpyAsync(&bad, d_bad, sizeof(bad), hipMemcpyDeviceToHost, st));
   SPZ_HIP_TRY(hipStreamSynchronize(st));
   lap("place+crc");
-  if (bad) return SPZ_AMD_ERR_UNSUPPORTED;
+  if (bad) return decline("bad-reference");  // a reference where there is no predecessor
   InfContext *c = new (std::nothrow) InfContext();
   if (c == nullptr) return SPZ_AMD_ERR_HIP;
   c->device = device;
@@ -933,6 +943,8 @@ int spz_amd_inflate_equals_device(void *ctx, const uint8_t *d_expected, uint64_t
   SPZ_HIP_TRY(hipStreamSynchronize(st));
   return diff == 0 ? SPZ_AMD_OK : SPZ_AMD_ERR_VERIFY;
 }
+
+const char *spz_amd_inflate_last_decline(void) { return g_last_decline; }
 
 uint32_t spz_amd_inflate_crc_piece_bytes(void) { return kCrcPiece; }
 

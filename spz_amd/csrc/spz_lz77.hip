@@ -560,7 +560,7 @@ struct HeaderSink {
 
 __global__ __launch_bounds__(64) void lz_header_kernel(spz_amd_deflate_block *__restrict__ blocks, spz_amd_deflate_codes *__restrict__ codes,
                                                        const BlockTrees *__restrict__ trees, uint32_t *__restrict__ header,
-                                                       uint32_t num_blocks) {
+                                                       uint32_t *__restrict__ header_bits, uint32_t num_blocks) {
   const uint32_t b = blockIdx.x * 64u + threadIdx.x;
   if (b >= num_blocks) return;
   const spz_amd_deflate_block blk = blocks[b];
@@ -605,6 +605,7 @@ __global__ __launch_bounds__(64) void lz_header_kernel(spz_amd_deflate_block *__
   blocks[b].header_word_begin = b * kHeaderStride;
   blocks[b].header_words = s.words;
   blocks[b].header_bits = s.total;
+  header_bits[b] = s.total;
 }
 
 constexpr uint32_t kEncodeThreads = 256;
@@ -719,6 +720,7 @@ struct LzContext {
   uint64_t part_end[kBodyParts] = {};  // byte offsets in the body
   int n_parts = 0;
   uint32_t validated_blocks = 0;       // blocks lz_validate_kernel has been enqueued for since the body was zeroed
+  bool header_bits_dense = false;      // lz_header_kernel has filled EncodeArrays::header_bits (encode_planned)
 };
 
 // One copy stream and its events per device, made once (creating and destroying them per call cost what the overlap
@@ -1076,6 +1078,7 @@ struct EncodeArrays {
   BlockTrees *trees;
   spz_amd_deflate_plan *plan;
   uint32_t *invalid;       // lz_validate_kernel's count of blocks' threads that found a symbol wrong
+  uint32_t *header_bits;   // every block's header length, dense (what encode_finish_ex hands back)
   uint32_t *header;
   size_t header_capacity;  // words
 };
@@ -1093,6 +1096,7 @@ static bool encode_arrays(LzContext *c, uint32_t total_blocks, EncodeArrays *a) 
   a->trees = reinterpret_cast<BlockTrees *>(carve((size_t)total_blocks * sizeof(BlockTrees)));
   a->plan = reinterpret_cast<spz_amd_deflate_plan *>(carve((size_t)total_blocks * sizeof(spz_amd_deflate_plan)));
   a->invalid = reinterpret_cast<uint32_t *>(carve(sizeof(uint32_t)));
+  a->header_bits = reinterpret_cast<uint32_t *>(carve((size_t)total_blocks * sizeof(uint32_t)));
   if (off + 4096 > c->scratch_b_bytes) return false;
   a->header = reinterpret_cast<uint32_t *>(c->scratch_b + off);
   a->header_capacity = (c->scratch_b_bytes - off) / sizeof(uint32_t);
@@ -1187,9 +1191,9 @@ int spz_amd_zlib_encode_finish_ex(void *ctx, uint32_t total_blocks, uint64_t bod
       return SPZ_AMD_ERR_INVALID_ARG;  // not the body encode_planned was given
     }
     SPZ_HIP_TRY(hipMemcpyAsync(h_symbol_bits, a.bits, (size_t)total_blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost, c->lane->stream));
-    if (h_header_bits != nullptr) {
-      SPZ_HIP_TRY(hipMemcpy2DAsync(h_header_bits, sizeof(uint32_t), &a.blocks[0].header_bits, sizeof(spz_amd_deflate_block),
-                                   sizeof(uint32_t), total_blocks, hipMemcpyDeviceToHost, c->lane->stream));
+    if (h_header_bits != nullptr) {  // dense: a strided hipMemcpy2DAsync out of the block kept the block's memory after hipFree
+      if (!c->header_bits_dense) return SPZ_AMD_ERR_INVALID_ARG;
+      SPZ_HIP_TRY(hipMemcpyAsync(h_header_bits, a.header_bits, (size_t)total_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, c->lane->stream));
     }
     SPZ_HIP_TRY(hipStreamSynchronize(c->lane->stream));
     SPZ_HIP_TRY(hipMemcpyAsync(&invalid, a.invalid, sizeof(invalid), hipMemcpyDeviceToHost, st));  // behind lz_validate_kernel
@@ -1206,8 +1210,8 @@ int spz_amd_zlib_encode_finish_ex(void *ctx, uint32_t total_blocks, uint64_t bod
   SPZ_HIP_TRY(hipMemcpyAsync(h_body, c->scratch_a, body_bytes, hipMemcpyDeviceToHost, st));
   SPZ_HIP_TRY(hipMemcpyAsync(h_symbol_bits, a.bits, (size_t)total_blocks * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   if (h_header_bits != nullptr) {
-    SPZ_HIP_TRY(hipMemcpy2DAsync(h_header_bits, sizeof(uint32_t), &a.blocks[0].header_bits, sizeof(spz_amd_deflate_block),
-                                 sizeof(uint32_t), total_blocks, hipMemcpyDeviceToHost, st));
+    if (!c->header_bits_dense) return SPZ_AMD_ERR_INVALID_ARG;  // the header lengths are the device's only after encode_planned
+    SPZ_HIP_TRY(hipMemcpyAsync(h_header_bits, a.header_bits, (size_t)total_blocks * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
   }
   SPZ_HIP_TRY(hipMemcpyAsync(&invalid, a.invalid, sizeof(invalid), hipMemcpyDeviceToHost, st));
   SPZ_HIP_TRY(hipStreamSynchronize(st));
@@ -1273,7 +1277,9 @@ int spz_amd_zlib_encode_planned(void *ctx, const spz_amd_deflate_static *tables,
   SPZ_HIP_TRY(hipMemcpyAsync(a.tables, tables, sizeof(*tables), hipMemcpyHostToDevice, st));
   SPZ_HIP_TRY(hipMemcpyAsync(a.blocks, h_blocks, (size_t)num_blocks * sizeof(spz_amd_deflate_block), hipMemcpyHostToDevice, st));
   SPZ_HIP_TRY(hipMemsetAsync(a.invalid, 0, sizeof(uint32_t), st));
-  hipLaunchKernelGGL(lz_header_kernel, dim3((num_blocks + 63) / 64), dim3(64), 0, st, a.blocks, a.codes, a.trees, a.header, num_blocks);
+  hipLaunchKernelGGL(lz_header_kernel, dim3((num_blocks + 63) / 64), dim3(64), 0, st, a.blocks, a.codes, a.trees, a.header, a.header_bits,
+                     num_blocks);
+  c->header_bits_dense = true;
   SPZ_HIP_TRY(hipGetLastError());
   // in a few launches, so that the body's first parts are on their way to the host while the later ones are packed
   if (c->lane == nullptr) c->lane = copy_lane_acquire(c->device);

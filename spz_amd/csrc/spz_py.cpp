@@ -347,6 +347,8 @@ PYBIND11_MODULE(spz, m) {
      "(links, match tables, lazy state machine, record-window splice); None when declined.");
   m.def("_device_inflate_count", []() { return spz::deviceInflateCount(); },
         "gzip members inflated on the device so far.");
+  m.def("_device_inflate_last_decline", []() { return std::string(spz::deviceInflateLastDecline()); },
+        "Why the device reader last stood down on this thread ('' = it did not).");
   m.def("_device_gzip_parse_count", []() { return spz::deviceGzipParseCount(); },
         "gzip members written so far with their LZ77 parse done on the device.");
   m.def("_device_gzip_reject_count", []() { return spz::deviceGzipRejectCount(); },

@@ -38,6 +38,64 @@ def alloc_cloud(n, sh_degree, device):
     return {k: torch.empty(n * floats_per_point(k, sh_degree), dtype=torch.float32, device=device) for k in FIELDS}
 
 
+class _DeviceArray:
+    """A typed view of device memory somebody else owns (kept alive through `owner`), for torch.as_tensor."""
+
+    def __init__(self, ptr, count, typestr, owner):
+        self.ptr, self.count, self.typestr, self.owner = int(ptr), int(count), typestr, owner
+
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.count,), "typestr": self.typestr, "data": (self.ptr, False), "version": 2, "strides": None}
+
+
+class PlacedBuffers:
+    """Device buffers of one resident cloud made by spz_amd_cloud_buffers_alloc (spz_place.hip): `cloud` is the usual
+    dict of flat float32 CUDA tensors, `stream` a uint8 CUDA tensor (this object's, or the caller's), `report` what
+    the placement probe saw.  The memory goes when the object does (or at free()); tensors made from it must not
+    outlive it."""
+
+    def __init__(self, raw, n, sh_degree, device, stream_tensor=None):
+        self._raw, self._freed = raw, False
+        self.cloud = {}
+        for k in FIELDS:
+            cnt = n * floats_per_point(k, sh_degree)
+            ptr = getattr(raw.cloud, k)
+            self.cloud[k] = (torch.as_tensor(_DeviceArray(ptr, cnt, "<f4", self), device=device) if cnt
+                             else torch.empty(0, dtype=torch.float32, device=device))
+        self.stream = stream_tensor if stream_tensor is not None else torch.as_tensor(
+            _DeviceArray(raw.stream, raw.stream_capacity, "|u1", self), device=device)
+        self.report = {"sh_placements_timed": int(raw.candidates), "probe_ms_first": round(float(raw.probe_ms_first), 4),
+                       "probe_ms_chosen": round(float(raw.probe_ms_chosen), 4), "probe_ms_slowest": round(float(raw.probe_ms_worst), 4)}
+
+    def free(self):
+        if not self._freed:
+            self._freed = True
+            self.cloud, self.stream = {}, None
+            abi.load_library().spz_amd_cloud_buffers_free(C.byref(self._raw))
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:  # noqa: BLE001  (interpreter shutdown)
+            pass
+
+
+def alloc_placed(n, sh_degree, device, version=3, stream_t=None, probe="decode", max_candidates=6, stream=None):
+    """Buffers for a resident cloud of n points with the sh array placed for speed: the library times the
+    launch they are for — probe "decode" (stream read, cloud written), "encode" (cloud read; the stream is OVERWRITTEN
+    with zeros' code) or None — on up to `max_candidates` placements of the sh array and keeps the fastest.  `stream_t`:
+    an existing stream tensor to place against (otherwise one is allocated with the small arrays)."""
+    L = abi.load_library()
+    raw = abi.CloudBuffers()
+    mode = {None: 0, "none": 0, "decode": 1, "encode": 2}[probe]
+    with torch.cuda.device(device):
+        rc = L.spz_amd_cloud_buffers_alloc(int(n), int(sh_degree), int(version), stream_t.data_ptr() if stream_t is not None else None,
+                                           mode, int(max_candidates), _stream_handle(stream), C.byref(raw))
+    abi.check(rc, "spz_amd_cloud_buffers_alloc")
+    return PlacedBuffers(raw, n, sh_degree, device, stream_t)
+
+
 def make_header(num_points, sh_degree, version=3, fractional_bits=12, antialiased=False):
     return abi.Header(int(version), int(num_points), int(sh_degree), int(fractional_bits),
                       1 if antialiased else 0, 0)

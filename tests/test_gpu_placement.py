@@ -1,0 +1,70 @@
+"""spz_amd_cloud_buffers_alloc (spz_place.hip): device buffers for a resident cloud whose sh array is placed by timing
+the launch.  Placement must never change a result: streams encoded from, and floats decoded into, placed
+buffers are the oracle's, bit for bit; the report says what was timed; small clouds are not timed at all."""
+import numpy as np
+import pytest
+
+from conftest import FIELDS
+
+pytestmark = pytest.mark.gpu
+
+
+def test_placed_buffers_give_the_oracles_bytes_and_floats(cuda, oracle):
+    import torch
+    from spz_amd import abi, device as D
+    from spz_amd.synth import make_cloud_numpy
+    n, deg = 200_003, 3
+    c = make_cloud_numpy(n, deg, 5)
+    p_out = D.alloc_placed(n, deg, cuda, 3, None, "decode")
+    p_in = D.alloc_placed(n, deg, cuda, 3, p_out.stream, "encode")
+    assert p_out.report["sh_placements_timed"] == 1 and p_out.report["probe_ms_chosen"] == 0.0   # 36 MB of sh: not timed
+    for k in FIELDS:
+        p_in.cloud[k].copy_(torch.from_numpy(c[k]))
+    lay = abi.stream_layout(n, deg, 3)
+    s = D.encode(p_in.cloud, n, deg, True, abi.RDF, 3, out=p_out.stream[:lay.total_bytes])
+    torch.cuda.synchronize()
+    want = oracle.pack(c, n, deg, True, abi.RDF)
+    assert np.array_equal(s.cpu().numpy(), want)
+    d = D.decode(s, D.make_header(n, deg, 3, 12, True), abi.LUF, out=p_out.cloud)
+    torch.cuda.synchronize()
+    rc, w = oracle.unpack(want, abi.LUF)
+    assert rc == 0
+    for k in FIELDS:
+        assert np.array_equal(d[k].cpu().numpy().view(np.uint32), w[k].view(np.uint32)), k
+    p_in.free()
+    p_out.free()
+    assert p_out.cloud == {} and p_out.stream is None
+
+
+def test_large_clouds_are_timed_and_the_choice_is_never_the_slowest(cuda):
+    """6 M SH3 points (1.08 GB of sh floats): the probe runs the real kernels; the report is consistent, the chosen
+    placement is the fastest seen, and the buffers work (a decode into them equals a decode into torch's)."""
+    import torch
+    from spz_amd import abi, device as D
+    from spz_amd.synth import make_cloud_torch
+    n, deg = 6_000_000, 3
+    p_out = D.alloc_placed(n, deg, cuda, 3, None, "decode", max_candidates=4)
+    r = p_out.report
+    assert 1 <= r["sh_placements_timed"] <= 4
+    assert 0.0 < r["probe_ms_chosen"] <= r["probe_ms_first"] <= r["probe_ms_slowest"]
+    cloud = make_cloud_torch(n, deg, 9, cuda)
+    lay = abi.stream_layout(n, deg, 3)
+    s = D.encode(cloud, n, deg, False, abi.RUB, 3, out=p_out.stream[:lay.total_bytes])
+    hdr = D.make_header(n, deg, 3)
+    a = D.decode(s, hdr, abi.RDF, out=p_out.cloud)
+    b = D.decode(s, hdr, abi.RDF)
+    torch.cuda.synchronize()
+    for k in FIELDS:
+        assert torch.equal(a[k].view(torch.int32), b[k].view(torch.int32)), k
+    p_out.free()
+
+
+def test_degree_zero_and_bad_arguments(cuda):
+    from spz_amd import abi, device as D
+    p = D.alloc_placed(1000, 0, cuda, 2, None, "decode")
+    assert p.cloud["sh"].numel() == 0 and p.cloud["positions"].numel() == 3000
+    p.free()
+    with pytest.raises(abi.SpzAmdError):
+        D.alloc_placed(0, 3, cuda)
+    with pytest.raises(abi.SpzAmdError):
+        D.alloc_placed(10, 5, cuda)

@@ -64,7 +64,7 @@ def build(names):
         cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off",
                "-fno-fast-math", "-fhip-fp32-correctly-rounded-divide-sqrt", f"-I{ROOT}/include", "-shared",
                "-o", out] + [os.path.join(ROOT, "spz_amd", "csrc", f) for f in
-                             ("spz_kernels.hip", "spz_abi.hip", "spz_hostpath.hip", "spz_ply_kernels.hip", "spz_median.hip", "spz_exchange.hip", "spz_lz77.hip", "spz_inflate_dev.hip")] + ["-ldl"] + defs
+                             ("spz_kernels.hip", "spz_abi.hip", "spz_hostpath.hip", "spz_ply_kernels.hip", "spz_median.hip", "spz_exchange.hip", "spz_lz77.hip", "spz_inflate_dev.hip", "spz_place.hip")] + ["-ldl"] + defs
         print(" ".join(cmd[-4:]), flush=True)
         subprocess.run(cmd, check=True)
 
