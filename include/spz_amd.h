@@ -442,6 +442,24 @@ int spz_amd_zlib_encode_finish(void *ctx, uint32_t total_blocks, uint64_t body_b
                                uint64_t *h_symbol_bits);
 int spz_amd_zlib_encode_finish_ex(void *ctx, uint32_t total_blocks, uint64_t body_bytes, uint8_t *h_body,
                                   uint64_t *h_symbol_bits, uint32_t *h_header_bits /* may be NULL */);
+/* The same parse with its table and match stages fed while the input is still being produced (saveSpz: the quantise step's
+ * sections become final one after the other while the floats upload, and the device would idle through that upload).
+ * session_open(size): the parse's device memory for an input of `size` bytes (SPZ_AMD_ERR_UNSUPPORTED: declined, as
+ * parse_open_dev would).  session_feed: bytes [0, final_upto) of d_stream are final once the work queued on
+ * `producer_stream` so far is done — they are copied and the table / match kernels for what they cover are enqueued on
+ * the session's own stream; returns at once; final_upto must not decrease.  parse_open_session consumes the session
+ * (also on failure): whatever has not been fed comes from d_stream (all of it final by now) and the call goes on as
+ * parse_open_dev.  session_close: for a session that is not going to be consumed.  spz_amd_encode_host_keep_session is
+ * spz_amd_encode_host_keep feeding such a session: the five small sections of all points first, then sh chunk by chunk. */
+int spz_amd_zlib_session_open(uint64_t size, int device, void **session);
+int spz_amd_zlib_session_feed(void *session, const uint8_t *d_stream, uint64_t final_upto, void *producer_stream);
+void spz_amd_zlib_session_close(void *session);
+int spz_amd_zlib_parse_open_session(void *session, const uint8_t *h_data, const uint8_t *d_stream, uint64_t size, uint64_t tail_begin,
+                                    const uint32_t *h_tail_rec, uint32_t n_rec, void **ctx, uint64_t *num_symbols,
+                                    uint32_t *tail_first_symbol, void (*produce_tail_rec)(void *), void *produce_arg);
+int spz_amd_encode_host_keep_session(const spz_amd_cloud_in *h_cloud, uint64_t num_points, int sh_degree, int antialiased,
+                                     int from_coord, int version, uint8_t *h_stream, size_t capacity, int device,
+                                     const uint8_t **d_stream, void *zlib_session);
 /* Every encode_finish(_ex) returns SPZ_AMD_ERR_VERIFY instead of a body when the symbols it was coded from do not
  * reproduce the input (checked on the device for every block, always: each literal is its input byte, each match
  * copies equal bytes from at most 32 KiB back, each block covers exactly its input range).

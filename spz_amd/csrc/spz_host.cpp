@@ -421,22 +421,35 @@ bool verifiedExact(const uint8_t *data, size_t size, const std::vector<uint8_t> 
 std::atomic<uint64_t> g_device_rejects{0};  // members of the device writer that failed a check and were not returned
 
 // The LZ77 parse of the exact writer on the MI355X (spz_lz77.hip): SPZ_AMD_GZIP_DEVICE = 0 never, 1 whenever a
-// device answers, unset: for inputs of 8 MiB and more when a device answers.
+// device answers, unset: for inputs of 2 MiB and more when a device answers.
 struct DeviceHeadParser final : exactgz::HeadParser {
   void *ctx = nullptr;
   int status = SPZ_AMD_OK;
   const uint8_t *d_copy = nullptr;  // the input's bytes on the device already (saveSpz), or null
-  ~DeviceHeadParser() override { spz_amd_zlib_parse_close(ctx); }
+  void *session = nullptr;          // a parse whose first stages were fed while the input was produced (saveSpz), or null
+  ~DeviceHeadParser() override {
+    spz_amd_zlib_parse_close(ctx);
+    spz_amd_zlib_session_close(session);
+  }
+  int open(const uint8_t *data, size_t size, uint64_t tail_begin, const uint32_t *tail_rec, uint32_t n_rec, void (*produce)(void *),
+           void *arg, uint64_t *num_symbols, uint32_t *tail_first_symbol) {
+    if (session != nullptr) {  // consumed by the call, whatever it returns
+      void *q = session;
+      session = nullptr;
+      return spz_amd_zlib_parse_open_session(q, data, d_copy, size, tail_begin, tail_rec, n_rec, &ctx, num_symbols, tail_first_symbol,
+                                             produce, arg);
+    }
+    return spz_amd_zlib_parse_open_dev(data, d_copy, size, tail_begin, tail_rec, n_rec, deviceIndex(), &ctx, num_symbols,
+                                       tail_first_symbol, produce, arg);
+  }
   bool parse(const uint8_t *data, size_t size, uint64_t tail_begin, const uint32_t *tail_rec, uint32_t n_rec,
              uint64_t *num_symbols, uint32_t *tail_first_symbol) override {
-    status = spz_amd_zlib_parse_open_dev(data, d_copy, size, tail_begin, tail_rec, n_rec, deviceIndex(), &ctx, num_symbols,
-                                         tail_first_symbol, nullptr, nullptr);
+    status = open(data, size, tail_begin, tail_rec, n_rec, nullptr, nullptr, num_symbols, tail_first_symbol);
     return status == SPZ_AMD_OK;
   }
   bool parseLate(const uint8_t *data, size_t size, uint64_t tail_begin, const uint32_t *tail_rec, uint32_t n_rec,
                  void (*produce)(void *), void *arg, uint64_t *num_symbols, uint32_t *tail_first_symbol) override {
-    status = spz_amd_zlib_parse_open_dev(data, d_copy, size, tail_begin, tail_rec, n_rec, deviceIndex(), &ctx, num_symbols,
-                                         tail_first_symbol, produce, arg);
+    status = open(data, size, tail_begin, tail_rec, n_rec, produce, arg, num_symbols, tail_first_symbol);
     return status == SPZ_AMD_OK;
   }
   bool fetch(uint16_t *dist, uint8_t *lc) override {
@@ -488,7 +501,9 @@ bool deviceParseWanted(size_t size) {
   const char *e = std::getenv("SPZ_AMD_GZIP_DEVICE");
   if (e && e[0] == '0') return false;
   const bool forced = e && e[0] == '1';
-  if (!forced && size < (size_t(8) << 20)) return false;
+  // profiles/r03_size_sweep.json: the device writer wins from the smallest stream measured (60 k points SH3, 3.9 MB:
+  // 13 ms against 53 ms for the multi-threaded host writer on the box's 16 CPUs)
+  if (!forced && size < (size_t(2) << 20)) return false;
   return spz_amd_device_count() > 0;
 }
 
@@ -500,14 +515,23 @@ uint64_t deviceGzipParseCount() { return g_device_parses.load(); }
 uint64_t deviceGzipRejectCount() { return g_device_rejects.load(); }
 
 namespace {
-bool compressGzippedWithCopy(const uint8_t *data, size_t size, std::vector<uint8_t> *out, const uint8_t *d_copy);
+bool compressGzippedWithCopy(const uint8_t *data, size_t size, std::vector<uint8_t> *out, const uint8_t *d_copy, void **session = nullptr);
 }
 bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out) {
   return compressGzippedWithCopy(data, size, out, nullptr);
 }
 namespace {
-// d_copy: the same bytes on the device (spz_amd_encode_host_keep), or null
-bool compressGzippedWithCopy(const uint8_t *data, size_t size, std::vector<uint8_t> *out, const uint8_t *d_copy) {
+// d_copy: the same bytes on the device (spz_amd_encode_host_keep), or null; *session: a parse already fed with them (taken)
+bool compressGzippedWithCopy(const uint8_t *data, size_t size, std::vector<uint8_t> *out, const uint8_t *d_copy, void **session) {
+  struct DropSession {  // whichever way this call goes, a session nobody consumed is closed
+    void **s;
+    ~DropSession() {
+      if (s && *s) {
+        spz_amd_zlib_session_close(*s);
+        *s = nullptr;
+      }
+    }
+  } drop_session{session};
   // Large inputs: the writer that reproduces zlib's bytes exactly with its parse on the device or on all
   // cores (it checks itself against zlib on a prefix, and declines inputs it cannot split); zlib itself
   // otherwise and as the fallback.
@@ -526,6 +550,10 @@ bool compressGzippedWithCopy(const uint8_t *data, size_t size, std::vector<uint8
         {
           DeviceHeadParser parser;
           parser.d_copy = d_copy;
+          if (session && *session && d_copy) {
+            parser.session = *session;
+            *session = nullptr;
+          }
           ok = exactgz::compressWithHeadParser(data, size, std::max(threads, 1), parser, out, verify);
           if (timing) {
             std::fprintf(stderr, "[exactgz] writer     %.3f s in all\n",
@@ -867,15 +895,36 @@ std::atomic<uint64_t> g_device_inflates{0};
 
 thread_local const char *g_inflate_decline = "";  // deviceInflateLastDecline()
 
+// Is a member of this size one the device reader will be asked about (SPZ_AMD_GUNZIP_DEVICE, size, core count)?
+bool deviceInflateWanted(size_t size, size_t header_len) {
+  const char *e = std::getenv("SPZ_AMD_GUNZIP_DEVICE");
+  if (e && e[0] == '0') return false;
+  const bool forced = e && e[0] == '1';
+  // profiles/r03_size_sweep.json (16 usable CPUs): the parallel host reader wins below a member of ~60 MB (41 MB member:
+  // 46 ms host, 55 ms device; 82 MB: 70 / 58; 163 MB: 181 / 105; 409 MB: 380 / 150) — a wave takes as long for its
+  // chunk whether there are 300 chunks or 5 000 — and scales with cores, which the device reader does not
+  if (size < header_len + 8 + (forced ? (size_t(1) << 20) : (size_t(56) << 20))) return false;
+  if (!forced && detail::effectiveCpuCount() >= 32) return false;
+  return spz_amd_device_count() > 0;
+}
+
+// The first `want` bytes a raw deflate stream inflates to (zlib); returns how many it got.
+size_t inflatePrefix(const uint8_t *deflate, size_t n, uint8_t *out, size_t want) {
+  z_stream zs = {};
+  if (inflateInit2(&zs, -MAX_WBITS) != Z_OK) return 0;
+  zs.next_in = const_cast<Bytef *>(deflate);
+  zs.avail_in = static_cast<uInt>(std::min<size_t>(n, size_t(1) << 16));
+  zs.next_out = out;
+  zs.avail_out = static_cast<uInt>(want);
+  (void)inflate(&zs, Z_SYNC_FLUSH);
+  const size_t got = want - zs.avail_out;
+  inflateEnd(&zs);
+  return got;
+}
+
 // Inflates the member on the device and checks length and CRC-32 against its trailer; nullptr: declined or wrong.
 void *openVerifiedDeviceInflate(const uint8_t *gz, size_t size, size_t header_len, uint64_t *out_bytes) {
-  const char *e = std::getenv("SPZ_AMD_GUNZIP_DEVICE");
-  if (e && e[0] == '0') return nullptr;
-  const bool forced = e && e[0] == '1';
-  if (size < header_len + 8 + (forced ? (size_t(1) << 20) : (size_t(8) << 20))) return nullptr;
-  // 409 MB member: 0.17 s on the device, 0.25 s on 16 CPUs; the host reader scales with cores, the device one does not
-  if (!forced && detail::effectiveCpuCount() >= 32) return nullptr;
-  if (spz_amd_device_count() <= 0) return nullptr;
+  if (!deviceInflateWanted(size, header_len)) return nullptr;
   const size_t nbytes = size - header_len - 8;
   auto le32 = [&](const uint8_t *q) {
     return static_cast<uint32_t>(q[0]) | (static_cast<uint32_t>(q[1]) << 8) | (static_cast<uint32_t>(q[2]) << 16) |
@@ -1062,14 +1111,16 @@ void sizeCloudArrays(GaussianCloud *r, size_t n, size_t shDim, detail::Prefault 
 }  // namespace
 
 namespace {
-bool packToStreamKeep(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream, const uint8_t **d_copy);
+bool packToStreamKeep(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream, const uint8_t **d_copy,
+                      void *zlib_session = nullptr);
 }
 bool packToStream(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream) {
   return packToStreamKeep(g, o, stream, nullptr);
 }
 namespace {
 // d_copy != null: *d_copy receives the device's copy of the stream (or null), to be given back with spz_amd_kept_stream_release
-bool packToStreamKeep(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream, const uint8_t **d_copy) {
+bool packToStreamKeep(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream, const uint8_t **d_copy,
+                      void *zlib_session) {
   if (d_copy) *d_copy = nullptr;
   g_last_status = SPZ_AMD_OK;
   if (!checkSizes(g)) {
@@ -1091,8 +1142,9 @@ bool packToStreamKeep(const GaussianCloud &g, const PackOptions &o, std::vector<
   prefault.start();
   spz_amd_cloud_in in = {g.positions.data(), g.scales.data(), g.rotations.data(),
                          g.alphas.data(),    g.colors.data(), g.sh.empty() ? nullptr : g.sh.data()};
-  const int rc = d_copy ? spz_amd_encode_host_keep(&in, static_cast<uint64_t>(g.numPoints), g.shDegree, g.antialiased ? 1 : 0,
-                                                   static_cast<int>(o.from), 3, stream->data(), stream->size(), deviceIndex(), d_copy)
+  const int rc = d_copy ? spz_amd_encode_host_keep_session(&in, static_cast<uint64_t>(g.numPoints), g.shDegree, g.antialiased ? 1 : 0,
+                                                           static_cast<int>(o.from), 3, stream->data(), stream->size(), deviceIndex(), d_copy,
+                                                           zlib_session)
                         : spz_amd_encode_host(&in, static_cast<uint64_t>(g.numPoints), g.shDegree, g.antialiased ? 1 : 0,
                                               static_cast<int>(o.from), 3, stream->data(), stream->size(), deviceIndex());
   return !deviceFailed(rc, "encode");
@@ -1260,13 +1312,33 @@ bool saveSpz(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> 
   spz_amd_layout lay;
   const bool keep_on_device = g.numPoints > 0 && spz_amd_stream_layout(static_cast<uint64_t>(g.numPoints), g.shDegree, 3, &lay) == SPZ_AMD_OK &&
                               lay.total_bytes >= (size_t(1) << 20) && exactGzipThreads() >= 1 && deviceParseWanted(lay.total_bytes);
-  if (!packToStreamKeep(g, o, &stream, keep_on_device ? &d_copy : nullptr)) return false;
-  if (timing) std::fprintf(stderr, "[saveSpz] pack %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
   // Default: the reference's single deflate stream (byte-identical files).  SPZ_AMD_GZIP_THREADS=n>1
   // opts into the parallel container (same content, different bytes, n x faster).
   const char *e = std::getenv("SPZ_AMD_GZIP_THREADS");
   const int threads = e ? std::atoi(e) : 1;
-  if (threads <= 1) return compressGzippedWithCopy(stream.data(), stream.size(), out, d_copy);
+  // ... and its first stages (hash chains, match tables: a pure function of the stream's bytes) run on the finished
+  // sections while the rest of the floats still upload: SPZ_AMD_GZIP_OVERLAP=0 starts them after the pack, as before
+  void *session = nullptr;
+  struct CloseSession {
+    void **s;
+    ~CloseSession() {
+      if (*s) spz_amd_zlib_session_close(*s);
+    }
+  } close_session{&session};
+  static const bool overlap = [] {
+    const char *v = std::getenv("SPZ_AMD_GZIP_OVERLAP");
+    return !(v && v[0] == '0');
+  }();
+  if (keep_on_device && overlap && threads <= 1 && std::strcmp(zlibVersion(), "1.2.11") == 0) {
+    const size_t avail = availablePhysicalBytes();
+    if ((avail == 0 || lay.total_bytes / 2 * 9 < avail) &&
+        spz_amd_zlib_session_open(lay.total_bytes, deviceIndex(), &session) != SPZ_AMD_OK) {
+      session = nullptr;  // declined (size, memory): the stage starts after the pack, or runs on the host
+    }
+  }
+  if (!packToStreamKeep(g, o, &stream, keep_on_device ? &d_copy : nullptr, session)) return false;
+  if (timing) std::fprintf(stderr, "[saveSpz] pack %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  if (threads <= 1) return compressGzippedWithCopy(stream.data(), stream.size(), out, d_copy, &session);
   return compressGzippedParallel(stream.data(), stream.size(), out, threads);
 }
 
@@ -1480,6 +1552,11 @@ DevicePackedGaussians loadSpzPackedDevice(const std::string &filename) {
 
 GaussianCloud loadSpz(const uint8_t *data, int32_t size, const UnpackOptions &o) {
   g_last_status = SPZ_AMD_OK;
+  static const bool timing = std::getenv("SPZ_AMD_EXACT_GZIP_TIMING") != nullptr;
+  const auto t_load = std::chrono::steady_clock::now();
+  auto lap = [&](const char *what) {
+    if (timing) std::fprintf(stderr, "[loadSpz] %-22s %.3f s since the call\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_load).count());
+  };
   // An ordinary member that the device inflates stays there: the decode kernels read the stream where it is and only
   // the floats cross PCIe.
   bool device_declined = false;
@@ -1487,10 +1564,28 @@ GaussianCloud loadSpz(const uint8_t *data, int32_t size, const UnpackOptions &o)
     GzipIndex idx;
     const size_t headerLen = parseGzipHeader(data, static_cast<size_t>(size), &idx);
     uint64_t stream_bytes = 0;
+    // The output arrays can be sized — and their pages mapped, 25-30 ms for a 10 M-point cloud — while the device
+    // inflates: the stream's first 16 bytes say how many points are coming, and zlib has them in microseconds.  Only
+    // for members the device reader is going to be asked about; what it finds later must agree with this peek.
+    GaussianCloud r;
+    detail::Prefault prefault;
+    spz_amd_header early = {};
+    bool sized_early = false;
+    if (headerLen != 0 && idx.pieceBytes.empty() && deviceInflateWanted(static_cast<size_t>(size), headerLen)) {
+      uint8_t first[16];
+      if (inflatePrefix(data + headerLen, static_cast<size_t>(size) - headerLen, first, sizeof(first)) == sizeof(first) &&
+          spz_amd_peek_header_ex(first, sizeof(first), SPZ_AMD_REFERENCE_MAX_POINTS, &early) == SPZ_AMD_OK) {
+        sizeCloudArrays(&r, early.num_points, static_cast<size_t>(dimForDegree(early.sh_degree)), &prefault);
+        prefault.startBeside();
+        sized_early = true;
+      }
+      lap("sized from a peek");
+    }
     void *ctx = (headerLen != 0 && idx.pieceBytes.empty())
                     ? openVerifiedDeviceInflate(data, static_cast<size_t>(size), headerLen, &stream_bytes)
                     : nullptr;
     if (ctx != nullptr) {
+      lap("inflated on the device");
       struct Close {
         void *c;
         ~Close() { spz_amd_inflate_close(c); }
@@ -1502,18 +1597,22 @@ GaussianCloud loadSpz(const uint8_t *data, int32_t size, const UnpackOptions &o)
           spz_amd_write_header(&hdr, first16) == SPZ_AMD_OK) {
         // the reference's checks and log lines (load-spz.cc:553-568), on the 16 header bytes and the stream's size
         if (!peekHeaderLogged(first16, static_cast<size_t>(stream_bytes), &hdr)) return {};
-        GaussianCloud r;
         r.numPoints = static_cast<int32_t>(hdr.num_points);
         r.shDegree = hdr.sh_degree;
         r.antialiased = (hdr.flags & 1) != 0;
-        detail::Prefault prefault;
-        sizeCloudArrays(&r, hdr.num_points, static_cast<size_t>(dimForDegree(hdr.sh_degree)), &prefault);
-        prefault.start();
+        prefault.join();   // mapped before the downloads begin (beside them the two contend: spz_host_util.hpp)
+        lap("pages mapped");
+        detail::Prefault late;
+        if (!sized_early || early.num_points != hdr.num_points || early.sh_degree != hdr.sh_degree) {
+          sizeCloudArrays(&r, hdr.num_points, static_cast<size_t>(dimForDegree(hdr.sh_degree)), &late);
+          late.start();
+        }
         spz_amd_cloud_out out = {r.positions.data(), r.scales.data(), r.rotations.data(),
                                  r.alphas.data(),    r.colors.data(), r.sh.empty() ? nullptr : r.sh.data()};
         const int rc = spz_amd_decode_host_from_device(d_stream, static_cast<size_t>(stream_bytes), &hdr, static_cast<int>(o.to),
                                                        &out, deviceIndex());
-        prefault.join();
+        late.join();
+        lap("decoded and downloaded");
         if (rc == SPZ_AMD_OK) {
           g_device_inflates.fetch_add(1);
           return r;

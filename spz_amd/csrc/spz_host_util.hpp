@@ -151,7 +151,7 @@ class Prefault {
     (void)bytes;
 #endif
   }
-  void start() {
+  void start(bool join_at_start = true) {
     if (segs_.empty()) return;
     std::sort(segs_.begin(), segs_.end(), [](const Seg &x, const Seg &y) { return x.where < y.where; });
     const int threads = std::min<int>(prefaultThreads(), static_cast<int>(segs_.size()));
@@ -170,8 +170,10 @@ class Prefault {
     } catch (const std::system_error &) {
       // no thread to be had: whatever is not mapped by the threads that did start faults in on first use
     }
-    if (prefaultJoinFirst()) join();
+    if (join_at_start && prefaultJoinFirst()) join();
   }
+  // start(), but never waits: for mapping beside device work that copies nothing (kernels), where the two do not contend
+  void startBeside() { start(false); }
   void join() {
     for (auto &t : pool_) t.join();
     pool_.clear();

@@ -361,7 +361,7 @@ uint8_t *kept_acquire(int device, size_t bytes) {  // the current device is `dev
 }
 
 int encode_host_impl(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int antialiased, int from_coord, int version,
-                     uint8_t *h_stream, size_t capacity, int device, const uint8_t **d_keep);
+                     uint8_t *h_stream, size_t capacity, int device, const uint8_t **d_keep, void *zlib_session = nullptr);
 }  // namespace
 
 namespace spz_amd_detail {
@@ -400,11 +400,19 @@ int spz_amd_encode_host_keep(const spz_amd_cloud_in *h, uint64_t n, int sh_degre
   return encode_host_impl(h, n, sh_degree, antialiased, from_coord, version, h_stream, capacity, device, d_stream);
 }
 
+int spz_amd_encode_host_keep_session(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int antialiased, int from_coord,
+                                     int version, uint8_t *h_stream, size_t capacity, int device, const uint8_t **d_stream,
+                                     void *zlib_session) {
+  if (d_stream == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  *d_stream = nullptr;
+  return encode_host_impl(h, n, sh_degree, antialiased, from_coord, version, h_stream, capacity, device, d_stream, zlib_session);
+}
+
 }  // extern "C"
 
 namespace {
 int encode_host_impl(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int antialiased, int from_coord, int version,
-                     uint8_t *h_stream, size_t capacity, int device, const uint8_t **d_keep) {
+                     uint8_t *h_stream, size_t capacity, int device, const uint8_t **d_keep, void *zlib_session) {
   if (h == nullptr || h_stream == nullptr || !valid_coord(from_coord)) return SPZ_AMD_ERR_INVALID_ARG;
   spz_amd_layout lay;
   int rc = spz_amd_stream_layout(n, sh_degree, version, &lay);
@@ -466,7 +474,54 @@ int encode_host_impl(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int a
     }
     return SPZ_AMD_OK;
   };
-  rc = run_pipeline(pipe, device, chunks, up, down);
+  if (zlib_session != nullptr && kept != nullptr) {
+    // Section-major, for a caller whose container stage starts on the finished prefix of the stream (the stream is
+    // attribute-major, so point-range chunks finish no section before the last of them): chunk 0 = the five small
+    // arrays of ALL points (20 of the 20 + D bytes per point: the stream's first sections, final after one launch),
+    // chunks 1.. = sh ranges, each extending the finished prefix.  After every launch the session is told how far the
+    // stream is final; its table and match kernels then run beside the remaining uploads.
+    const size_t sh_fpp = fpp[5];
+    uint64_t cps = n;
+    int sh_chunks = 0;
+    if (sh_fpp) sh_chunks = plan_chunks(n, sh_fpp * sizeof(float), &cps);
+    if (1 + sh_chunks > pipe->n_events) return SPZ_AMD_ERR_INVALID_ARG;
+    const uint64_t small_end = lay.offset[SPZ_AMD_SEC_SH];
+    auto up2 = [&](int k) -> int {
+      if (k == 0) {
+        for (int i = 0; i < 5; ++i) {
+          SPZ_HIP_TRY(hipMemcpyAsync(fb[i], src[i], n * fpp[i] * sizeof(float), hipMemcpyHostToDevice, pipe->up));
+        }
+        const spz_amd_cloud_in d = {fb[0], fb[1], fb[2], fb[3], fb[4], fb[5]};
+        const int erc = spz_amd_encode_shard_sections_device(&d, 0, n, n, sh_degree, antialiased, from_coord, version, 1, 0x1fu, sb,
+                                                             lay.total_bytes, pipe->up);
+        if (erc != SPZ_AMD_OK) return erc;
+        return spz_amd_zlib_session_feed(zlib_session, sb, sh_fpp ? small_end : lay.total_bytes, pipe->up);
+      }
+      const uint64_t first = (uint64_t)(k - 1) * cps, count = std::min<uint64_t>(cps, n - first);
+      SPZ_HIP_TRY(hipMemcpyAsync(fb[5] + first * sh_fpp, src[5] + first * sh_fpp, count * sh_fpp * sizeof(float), hipMemcpyHostToDevice,
+                                 pipe->up));
+      const spz_amd_cloud_in d = {fb[0] + first * 3, fb[1] + first * 3, fb[2] + first * 4, fb[3] + first, fb[4] + first * 3,
+                                  fb[5] + first * sh_fpp};
+      const int erc = spz_amd_encode_shard_sections_device(&d, first, count, n, sh_degree, antialiased, from_coord, version, 0, 0x20u, sb,
+                                                           lay.total_bytes, pipe->up);
+      if (erc != SPZ_AMD_OK) return erc;
+      const uint64_t upto = first + count == n ? lay.total_bytes : small_end + (first + count) * lay.bytes_per_point[SPZ_AMD_SEC_SH];
+      return spz_amd_zlib_session_feed(zlib_session, sb, upto, pipe->up);
+    };
+    auto down2 = [&](int k) -> int {
+      if (k == 0) {
+        SPZ_HIP_TRY(hipMemcpyAsync(h_stream, sb, small_end, hipMemcpyDeviceToHost, pipe->down));  // header + five sections
+        return SPZ_AMD_OK;
+      }
+      const uint64_t first = (uint64_t)(k - 1) * cps, count = std::min<uint64_t>(cps, n - first);
+      const uint64_t off = small_end + first * lay.bytes_per_point[SPZ_AMD_SEC_SH], len = count * lay.bytes_per_point[SPZ_AMD_SEC_SH];
+      if (len) SPZ_HIP_TRY(hipMemcpyAsync(h_stream + off, sb + off, len, hipMemcpyDeviceToHost, pipe->down));
+      return SPZ_AMD_OK;
+    };
+    rc = run_pipeline(pipe, device, 1 + sh_chunks, up2, down2);
+  } else {
+    rc = run_pipeline(pipe, device, chunks, up, down);
+  }
   if (rc == SPZ_AMD_OK && kept) {
     *d_keep = kept;
     kept_guard.p = nullptr;  // the caller's now: spz_amd_kept_stream_release

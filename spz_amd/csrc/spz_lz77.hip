@@ -60,16 +60,17 @@ enum TableMode { TABLE_LINK = 0, TABLE_RANK = 1 };
 
 template <int MODE>
 __global__ __launch_bounds__(512) void lz_table_kernel(const uint8_t *__restrict__ d, uint64_t n_pos,
-                                                       uint16_t *__restrict__ out) {
+                                                       uint16_t *__restrict__ out, uint32_t first_segment) {
   __shared__ uint16_t table[HASH_MASK + 1];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-  const uint64_t s0 = (uint64_t)blockIdx.x * kLinkSegment;
+  const uint32_t segment = blockIdx.x + first_segment;
+  const uint64_t s0 = (uint64_t)segment * kLinkSegment;
   const uint64_t s1 = (s0 + kLinkSegment < n_pos) ? s0 + kLinkSegment : n_pos;
   const uint64_t start = s0 >= W ? s0 - W : 0;  // the walks of the first positions reach 32 KiB back
   const uint16_t fresh = MODE == TABLE_LINK ? (uint16_t)((uint32_t)start - kRetiredAge) : (uint16_t)0;
   for (uint32_t i = tid; i <= HASH_MASK; i += kLinkThreads) table[i] = fresh;
   __syncthreads();
-  uint16_t *slab = out + (size_t)blockIdx.x * kRankSlab;  // RANK: entry i is position s0 - W + i
+  uint16_t *slab = out + (size_t)segment * kRankSlab;  // RANK: entry i is position s0 - W + i
   // The workgroup is alone on its CU (the table takes 128 KiB of LDS), so nothing hides a load's latency for it: the
   // next round's three bytes (one unaligned dword; the input is padded) are requested before this round's work.
   auto load3 = [&](uint64_t q) -> uint32_t {
@@ -155,13 +156,13 @@ struct WindowU16 {
 
 __global__ __launch_bounds__(1024) void lz_match_kernel(const uint8_t *__restrict__ d, const uint16_t *__restrict__ link,
                                                         const uint16_t *__restrict__ rank_slabs, uint64_t n_pos, uint64_t size,
-                                                        uint32_t *__restrict__ r128, uint32_t *__restrict__ r32) {
+                                                        uint32_t *__restrict__ r128, uint32_t *__restrict__ r32, uint32_t first_tile) {
   __shared__ uint32_t s_link[kMatchWindowDwords];
   __shared__ uint32_t s_rank[kMatchWindowDwords];
   __shared__ uint32_t s_next_chunk;
   const uint32_t tid = threadIdx.x;
   if (tid == 0) s_next_chunk = 0u;
-  const uint64_t t0 = (uint64_t)blockIdx.x * kMatchTile;
+  const uint64_t t0 = (uint64_t)(blockIdx.x + first_tile) * kMatchTile;
   const long long origin = (long long)t0 - (long long)W;  // window position 0; a multiple of 4 KiB
   const uint64_t seg = t0 / kLinkSegment;
   const uint32_t *l32 = reinterpret_cast<const uint32_t *>(link);
@@ -768,6 +769,233 @@ using namespace spz_amd_detail;
 
 extern "C" {
 
+}  // extern "C"
+
+// Device-to-device copy by a kernel: a hipMemcpyAsync between device buffers goes to the copy engine, where — measured —
+// it queues behind the host-to-device uploads that a feed is supposed to run beside (the session's kernels then start
+// when the uploads end: no overlap at all).  Source and destination have the same offset inside their buffers, so they
+// are aligned alike.
+__global__ __launch_bounds__(256) void lz_copy_kernel(uint8_t *__restrict__ dst, const uint8_t *__restrict__ src, unsigned long long n) {
+  const unsigned long long head = (16ull - (reinterpret_cast<unsigned long long>(dst) & 15ull)) & 15ull;
+  const unsigned long long tid = (unsigned long long)blockIdx.x * 256ull + threadIdx.x, nthreads = (unsigned long long)gridDim.x * 256ull;
+  if ((reinterpret_cast<unsigned long long>(src) & 15ull) != (reinterpret_cast<unsigned long long>(dst) & 15ull) || n < 64ull) {
+    for (unsigned long long i = tid; i < n; i += nthreads) dst[i] = src[i];
+    return;
+  }
+  if (tid < head) dst[tid] = src[tid];
+  const unsigned long long groups = (n - head) / 16ull;
+  const uint4 *s4 = reinterpret_cast<const uint4 *>(src + head);
+  uint4 *d4 = reinterpret_cast<uint4 *>(dst + head);
+  for (unsigned long long g = tid; g < groups; g += nthreads) d4[g] = s4[g];
+  const unsigned long long done = head + groups * 16ull;
+  if (tid < n - done) dst[done + tid] = src[done + tid];
+}
+
+extern "C" {
+
+// ---- a parse whose table and match stages are fed as the input becomes final -----------------------------------------
+// saveSpz: the stream's bytes become final section by section while the floats are still uploading (the GPU would idle
+// through that upload); tables and match tables are a pure function of the input bytes, so they can start on the finished
+// prefix.  A session holds the parse's block and how far the stages have come; spz_amd_zlib_parse_open_dev is a session
+// fed once, whole.
+struct LzSession {
+  int device = 0;
+  uint64_t size = 0, tail_begin = 0, n_pos = 0;
+  uint32_t max_jobs = 0, n_tiles = 0, n_seg = 0;
+  size_t pos_padded = 0, data_bytes = 0, rec_words = 0;
+  size_t o_data = 0, o_link = 0, o_rank = 0, o_r128 = 0, o_r32 = 0, o_rec = 0, o_sd = 0, o_sl = 0, o_xd = 0, o_xl = 0, o_info = 0, o_goff = 0;
+  char *block = nullptr;
+  hipStream_t stream = nullptr;    // the feeds' kernels (null: the default stream)
+  hipEvent_t producer_done = nullptr;
+  bool own_stream = false;
+  uint64_t fed = 0;                // input bytes copied into the block
+  uint32_t seg_done = 0, tile_done = 0;
+  bool zeroed = false;
+  uint8_t *d_data() const { return reinterpret_cast<uint8_t *>(block + o_data); }
+  uint16_t *d_link() const { return reinterpret_cast<uint16_t *>(block + o_link); }
+  uint16_t *d_rank() const { return reinterpret_cast<uint16_t *>(block + o_rank); }
+  uint32_t *d_r128() const { return reinterpret_cast<uint32_t *>(block + o_r128); }
+  uint32_t *d_r32() const { return reinterpret_cast<uint32_t *>(block + o_r32); }
+};
+
+static uint64_t lz_tail_begin(uint64_t size) { return (size - 2ull * W) / W * W; }  // spz_deflate.cpp: compressWithHeadParser
+
+static void lz_session_destroy(LzSession *q) {
+  if (q == nullptr) return;
+  DeviceGuard guard;
+  if (guard.enter(q->device) == SPZ_AMD_OK) {
+    if (q->own_stream && q->stream) {
+      (void)hipStreamSynchronize(q->stream);
+      (void)hipStreamDestroy(q->stream);
+    }
+    if (q->producer_done) (void)hipEventDestroy(q->producer_done);
+    if (q->block) scratch_release(q->device, q->block);
+  }
+  delete q;
+}
+
+// Geometry and memory of a parse of `size` bytes; the current device is `device`.
+static int lz_session_create(uint64_t size, uint64_t tail_begin, int device, bool own_stream, LzSession **out) {
+  *out = nullptr;
+  if (tail_begin == 0 || tail_begin % W != 0 || size >= (1ull << 32)) return SPZ_AMD_ERR_INVALID_ARG;
+  const uint64_t n_pos = tail_begin + kTableSlack;  // positions the tables cover
+  if (n_pos + kReadAhead + MIN_LOOKAHEAD > size) return SPZ_AMD_ERR_INVALID_ARG;
+  LzSession *q = new (std::nothrow) LzSession();
+  if (q == nullptr) return SPZ_AMD_ERR_HIP;
+  q->device = device;
+  q->size = size;
+  q->tail_begin = tail_begin;
+  q->n_pos = n_pos;
+  q->max_jobs = (uint32_t)(tail_begin / kSmallestJob);  // tail_begin is a multiple of W = 4 of them
+  q->n_tiles = (uint32_t)((n_pos + kMatchTile - 1) / kMatchTile);
+  q->pos_padded = (size_t)q->n_tiles * kMatchTile;
+  // carve one allocation
+  size_t off = 0;
+  auto carve = [&](size_t bytes) {
+    const size_t at = off;
+    off += round_up(bytes, 256);
+    return at;
+  };
+  q->data_bytes = std::max<size_t>(q->pos_padded + kReadAhead + 64, round_up(size, 4) + 64);  // what the last tile stages; the whole input
+  q->o_data = carve(q->data_bytes);
+  q->n_seg = (uint32_t)((n_pos + kLinkSegment - 1) / kLinkSegment);
+  q->o_link = carve(q->pos_padded * sizeof(uint16_t));
+  q->o_rank = carve((size_t)q->n_seg * kRankSlab * sizeof(uint16_t));
+  q->o_r128 = carve(q->pos_padded * sizeof(uint32_t));
+  q->o_r32 = carve(q->pos_padded * sizeof(uint32_t));
+  q->rec_words = (size_t)tail_begin + kTailWindow;
+  q->o_rec = carve(q->rec_words * sizeof(uint32_t));
+  const size_t sym_entries = (size_t)q->max_jobs * job_symbol_stride(kSmallestJob);  // larger jobs need fewer
+  q->o_sd = carve(sym_entries * sizeof(uint16_t));
+  q->o_sl = carve(sym_entries);
+  q->o_xd = carve(sym_entries * sizeof(uint16_t));
+  q->o_xl = carve(sym_entries);
+  q->o_info = carve((size_t)(q->max_jobs + 1) * sizeof(JobInfo));
+  q->o_goff = carve((size_t)q->max_jobs * sizeof(unsigned long long));
+  const size_t total = off;
+  size_t free_b = 0;
+  int rc = device_free_bytes(device, &free_b);
+  if (rc == SPZ_AMD_OK && total + (size_t(256) << 20) > free_b) rc = SPZ_AMD_ERR_UNSUPPORTED;  // the caller parses on the host
+  if (rc == SPZ_AMD_OK) rc = scratch_acquire(device, total, reinterpret_cast<void **>(&q->block));
+  if (rc == SPZ_AMD_OK && own_stream) {
+    if (hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&q->producer_done, hipEventDisableTiming) != hipSuccess) {
+      rc = SPZ_AMD_ERR_HIP;
+    }
+    q->own_stream = true;
+  }
+  if (rc != SPZ_AMD_OK) {
+    lz_session_destroy(q);
+    return rc;
+  }
+  *out = q;
+  return SPZ_AMD_OK;
+}
+
+// Bytes [0, upto) of the input are final (device memory `d_src` once `producer`'s queued work is done, or host memory
+// `h_src`): brings them into the block and launches the table and match kernels for every segment and tile they cover.
+// Nothing is waited for.  upto == size: everything that is left.
+static int lz_session_feed(LzSession *q, const uint8_t *d_src, const uint8_t *h_src, uint64_t upto, hipStream_t producer) {
+  hipStream_t st = q->stream;
+  if (upto > q->size) upto = q->size;
+  if (!q->zeroed) {
+    SPZ_HIP_TRY(hipMemsetAsync(q->d_link(), 0, q->pos_padded * sizeof(uint16_t), st));
+    q->zeroed = true;
+  }
+  if (upto > q->fed) {
+    if (d_src != nullptr) {
+      if (q->own_stream && producer != st) {  // the producer's kernels first
+        SPZ_HIP_TRY(hipEventRecord(q->producer_done, producer));
+        SPZ_HIP_TRY(hipStreamWaitEvent(st, q->producer_done, 0));
+      }
+      const unsigned long long nb = upto - q->fed;
+      const uint32_t blocks = (uint32_t)std::min<unsigned long long>(4096ull, (nb / 16ull + 255ull) / 256ull + 1ull);
+      hipLaunchKernelGGL(lz_copy_kernel, dim3(blocks), dim3(256), 0, st, q->d_data() + q->fed, d_src + q->fed, nb);
+      SPZ_HIP_TRY(hipGetLastError());
+    } else {
+      SPZ_HIP_TRY(upload_adaptive(q->d_data() + q->fed, h_src + q->fed, upto - q->fed, st));
+    }
+    q->fed = upto;
+    if (upto == q->size && q->size < q->data_bytes) SPZ_HIP_TRY(hipMemsetAsync(q->d_data() + q->size, 0, q->data_bytes - q->size, st));
+  }
+  const bool all = q->fed == q->size;
+  // a segment reads its positions' three bytes (one dword each): final up to its end + 4; the last segments at the end
+  uint32_t seg_to = all ? q->n_seg : (uint32_t)std::min<uint64_t>(q->n_seg, q->fed >= 4 ? (q->fed - 4) / kLinkSegment : 0);
+  if (seg_to > q->seg_done) {
+    hipLaunchKernelGGL(lz_table_kernel<TABLE_LINK>, dim3(seg_to - q->seg_done), dim3(kLinkThreads), 0, st, q->d_data(), q->n_pos, q->d_link(),
+                       q->seg_done);
+    SPZ_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(lz_table_kernel<TABLE_RANK>, dim3(seg_to - q->seg_done), dim3(kLinkThreads), 0, st, q->d_data(), q->n_pos, q->d_rank(),
+                       q->seg_done);
+    SPZ_HIP_TRY(hipGetLastError());
+    q->seg_done = seg_to;
+  }
+  // a tile's walks read links and ranks up to its last position and input bytes kReadAhead + a dword beyond it
+  const uint64_t tables_to = all ? q->pos_padded : (uint64_t)q->seg_done * kLinkSegment;
+  const uint64_t bytes_to = all ? q->pos_padded : (q->fed > kReadAhead + 8 ? q->fed - kReadAhead - 8 : 0);
+  uint32_t tile_to = (uint32_t)std::min<uint64_t>(q->n_tiles, std::min(tables_to, bytes_to) / kMatchTile);
+  if (all) tile_to = q->n_tiles;
+  if (tile_to > q->tile_done) {
+    hipLaunchKernelGGL(lz_match_kernel, dim3(tile_to - q->tile_done), dim3(kMatchThreads), 0, st, q->d_data(), q->d_link(), q->d_rank(), q->n_pos,
+                       q->size, q->d_r128(), q->d_r32(), q->tile_done);
+    SPZ_HIP_TRY(hipGetLastError());
+    q->tile_done = tile_to;
+  }
+  return SPZ_AMD_OK;
+}
+
+}  // extern "C" (reopened below: the helpers above have C++ linkage)
+
+extern "C" {
+
+int spz_amd_zlib_session_open(uint64_t size, int device, void **session) {
+  if (session == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  *session = nullptr;
+  if (size < 16ull * W || size >= (1ull << 32) - 2ull * W) return SPZ_AMD_ERR_UNSUPPORTED;  // compressWithHeadParser's range
+  DeviceGuard guard;
+  int rc = guard.enter(device);
+  if (rc != SPZ_AMD_OK) return rc;
+  LzSession *q = nullptr;
+  rc = lz_session_create(size, lz_tail_begin(size), device, /*own_stream=*/true, &q);
+  if (rc != SPZ_AMD_OK) return rc;
+  *session = q;
+  return SPZ_AMD_OK;
+}
+
+int spz_amd_zlib_session_feed(void *session, const uint8_t *d_stream, uint64_t final_upto, void *producer_stream) {
+  LzSession *q = static_cast<LzSession *>(session);
+  if (q == nullptr || d_stream == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  DeviceGuard guard;
+  int rc = guard.enter(q->device);
+  if (rc != SPZ_AMD_OK) return rc;
+  return lz_session_feed(q, d_stream, nullptr, final_upto, static_cast<hipStream_t>(producer_stream));
+}
+
+void spz_amd_zlib_session_close(void *session) { lz_session_destroy(static_cast<LzSession *>(session)); }
+
+static int parse_open_impl(LzSession *q, const uint8_t *h_data, const uint8_t *d_copy, const uint32_t *h_tail_rec, uint32_t n_rec, void **ctx,
+                           uint64_t *num_symbols, uint32_t *tail_first_symbol, void (*produce_tail_rec)(void *), void *produce_arg);
+
+int spz_amd_zlib_parse_open_session(void *session, const uint8_t *h_data, const uint8_t *d_stream, uint64_t size, uint64_t tail_begin,
+                                    const uint32_t *h_tail_rec, uint32_t n_rec, void **ctx, uint64_t *num_symbols,
+                                    uint32_t *tail_first_symbol, void (*produce_tail_rec)(void *), void *produce_arg) {
+  LzSession *q = static_cast<LzSession *>(session);
+  if (q == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  if (h_data == nullptr || h_tail_rec == nullptr || ctx == nullptr || num_symbols == nullptr || tail_first_symbol == nullptr ||
+      n_rec < kTailWindow || size != q->size || tail_begin != q->tail_begin) {
+    lz_session_destroy(q);
+    return SPZ_AMD_ERR_INVALID_ARG;
+  }
+  *ctx = nullptr;
+  DeviceGuard guard;
+  int rc = guard.enter(q->device);
+  if (rc != SPZ_AMD_OK) {
+    lz_session_destroy(q);
+    return rc;
+  }
+  return parse_open_impl(q, h_data, d_stream, h_tail_rec, n_rec, ctx, num_symbols, tail_first_symbol, produce_tail_rec, produce_arg);
+}
+
 int spz_amd_zlib_parse_open_dev(const uint8_t *h_data, const uint8_t *d_copy, uint64_t size, uint64_t tail_begin,
                                 const uint32_t *h_tail_rec, uint32_t n_rec, int device, void **ctx, uint64_t *num_symbols,
                                 uint32_t *tail_first_symbol, void (*produce_tail_rec)(void *), void *produce_arg) {
@@ -776,13 +1004,30 @@ int spz_amd_zlib_parse_open_dev(const uint8_t *h_data, const uint8_t *d_copy, ui
     return SPZ_AMD_ERR_INVALID_ARG;
   }
   *ctx = nullptr;
-  if (tail_begin == 0 || tail_begin % W != 0 || n_rec < kTailWindow || size >= (1ull << 32)) return SPZ_AMD_ERR_INVALID_ARG;
-  const uint64_t n_pos = tail_begin + kTableSlack;  // positions the tables cover
-  if (n_pos + kReadAhead + MIN_LOOKAHEAD > size) return SPZ_AMD_ERR_INVALID_ARG;
+  if (n_rec < kTailWindow) return SPZ_AMD_ERR_INVALID_ARG;
   DeviceGuard guard;
   int rc = guard.enter(device);
   if (rc != SPZ_AMD_OK) return rc;
+  LzSession *q = nullptr;
+  rc = lz_session_create(size, tail_begin, device, /*own_stream=*/false, &q);
+  if (rc != SPZ_AMD_OK) return rc;
+  return parse_open_impl(q, h_data, d_copy, h_tail_rec, n_rec, ctx, num_symbols, tail_first_symbol, produce_tail_rec, produce_arg);
+}
 
+// The rest of the parse on a session (consumed: its block goes to the context or back to the cache).
+static int parse_open_impl(LzSession *q, const uint8_t *h_data, const uint8_t *d_copy, const uint32_t *h_tail_rec, uint32_t n_rec, void **ctx,
+                           uint64_t *num_symbols, uint32_t *tail_first_symbol, void (*produce_tail_rec)(void *), void *produce_arg) {
+  (void)n_rec;
+  struct Drop {
+    LzSession *q;
+    ~Drop() { lz_session_destroy(q); }
+  } drop{q};
+  const int device = q->device;
+  const uint64_t size = q->size, tail_begin = q->tail_begin, n_pos = q->n_pos;
+  const size_t pos_padded = q->pos_padded, rec_words = q->rec_words;
+  const size_t o_rec = q->o_rec, o_sd = q->o_sd, o_xd = q->o_xd, o_info = q->o_info;
+  char *block = q->block;
+  int rc = SPZ_AMD_OK;
   static const bool timing = std::getenv("SPZ_AMD_LZ_TIMING") != nullptr;
   auto t_prev = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
@@ -792,85 +1037,29 @@ int spz_amd_zlib_parse_open_dev(const uint8_t *h_data, const uint8_t *d_copy, ui
     std::fprintf(stderr, "[lz77] %-10s %.4f s\n", what, std::chrono::duration<double>(now - t_prev).count());
     t_prev = now;
   };
-
-  const uint32_t max_jobs = (uint32_t)(tail_begin / kSmallestJob);  // tail_begin is a multiple of W = 4 of them
-  const uint32_t n_tiles = (uint32_t)((n_pos + kMatchTile - 1) / kMatchTile);
-  const size_t pos_padded = (size_t)n_tiles * kMatchTile;
-  // carve one allocation
-  size_t off = 0;
-  auto carve = [&](size_t bytes) {
-    const size_t at = off;
-    off += round_up(bytes, 256);
-    return at;
-  };
-  const size_t data_bytes = std::max<size_t>(pos_padded + kReadAhead + 64, round_up(size, 4) + 64);  // what the last tile stages; the whole input
-  const size_t o_data = carve(data_bytes);
-  const uint32_t n_seg = (uint32_t)((n_pos + kLinkSegment - 1) / kLinkSegment);
-  const size_t o_link = carve(pos_padded * sizeof(uint16_t));
-  const size_t o_rank = carve((size_t)n_seg * kRankSlab * sizeof(uint16_t));
-  const size_t o_r128 = carve(pos_padded * sizeof(uint32_t));
-  const size_t o_r32 = carve(pos_padded * sizeof(uint32_t));
-  const size_t rec_words = (size_t)tail_begin + kTailWindow;
-  const size_t o_rec = carve(rec_words * sizeof(uint32_t));
-  const size_t sym_entries = (size_t)max_jobs * job_symbol_stride(kSmallestJob);  // larger jobs need fewer
-  const size_t o_sd = carve(sym_entries * sizeof(uint16_t));
-  const size_t o_sl = carve(sym_entries);
-  const size_t o_xd = carve(sym_entries * sizeof(uint16_t));
-  const size_t o_xl = carve(sym_entries);
-  const size_t o_info = carve((size_t)(max_jobs + 1) * sizeof(JobInfo));
-  const size_t o_goff = carve((size_t)max_jobs * sizeof(unsigned long long));
-  const size_t total = off;
-  size_t free_b = 0;
-  rc = device_free_bytes(device, &free_b);
-  if (rc != SPZ_AMD_OK) return rc;
-  if (total + (size_t(256) << 20) > free_b) return SPZ_AMD_ERR_UNSUPPORTED;  // the caller parses on the host
-  char *block = nullptr;
-  rc = scratch_acquire(device, total, reinterpret_cast<void **>(&block));
-  if (rc != SPZ_AMD_OK) return rc;
-  struct Free {
-    char *p;
-    int device;
-    ~Free() {
-      if (p) scratch_release(device, p);
-    }
-  } holder{block, device};
-  uint8_t *d_data = reinterpret_cast<uint8_t *>(block + o_data);
-  uint16_t *d_link = reinterpret_cast<uint16_t *>(block + o_link);
-  uint16_t *d_rank = reinterpret_cast<uint16_t *>(block + o_rank);
-  uint32_t *d_r128 = reinterpret_cast<uint32_t *>(block + o_r128);
-  uint32_t *d_r32 = reinterpret_cast<uint32_t *>(block + o_r32);
-  uint32_t *d_rec = reinterpret_cast<uint32_t *>(block + o_rec);
-  uint16_t *d_sd = reinterpret_cast<uint16_t *>(block + o_sd);
-  uint8_t *d_sl = reinterpret_cast<uint8_t *>(block + o_sl);
-  uint16_t *d_xd = reinterpret_cast<uint16_t *>(block + o_xd);
-  uint8_t *d_xl = reinterpret_cast<uint8_t *>(block + o_xl);
-  JobInfo *d_info = reinterpret_cast<JobInfo *>(block + o_info);
-  unsigned long long *d_goff = reinterpret_cast<unsigned long long *>(block + o_goff);
-
-  hipStream_t st = nullptr;
-  const size_t upload = std::min<size_t>(size, data_bytes);
-  lap("alloc");
-  if (d_copy != nullptr) {  // the same bytes, already on this device
-    SPZ_HIP_TRY(hipMemcpyAsync(d_data, d_copy, upload, hipMemcpyDeviceToDevice, st));
-  } else {
-    SPZ_HIP_TRY(upload_adaptive(d_data, h_data, upload, st));
+  if (timing && q->own_stream) {
+    std::fprintf(stderr, "[lz77] fed beside the upload: %u of %u table segments, %u of %u match tiles enqueued so far\n", q->seg_done, q->n_seg,
+                 q->tile_done, q->n_tiles);
   }
-  if (upload < data_bytes) SPZ_HIP_TRY(hipMemsetAsync(d_data + upload, 0, data_bytes - upload, st));
-  SPZ_HIP_TRY(hipMemsetAsync(d_link, 0, pos_padded * sizeof(uint16_t), st));
-  lap("upload");
-  hipLaunchKernelGGL(lz_table_kernel<TABLE_LINK>, dim3(n_seg), dim3(kLinkThreads), 0, st, d_data, n_pos, d_link);
-  SPZ_HIP_TRY(hipGetLastError());
-  lap("links");
-  hipLaunchKernelGGL(lz_table_kernel<TABLE_RANK>, dim3(n_seg), dim3(kLinkThreads), 0, st, d_data, n_pos, d_rank);
-  SPZ_HIP_TRY(hipGetLastError());
-  lap("ranks");
-  hipLaunchKernelGGL(lz_match_kernel, dim3(n_tiles), dim3(kMatchThreads), 0, st, d_data, d_link, d_rank, n_pos, size, d_r128, d_r32);
-  SPZ_HIP_TRY(hipGetLastError());
+  uint8_t *d_data = q->d_data();
+  uint32_t *d_r128 = q->d_r128(), *d_r32 = q->d_r32();
+  uint32_t *d_rec = reinterpret_cast<uint32_t *>(block + o_rec);
+  uint16_t *d_sd = reinterpret_cast<uint16_t *>(block + q->o_sd);
+  uint8_t *d_sl = reinterpret_cast<uint8_t *>(block + q->o_sl);
+  uint16_t *d_xd = reinterpret_cast<uint16_t *>(block + q->o_xd);
+  uint8_t *d_xl = reinterpret_cast<uint8_t *>(block + q->o_xl);
+  JobInfo *d_info = reinterpret_cast<JobInfo *>(block + q->o_info);
+  unsigned long long *d_goff = reinterpret_cast<unsigned long long *>(block + q->o_goff);
+  // what the feeds have not covered yet (everything, for a session fed once)
+  rc = lz_session_feed(q, d_copy, d_copy ? nullptr : h_data, size, q->stream);
+  if (rc != SPZ_AMD_OK) return rc;
   // the caller's tail parse can run now, beside the kernels above: its records are not read before this point
   if (produce_tail_rec) produce_tail_rec(produce_arg);
   std::vector<uint32_t> tail_states(kTailWindow);
   for (uint32_t k = 0; k < kTailWindow; ++k) tail_states[k] = h_tail_rec[2 * k];
-  lap("matches");
+  if (q->own_stream) SPZ_HIP_TRY(hipStreamSynchronize(q->stream));  // the later stages run on the default stream
+  lap("tables+matches");
+  hipStream_t st = nullptr;
   // stage 3, with larger jobs if two neighbours do not meet (the tables do not depend on the jobs)
   uint32_t n_jobs = 0, job_bytes = 0;
   std::vector<JobInfo> info;
@@ -927,7 +1116,7 @@ int spz_amd_zlib_parse_open_dev(const uint8_t *h_data, const uint8_t *d_copy, ui
   if (c == nullptr) return SPZ_AMD_ERR_HIP;
   c->device = device;
   c->block = block;
-  holder.p = nullptr;
+  q->block = nullptr;  // the context's now; the session's stream and event go with the session
   c->dense_dist = dense_dist;
   c->dense_lc = dense_lc;
   c->num_symbols = total_syms;

@@ -1,4 +1,4 @@
-"""The container stage on the device is the default for every saveSpz / loadSpz of 8 MiB and more (spz_lz77.hip,
+"""The container stage on the device is the default for every saveSpz of 2 MiB and more (and loadSpz of large files) (spz_lz77.hip,
 spz_inflate_dev.hip).  These tests are about what protects a user there: a wrong symbol out of the parse kernels must
 never reach a file (the on-device symbol check, always on), SPZ_AMD_GZIP_VERIFY=1 must inflate the member on the
 device and compare it with the input, the default route must give zlib's bytes at the BASELINE size (10 M SH3 points,

@@ -71,7 +71,7 @@ def test_device_parse_is_off_below_the_threshold_and_when_disabled():
     rng = np.random.default_rng(5)
     data = make("sh_like", 2_000_000, rng)
     want = zlib_gzip(data)
-    os.environ.pop("SPZ_AMD_GZIP_DEVICE")           # default: 8 MiB and more
+    os.environ.pop("SPZ_AMD_GZIP_DEVICE")           # default: 2 MiB and more
     before = spz._device_gzip_parse_count()
     assert spz._compress_gzipped(data) == want
     assert spz._device_gzip_parse_count() == before
