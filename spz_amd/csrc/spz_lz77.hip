@@ -650,15 +650,14 @@ __global__ __launch_bounds__(256) void lz_encode_kernel(const uint16_t *__restri
   const uint32_t per = (n + kEncodeThreads - 1u) / kEncodeThreads;
   const uint32_t i0 = tid * per < n ? tid * per : n, i1 = i0 + per < n ? i0 + per : n;
   // what one symbol puts into the stream: the length part and the distance part (each at most 28 bits)
-  auto symbol = [&](uint32_t i, uint32_t *v0, uint32_t *n0, uint32_t *v1, uint32_t *n1) {
+  auto symbol = [&](bool end_block, uint32_t d, uint32_t l, uint32_t *v0, uint32_t *n0, uint32_t *v1, uint32_t *n1) {
     *v1 = 0;
     *n1 = 0;
-    if (i + 1u == n) {  // END_BLOCK
+    if (end_block) {
       *v0 = cd.lcode[256];
       *n0 = cd.llen[256];
       return;
     }
-    const uint32_t d = dist[g0 + i], l = lc[g0 + i];
     if (d == 0u) {
       *v0 = cd.lcode[l];
       *n0 = cd.llen[l];
@@ -674,12 +673,30 @@ __global__ __launch_bounds__(256) void lz_encode_kernel(const uint16_t *__restri
     *v1 = cd.dcode[dc] | (((dm - tb.base_dist[dc]) & ((1u << ed) - 1u)) << cd.dlen[dc]);
     *n1 = cd.dlen[dc] + ed;
   };
+  // A thread's run is contiguous, the lanes' runs 128 symbols apart: read symbol by symbol, every load instruction
+  // touches 64 different cache lines and a line is fetched again for each of its 64 entries unless it survives in the
+  // vector cache between iterations (it does not: 16 KiB of lines per wave).  Sixteen symbols per load instead — 32 + 16
+  // bytes per lane, unaligned (a block starts at an odd symbol index) — and a line is touched by two instructions.
+  constexpr uint32_t kChunk = 16;
+  auto for_each_symbol = [&](auto &&body) {
+    for (uint32_t c = i0; c < i1; c += kChunk) {
+      uint16_t dv[kChunk];
+      uint8_t lv[kChunk];
+      __builtin_memcpy(dv, dist + g0 + c, sizeof(dv));  // a few entries past the block's (or the stream's) last are in bounds:
+      __builtin_memcpy(lv, lc + g0 + c, sizeof(lv));    // the arrays have a position's worth of entries each
+#pragma unroll
+      for (uint32_t k = 0; k < kChunk; ++k) {
+        const uint32_t i = c + k;
+        if (i < i1) body(i + 1u == n, (uint32_t)dv[k], (uint32_t)lv[k]);
+      }
+    }
+  };
   uint32_t bits = 0;
-  for (uint32_t i = i0; i < i1; ++i) {
+  for_each_symbol([&](bool end_block, uint32_t d, uint32_t l) {
     uint32_t v0, n0, v1, n1;
-    symbol(i, &v0, &n0, &v1, &n1);
+    symbol(end_block, d, l, &v0, &n0, &v1, &n1);
     bits += n0 + n1;
-  }
+  });
   // exclusive scan of the runs' bit counts (a block's symbols take at most 32768 * 48 bits)
   s_scan[tid] = bits;
   __syncthreads();
@@ -694,12 +711,12 @@ __global__ __launch_bounds__(256) void lz_encode_kernel(const uint16_t *__restri
   if (i0 >= i1) return;
   const unsigned long long at = blk.bit_start + blk.header_bits + before;
   BitSink sink = {body, at >> 5, 0ull, (uint32_t)(at & 31ull), true};
-  for (uint32_t i = i0; i < i1; ++i) {
+  for_each_symbol([&](bool end_block, uint32_t d, uint32_t l) {
     uint32_t v0, n0, v1, n1;
-    symbol(i, &v0, &n0, &v1, &n1);
+    symbol(end_block, d, l, &v0, &n0, &v1, &n1);
     sink.put(v0, n0);
     if (n1) sink.put(v1, n1);
-  }
+  });
   sink.finish();
 }
 
@@ -805,8 +822,14 @@ struct LzSession {
   size_t pos_padded = 0, data_bytes = 0, rec_words = 0;
   size_t o_data = 0, o_link = 0, o_rank = 0, o_r128 = 0, o_r32 = 0, o_rec = 0, o_sd = 0, o_sl = 0, o_xd = 0, o_xl = 0, o_info = 0, o_goff = 0;
   char *block = nullptr;
-  hipStream_t stream = nullptr;    // the feeds' kernels (null: the default stream)
-  hipEvent_t producer_done = nullptr;
+  // A session fed in pieces runs its stages on three streams of its own: the table kernels of one piece are a few dozen
+  // workgroups (one per 512 KiB, alone on their CUs for ~2 ms whatever the piece's size) and would leave the chip idle
+  // if the match kernel of the piece before — which fills it — had to wait for them: LINK and RANK tables side by side,
+  // the match tiles of piece k beside the tables of piece k + 1 (measured in one stream: 103 ms of kernels for twelve
+  // pieces where the whole input at once takes 75).  A session fed once uses the default stream throughout.
+  hipStream_t stream = nullptr;    // copies and LINK tables (null: the default stream)
+  hipStream_t rank_stream = nullptr, match_stream = nullptr;
+  hipEvent_t producer_done = nullptr, copy_done = nullptr, link_done = nullptr, rank_done = nullptr;
   bool own_stream = false;
   uint64_t fed = 0;                // input bytes copied into the block
   uint32_t seg_done = 0, tile_done = 0;
@@ -824,11 +847,17 @@ static void lz_session_destroy(LzSession *q) {
   if (q == nullptr) return;
   DeviceGuard guard;
   if (guard.enter(q->device) == SPZ_AMD_OK) {
-    if (q->own_stream && q->stream) {
-      (void)hipStreamSynchronize(q->stream);
-      (void)hipStreamDestroy(q->stream);
+    if (q->own_stream) {
+      for (hipStream_t st : {q->stream, q->rank_stream, q->match_stream}) {
+        if (st) {
+          (void)hipStreamSynchronize(st);
+          (void)hipStreamDestroy(st);
+        }
+      }
     }
-    if (q->producer_done) (void)hipEventDestroy(q->producer_done);
+    for (hipEvent_t e : {q->producer_done, q->copy_done, q->link_done, q->rank_done}) {
+      if (e) (void)hipEventDestroy(e);
+    }
     if (q->block) scratch_release(q->device, q->block);
   }
   delete q;
@@ -879,7 +908,12 @@ static int lz_session_create(uint64_t size, uint64_t tail_begin, int device, boo
   if (rc == SPZ_AMD_OK) rc = scratch_acquire(device, total, reinterpret_cast<void **>(&q->block));
   if (rc == SPZ_AMD_OK && own_stream) {
     if (hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreateWithFlags(&q->producer_done, hipEventDisableTiming) != hipSuccess) {
+        hipStreamCreateWithFlags(&q->rank_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&q->match_stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&q->producer_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&q->copy_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&q->link_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&q->rank_done, hipEventDisableTiming) != hipSuccess) {
       rc = SPZ_AMD_ERR_HIP;
     }
     q->own_stream = true;
@@ -917,7 +951,12 @@ static int lz_session_feed(LzSession *q, const uint8_t *d_src, const uint8_t *h_
     }
     q->fed = upto;
     if (upto == q->size && q->size < q->data_bytes) SPZ_HIP_TRY(hipMemsetAsync(q->d_data() + q->size, 0, q->data_bytes - q->size, st));
+    if (q->own_stream) {  // the RANK tables read the same bytes
+      SPZ_HIP_TRY(hipEventRecord(q->copy_done, st));
+      SPZ_HIP_TRY(hipStreamWaitEvent(q->rank_stream, q->copy_done, 0));
+    }
   }
+  hipStream_t rst = q->own_stream ? q->rank_stream : st, mst = q->own_stream ? q->match_stream : st;
   const bool all = q->fed == q->size;
   // a segment reads its positions' three bytes (one dword each): final up to its end + 4; the last segments at the end
   uint32_t seg_to = all ? q->n_seg : (uint32_t)std::min<uint64_t>(q->n_seg, q->fed >= 4 ? (q->fed - 4) / kLinkSegment : 0);
@@ -925,10 +964,16 @@ static int lz_session_feed(LzSession *q, const uint8_t *d_src, const uint8_t *h_
     hipLaunchKernelGGL(lz_table_kernel<TABLE_LINK>, dim3(seg_to - q->seg_done), dim3(kLinkThreads), 0, st, q->d_data(), q->n_pos, q->d_link(),
                        q->seg_done);
     SPZ_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(lz_table_kernel<TABLE_RANK>, dim3(seg_to - q->seg_done), dim3(kLinkThreads), 0, st, q->d_data(), q->n_pos, q->d_rank(),
+    hipLaunchKernelGGL(lz_table_kernel<TABLE_RANK>, dim3(seg_to - q->seg_done), dim3(kLinkThreads), 0, rst, q->d_data(), q->n_pos, q->d_rank(),
                        q->seg_done);
     SPZ_HIP_TRY(hipGetLastError());
     q->seg_done = seg_to;
+    if (q->own_stream) {  // the match tiles wait for both tables (and, through them, for the bytes)
+      SPZ_HIP_TRY(hipEventRecord(q->link_done, st));
+      SPZ_HIP_TRY(hipEventRecord(q->rank_done, rst));
+      SPZ_HIP_TRY(hipStreamWaitEvent(mst, q->link_done, 0));
+      SPZ_HIP_TRY(hipStreamWaitEvent(mst, q->rank_done, 0));
+    }
   }
   // a tile's walks read links and ranks up to its last position and input bytes kReadAhead + a dword beyond it
   const uint64_t tables_to = all ? q->pos_padded : (uint64_t)q->seg_done * kLinkSegment;
@@ -936,7 +981,10 @@ static int lz_session_feed(LzSession *q, const uint8_t *d_src, const uint8_t *h_
   uint32_t tile_to = (uint32_t)std::min<uint64_t>(q->n_tiles, std::min(tables_to, bytes_to) / kMatchTile);
   if (all) tile_to = q->n_tiles;
   if (tile_to > q->tile_done) {
-    hipLaunchKernelGGL(lz_match_kernel, dim3(tile_to - q->tile_done), dim3(kMatchThreads), 0, st, q->d_data(), q->d_link(), q->d_rank(), q->n_pos,
+    if (q->own_stream) {  // tiles whose tables were done in an earlier feed still need this feed's bytes (their read-ahead)
+      SPZ_HIP_TRY(hipStreamWaitEvent(mst, q->copy_done, 0));
+    }
+    hipLaunchKernelGGL(lz_match_kernel, dim3(tile_to - q->tile_done), dim3(kMatchThreads), 0, mst, q->d_data(), q->d_link(), q->d_rank(), q->n_pos,
                        q->size, q->d_r128(), q->d_r32(), q->tile_done);
     SPZ_HIP_TRY(hipGetLastError());
     q->tile_done = tile_to;
@@ -1057,7 +1105,11 @@ static int parse_open_impl(LzSession *q, const uint8_t *h_data, const uint8_t *d
   if (produce_tail_rec) produce_tail_rec(produce_arg);
   std::vector<uint32_t> tail_states(kTailWindow);
   for (uint32_t k = 0; k < kTailWindow; ++k) tail_states[k] = h_tail_rec[2 * k];
-  if (q->own_stream) SPZ_HIP_TRY(hipStreamSynchronize(q->stream));  // the later stages run on the default stream
+  if (q->own_stream) {  // the later stages run on the default stream
+    SPZ_HIP_TRY(hipStreamSynchronize(q->stream));
+    SPZ_HIP_TRY(hipStreamSynchronize(q->rank_stream));
+    SPZ_HIP_TRY(hipStreamSynchronize(q->match_stream));
+  }
   lap("tables+matches");
   hipStream_t st = nullptr;
   // stage 3, with larger jobs if two neighbours do not meet (the tables do not depend on the jobs)
