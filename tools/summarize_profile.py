@@ -55,6 +55,32 @@ def main():
                 summary[r["Name"]] = {"calls": int(r["Calls"]), "avg_us": float(r["AverageNs"]) / 1e3,
                                       "min_us": float(r["MinNs"]) / 1e3, "max_us": float(r["MaxNs"]) / 1e3}
 
+    # The launches of bench.py's timed region alone (the range it names), from the kernel trace: the placement probe,
+    # the warm-up steps and the checks after the region launch the same kernels on other data and other placements.
+    mk, kt = find(a.tag, "stats", "marker_api_trace"), find(a.tag, "stats", "kernel_trace")
+    if mk and kt:
+        lo = hi = None
+        with open(mk) as f:
+            for r in csv.DictReader(f):
+                if "spz_bench_timed_region" in (r.get("Function", "") + r.get("Message", "") + r.get("Name", "")):
+                    lo, hi = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        if lo is not None and hi > lo:
+            per = {}
+            with open(kt) as f:
+                for r in csv.DictReader(f):
+                    s = short(r["Kernel_Name"])
+                    st, en = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+                    if s and lo <= st and en <= hi:
+                        per.setdefault(s, []).append((en - st) / 1e3)
+            summary["timed_region"] = {s: {"calls": len(v), "avg_us": sum(v) / len(v), "min_us": min(v), "max_us": max(v)}
+                                       for s, v in per.items()}
+            with open(os.path.join(out_dir, f"{a.tag}_kernel_stats_timed_region.csv"), "w", newline="") as f:
+                w = csv.writer(f)
+                w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "MinNs", "MaxNs", "note"])
+                for s, v in per.items():
+                    w.writerow([s, len(v), int(sum(v) * 1e3), sum(v) / len(v) * 1e3, int(min(v) * 1e3), int(max(v) * 1e3),
+                                "dispatches inside bench.py's range spz_bench_timed_region (rocprofv3 --marker-trace --kernel-trace)"])
+
     d = {0: 0, 1: 9, 2: 24, 3: 45}[a.sh_degree]
     float_bytes = a.points * (14 + d) * 4
     packed_bytes = a.points * (20 + d)
