@@ -833,8 +833,7 @@ struct LzSession {
   bool own_stream = false;
   uint64_t fed = 0;                // input bytes copied into the block
   uint32_t seg_done = 0, tile_done = 0;
-  uint32_t job_done = 0;           // jobs of the smallest size whose lazy state machine has been enqueued (own_stream only)
-  bool zeroed = false, parse_prepared = false;
+  bool zeroed = false;
   uint8_t *d_data() const { return reinterpret_cast<uint8_t *>(block + o_data); }
   uint16_t *d_link() const { return reinterpret_cast<uint16_t *>(block + o_link); }
   uint16_t *d_rank() const { return reinterpret_cast<uint16_t *>(block + o_rank); }
@@ -990,28 +989,10 @@ static int lz_session_feed(LzSession *q, const uint8_t *d_src, const uint8_t *h_
     SPZ_HIP_TRY(hipGetLastError());
     q->tile_done = tile_to;
   }
-  if (q->own_stream) {
-    // ... and the lazy state machine of the jobs (smallest size) whose positions' match tables are enqueued: a job reads
-    // the entries of its own range and one refill window beyond.  Should two neighbours not meet with jobs of this size
-    // the caller runs the stage again with larger ones, all at once, as it always did.
-    const uint32_t job_bytes = kJobSizes[0], n_jobs = (uint32_t)((q->tail_begin + job_bytes - 1) / job_bytes);
-    if (!q->parse_prepared) {
-      SPZ_HIP_TRY(hipMemsetAsync(q->block + q->o_rec, 0, q->rec_words * sizeof(uint32_t), mst));
-      SPZ_HIP_TRY(hipMemsetAsync(q->block + q->o_info, 0, (size_t)(q->max_jobs + 1) * sizeof(JobInfo), mst));
-      q->parse_prepared = true;
-    }
-    const uint64_t covered = (uint64_t)q->tile_done * kMatchTile;
-    uint32_t job_to = all ? n_jobs : (uint32_t)std::min<uint64_t>(n_jobs, covered > 2ull * kParseWindow ? (covered - 2ull * kParseWindow) / job_bytes : 0);
-    if (!all) job_to = job_to / 64u * 64u;  // whole waves, but for the last launch
-    if (job_to > q->job_done) {
-      hipLaunchKernelGGL(lz_parse_kernel, dim3((job_to - q->job_done + 63u) / 64u), dim3(64), 0, mst, q->d_r128(), q->d_r32(), job_bytes,
-                         (uint32_t)q->tail_begin, job_to, reinterpret_cast<uint32_t *>(q->block + q->o_rec),
-                         reinterpret_cast<uint16_t *>(q->block + q->o_sd), reinterpret_cast<uint8_t *>(q->block + q->o_sl),
-                         reinterpret_cast<JobInfo *>(q->block + q->o_info), q->job_done);
-      SPZ_HIP_TRY(hipGetLastError());
-      q->job_done = job_to;
-    }
-  }
+  // (The lazy state machine of the jobs whose match tables are enqueued was fed here as well, for one session of
+  // measurements: its single-wave workgroups run for milliseconds and each holds 16 KiB of a CU's LDS, which keeps the
+  // 144 KiB match workgroups and the 128 KiB table workgroups off that CU — the pack went from 85 ms to 118 ms with the
+  // jobs in the match stream and to 161 ms with a stream of their own.  The jobs run after the last tile again, 10 ms.)
   return SPZ_AMD_OK;
 }
 
@@ -1133,7 +1114,7 @@ static int parse_open_impl(LzSession *q, const uint8_t *h_data, const uint8_t *d
     SPZ_HIP_TRY(hipStreamSynchronize(q->rank_stream));
     SPZ_HIP_TRY(hipStreamSynchronize(q->match_stream));
   }
-  lap(q->own_stream ? "tables+matches+parse" : "tables+matches");
+  lap("tables+matches");
   hipStream_t st = nullptr;
   // stage 3, with larger jobs if two neighbours do not meet (the tables do not depend on the jobs)
   uint32_t n_jobs = 0, job_bytes = 0;
@@ -1145,18 +1126,12 @@ static int parse_open_impl(LzSession *q, const uint8_t *h_data, const uint8_t *d
     job_bytes = kJobSizes[attempt];
     n_jobs = (uint32_t)((tail_begin + job_bytes - 1) / job_bytes);
     const uint32_t parse_blocks = (n_jobs + 63u) / 64u;
-    if (attempt == 0 && q->own_stream && q->job_done == n_jobs) {
-      // the feeds have run this attempt's jobs behind their match tiles already; the records of the caller's tail parse
-      // (which only the stitch reads) go in now
-      SPZ_HIP_TRY(hipMemcpyAsync(d_rec + tail_begin, tail_states.data(), (size_t)kTailWindow * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-    } else {
-      SPZ_HIP_TRY(hipMemsetAsync(d_rec, 0, rec_words * sizeof(uint32_t), st));
-      SPZ_HIP_TRY(hipMemcpyAsync(d_rec + tail_begin, tail_states.data(), (size_t)kTailWindow * sizeof(uint32_t), hipMemcpyHostToDevice, st));
-      SPZ_HIP_TRY(hipMemsetAsync(d_info, 0, (size_t)(n_jobs + 1) * sizeof(JobInfo), st));
-      hipLaunchKernelGGL(lz_parse_kernel, dim3(parse_blocks), dim3(64), 0, st, d_r128, d_r32, job_bytes, (uint32_t)tail_begin, n_jobs, d_rec,
-                         d_sd, d_sl, d_info, 0u);
-      SPZ_HIP_TRY(hipGetLastError());
-    }
+    SPZ_HIP_TRY(hipMemsetAsync(d_rec, 0, rec_words * sizeof(uint32_t), st));
+    SPZ_HIP_TRY(hipMemcpyAsync(d_rec + tail_begin, tail_states.data(), (size_t)kTailWindow * sizeof(uint32_t), hipMemcpyHostToDevice, st));
+    SPZ_HIP_TRY(hipMemsetAsync(d_info, 0, (size_t)(n_jobs + 1) * sizeof(JobInfo), st));
+    hipLaunchKernelGGL(lz_parse_kernel, dim3(parse_blocks), dim3(64), 0, st, d_r128, d_r32, job_bytes, (uint32_t)tail_begin, n_jobs, d_rec,
+                       d_sd, d_sl, d_info, 0u);
+    SPZ_HIP_TRY(hipGetLastError());
     lap("parse");
     hipLaunchKernelGGL(lz_stitch_kernel, dim3(parse_blocks), dim3(64), 0, st, d_r128, d_r32, job_bytes, (uint32_t)tail_begin, n_jobs,
                        d_rec, d_xd, d_xl, d_info);
