@@ -75,37 +75,49 @@ struct HuffT {
   uint32_t packed[1 << FAST];  // filled by pack(): same index as fast[]
   uint32_t ent[NSYM];          // per symbol, without the code length (slow path)
   uint16_t count[16];
+  uint16_t offs[16];           // build()'s running offsets (a member: a local array indexed by a code length lives in
+                               // scratch memory on the device, 500 cycles an access)
   uint16_t symbol[NSYM];
   int ncodes;
   static constexpr int fastbits = FAST;
 
   // returns false for an over-subscribed set, or an incomplete one that is not a single code
   SPZ_INF_HD bool build(const uint8_t *lens, int n) {
+    _Pragma("clang loop unroll(disable)")
     for (int i = 0; i < 16; ++i) count[i] = 0;
+    _Pragma("clang loop unroll(disable)")
     for (int i = 0; i < n; ++i) count[lens[i]]++;
     ncodes = n - count[0];
     count[0] = 0;
     int left = 1;
+    _Pragma("clang loop unroll(disable)")
     for (int len = 1; len <= 15; ++len) {
       left <<= 1;
       left -= count[len];
       if (left < 0) return false;
     }
     if (left > 0 && ncodes != 1 && ncodes != 0) return false;
-    uint16_t offs[16];
+    offs[0] = 0;
     offs[1] = 0;
+    _Pragma("clang loop unroll(disable)")
     for (int len = 1; len < 15; ++len) offs[len + 1] = static_cast<uint16_t>(offs[len] + count[len]);
+    _Pragma("clang loop unroll(disable)")
     for (int i = 0; i < n; ++i) {
       if (lens[i]) symbol[offs[lens[i]]++] = static_cast<uint16_t>(i);
     }
+    _Pragma("clang loop unroll(disable)")
     for (int i = 0; i < (1 << FAST); ++i) fast[i] = 0;
     unsigned code = 0;
     int idx = 0;
+    _Pragma("clang loop unroll(disable)")
     for (int len = 1; len <= fastbits; ++len) {
+      _Pragma("clang loop unroll(disable)")
       for (int k = 0; k < count[len]; ++k, ++code, ++idx) {
         unsigned rev = 0;  // codes are sent most significant bit first
+        _Pragma("clang loop unroll(disable)")
         for (int b = 0; b < len; ++b) rev |= ((code >> b) & 1u) << (len - 1 - b);
         const uint16_t e = static_cast<uint16_t>((symbol[idx] << 4) | len);
+        _Pragma("clang loop unroll(disable)")
         for (unsigned j = rev; j < (1u << fastbits); j += (1u << len)) fast[j] = e;
       }
       code <<= 1;
@@ -115,6 +127,7 @@ struct HuffT {
   // Builds the packed tables from fast[]; `dist` selects the distance alphabet's bases.
   SPZ_INF_HD void pack(bool dist) {
     const int nsym = dist ? 32 : 288;
+    _Pragma("clang loop unroll(disable)")
     for (int sym = 0; sym < nsym; ++sym) {
       uint32_t e;
       if (dist) e = sym < 30 ? (distExtra(sym) << 4) | (distBase(sym) << 16) : ENT_INVALID;
@@ -125,6 +138,7 @@ struct HuffT {
       ent[sym] = e;
     }
     const uint32_t n = 1u << fastbits;
+    _Pragma("clang loop unroll(disable)")
     for (uint32_t i = 0; i < n; ++i) {
       const uint16_t f = fast[i];
       packed[i] = f ? (ent[f >> 4] | (f & 15u)) : 0u;
@@ -147,6 +161,7 @@ struct HuffT {
       return e >> 4;
     }
     int code = 0, first = 0, index = 0;
+    _Pragma("clang loop unroll(disable)")
     for (int l = 1; l <= 15; ++l) {
       code |= static_cast<int>(bits & 1);
       bits >>= 1;
@@ -169,27 +184,44 @@ using HuffDist = HuffT<FAST_D, 32>;
 
 // The fixed Huffman codes of block type 1 (RFC 1951 §3.2.6), built into the caller's tables.
 template <class HL, class HD>
-SPZ_INF_HD void buildStatic(HL *lit, HD *dist) {
-  uint8_t l[288];
+SPZ_INF_HD void buildStatic(HL *lit, HD *dist, uint8_t *lens /* 316 bytes of the caller's */) {
+  uint8_t *l = lens;
+  _Pragma("clang loop unroll(disable)")
   for (int i = 0; i < 144; ++i) l[i] = 8;
+  _Pragma("clang loop unroll(disable)")
   for (int i = 144; i < 256; ++i) l[i] = 9;
+  _Pragma("clang loop unroll(disable)")
   for (int i = 256; i < 280; ++i) l[i] = 7;
+  _Pragma("clang loop unroll(disable)")
   for (int i = 280; i < 288; ++i) l[i] = 8;
   lit->build(l, 288);
   lit->pack(false);
-  uint8_t d[30];
+  uint8_t *d = lens;
+  _Pragma("clang loop unroll(disable)")
   for (int i = 0; i < 30; ++i) d[i] = 5;
   dist->build(d, 30);
   dist->pack(true);
 }
 
+// What reading a dynamic block's header needs besides the two decoders: the code-length code, its lengths, the
+// literal/length + distance code lengths.  The caller's memory — a local on the host, LDS on the device (as locals these
+// arrays, indexed by data, are scratch memory there: the device's block-start search spent most of its time in them).
+struct HeaderWork {
+  HuffT<7, 19> clh;
+  uint8_t lens[286 + 30];
+  uint8_t cl[19];
+  uint16_t count[16];
+};
+
 // Same acceptance rule as HuffT::build(): not over-subscribed, and complete unless it has at most one code.
-SPZ_INF_HD bool completeCode(const uint8_t *lens, int n, int *ncodes) {
-  int count[16];
+SPZ_INF_HD bool completeCode(const uint8_t *lens, int n, int *ncodes, uint16_t *count) {
+  _Pragma("clang loop unroll(disable)")
   for (int i = 0; i < 16; ++i) count[i] = 0;
+  _Pragma("clang loop unroll(disable)")
   for (int i = 0; i < n; ++i) count[lens[i]]++;
   const int codes = n - count[0];
   int left = 1;
+  _Pragma("clang loop unroll(disable)")
   for (int len = 1; len <= 15; ++len) {
     left <<= 1;
     left -= count[len];
@@ -202,7 +234,10 @@ SPZ_INF_HD bool completeCode(const uint8_t *lens, int n, int *ncodes) {
 // Reads a dynamic block's code lengths (after the 3 header bits): lens[0 .. hlit) literal/length, lens[hlit .. hlit + hdist)
 // distance codes.
 template <class In>
-SPZ_INF_HD bool readCodeLengths(const In &in, uint64_t *at, uint8_t *lens, int *hlit_out, int *hdist_out) {
+SPZ_INF_HD bool readCodeLengths(const In &in, uint64_t *at, HeaderWork *w, int *hlit_out, int *hdist_out) {
+  uint8_t *lens = w->lens;
+  uint8_t *cl = w->cl;
+  HuffT<7, 19> &clh = w->clh;
   uint64_t pos = *at;
   if (pos + 14 > in.nbits) return false;
   uint64_t v = in.peek(pos);
@@ -210,20 +245,21 @@ SPZ_INF_HD bool readCodeLengths(const In &in, uint64_t *at, uint8_t *lens, int *
             hclen = static_cast<int>((v >> 10) & 15) + 4;
   if (hlit > 286 || hdist > 30) return false;
   pos += 14;
-  uint8_t cl[19];
+  _Pragma("clang loop unroll(disable)")
   for (int i = 0; i < 19; ++i) cl[i] = 0;
   if (pos + 3 * static_cast<uint64_t>(hclen) > in.nbits) return false;
   v = in.peek(pos);
+  _Pragma("clang loop unroll(disable)")
   for (int i = 0; i < hclen; ++i) {  // 19 * 3 = 57 bits: one peek is not always enough
     if (i == 16) v = in.peek(pos + 48);
     cl[clOrder(i)] = static_cast<uint8_t>((v >> (3 * (i & 15))) & 7);
   }
   pos += 3 * static_cast<uint64_t>(hclen);
-  HuffT<7, 19> clh;
   if (!clh.build(cl, 19)) return false;
   if (clh.ncodes < 1) return false;
   int n = 0;
   const int total = hlit + hdist;
+  _Pragma("clang loop unroll(disable)")
   for (int i = 0; i < 286 + 30; ++i) lens[i] = 0;
   // Kraft sums of the two sets as they come, in units of 2^-15: an over-subscribed set (which build() would refuse
   // in the end anyway) ends the reading at once — random bits that look like a header get there within a few
@@ -231,6 +267,7 @@ SPZ_INF_HD bool readCodeLengths(const In &in, uint64_t *at, uint8_t *lens, int *
   uint32_t kraft_lit = 0, kraft_dist = 0;
   auto add = [&](int from, int to, int len) {
     if (len == 0) return true;
+    _Pragma("clang loop unroll(disable)")
     for (int i = from; i < to; ++i) {
       if (i < hlit) kraft_lit += 32768u >> len;
       else kraft_dist += 32768u >> len;
@@ -276,11 +313,11 @@ SPZ_INF_HD bool readCodeLengths(const In &in, uint64_t *at, uint8_t *lens, int *
 
 // ... and builds both decoders.
 template <class In, class HL, class HD>
-SPZ_INF_HD bool readDynamic(const In &in, uint64_t *at, HL *lit, HD *dist) {
-  uint8_t lens[286 + 30];
+SPZ_INF_HD bool readDynamic(const In &in, uint64_t *at, HL *lit, HD *dist, HeaderWork *w) {
   int hlit = 0, hdist = 0;
   uint64_t pos = *at;
-  if (!readCodeLengths(in, &pos, lens, &hlit, &hdist)) return false;
+  if (!readCodeLengths(in, &pos, w, &hlit, &hdist)) return false;
+  const uint8_t *lens = w->lens;
   if (!lit->build(lens, hlit)) return false;
   if (!dist->build(lens + hlit, hdist)) return false;
   if (lit->ncodes < 2) return false;  // zlib never writes fewer; keeps the block-start search strict
@@ -361,7 +398,7 @@ enum Outcome { FAILED, LINKED, FINAL };
 // above, or the device's wave-wide form of it (spz_inflate_dev.hip).
 template <class In, class HL, class HD, class Sink, class HuffFn>
 SPZ_INF_HD Outcome decodeBlocksWith(const In &in, uint64_t start, uint64_t stop, Sink &sink, uint64_t *end, HL *lit, HD *dist,
-                                    HuffFn huff) {
+                                    HeaderWork *work, HuffFn huff) {
   uint64_t pos = start;
   for (;;) {
     if (pos == stop) return LINKED;
@@ -383,10 +420,10 @@ SPZ_INF_HD Outcome decodeBlocksWith(const In &in, uint64_t start, uint64_t stop,
       if (!sink.raw(in.bytes(pos >> 3), len)) return FAILED;
       pos += 8 * static_cast<uint64_t>(len);
     } else if (type == 1) {
-      buildStatic(lit, dist);
+      buildStatic(lit, dist, work->lens);
       if (!huff(in, &pos, *lit, *dist, sink, stop)) return FAILED;
     } else if (type == 2) {
-      if (!readDynamic(in, &pos, lit, dist)) return FAILED;
+      if (!readDynamic(in, &pos, lit, dist, work)) return FAILED;
       if (!huff(in, &pos, *lit, *dist, sink, stop)) return FAILED;
     } else {
       return FAILED;
@@ -400,7 +437,8 @@ SPZ_INF_HD Outcome decodeBlocksWith(const In &in, uint64_t start, uint64_t stop,
 
 template <class In, class HL, class HD, class Sink>
 SPZ_INF_HD Outcome decodeBlocks(const In &in, uint64_t start, uint64_t stop, Sink &sink, uint64_t *end, HL *lit, HD *dist) {
-  return decodeBlocksWith(in, start, stop, sink, end, lit, dist,
+  HeaderWork work;
+  return decodeBlocksWith(in, start, stop, sink, end, lit, dist, &work,
                           [](const In &i, uint64_t *at, const HL &L, const HD &D, Sink &s, uint64_t limit) {
                             return decodeHuffBlock(i, at, L, D, s, limit);
                           });
@@ -429,13 +467,12 @@ SPZ_INF_HD bool plausibleDynamicHeader(const In &in, uint64_t p) {
 // the block: what the device's search takes; the chunk before it has to end exactly there, which is the rest of
 // the proof.
 template <class In>
-SPZ_INF_HD bool hasValidDynamicHeader(const In &in, uint64_t p) {
+SPZ_INF_HD bool hasValidDynamicHeader(const In &in, uint64_t p, HeaderWork *w) {
   if (p + 64 >= in.nbits || !plausibleDynamicHeader(in, p)) return false;
   uint64_t pos = p + 3;
-  uint8_t lens[286 + 30];
   int hlit = 0, hdist = 0, nl = 0, nd = 0;
-  if (!readCodeLengths(in, &pos, lens, &hlit, &hdist)) return false;
-  return completeCode(lens, hlit, &nl) && completeCode(lens + hlit, hdist, &nd) && nl >= 2;
+  if (!readCodeLengths(in, &pos, w, &hlit, &hdist)) return false;
+  return completeCode(w->lens, hlit, &nl, w->count) && completeCode(w->lens + hlit, hdist, &nd, w->count) && nl >= 2;
 }
 
 // The full test: a non-final dynamic block starts at p, decodes to its end-of-block and is followed by a
@@ -444,7 +481,8 @@ template <class In, class HL, class HD>
 SPZ_INF_HD bool isBlockStart(const In &in, uint64_t p, HL *lit, HD *dist) {
   if (p + 64 >= in.nbits || !plausibleDynamicHeader(in, p)) return false;
   uint64_t pos = p + 3;
-  if (!readDynamic(in, &pos, lit, dist)) return false;
+  HeaderWork work;
+  if (!readDynamic(in, &pos, lit, dist, &work)) return false;
   NullSink sink;
   sink.n = 0;
   if (!decodeHuffBlock(in, &pos, *lit, *dist, sink)) return false;

@@ -46,6 +46,7 @@ constexpr uint32_t kExpand = 8;            // symbols a chunk may produce per co
 constexpr uint32_t kCrcPiece = 262144;
 constexpr uint32_t kMaxCand = 192;
 constexpr uint32_t kSearchPerThread = 64;  // bit positions a thread tests per round
+constexpr uint32_t kValidateSlots = 16;    // candidates whose code lengths are read at the same time (1.3 KiB of LDS each)
 
 // Tables of the device decoder: 9- and 7-bit fast tables (4.7 + 1 KiB per wave: the decode is bound by the latency
 // of its match copies, so what counts is how many waves a CU holds; longer codes take the canonical walk).
@@ -76,6 +77,7 @@ __global__ __launch_bounds__(256) void inf_search_kernel(const uint8_t *__restri
   __shared__ unsigned long long cand[kMaxCand];
   __shared__ uint32_t ncand;
   __shared__ unsigned long long found;
+  __shared__ HeaderWork s_work[kValidateSlots];  // the candidate checks' arrays (in scratch memory they were most of the kernel's time)
   const uint32_t tid = threadIdx.x, chunk = blockIdx.x + 1;  // chunk 0 starts at bit 0
   if (chunk >= n_chunks) return;
   const Bits in = {d, 8ull * nbytes, (size_t)nbytes};
@@ -132,7 +134,11 @@ __global__ __launch_bounds__(256) void inf_search_kernel(const uint8_t *__restri
     __syncthreads();
     // one candidate per thread: header and both code-length sets valid?  The lowest position that is wins.
     const uint32_t n = ncand < kMaxCand ? ncand : kMaxCand;
-    if (tid < n && hasValidDynamicHeader(in, cand[tid])) atomicMin(&found, cand[tid]);
+    for (uint32_t base = 0; base < n; base += kValidateSlots) {   // kValidateSlots at a time: their arrays are in LDS
+      if (tid < kValidateSlots && base + tid < n && hasValidDynamicHeader(in, cand[base + tid], &s_work[tid])) {
+        atomicMin(&found, cand[base + tid]);
+      }
+    }
     __syncthreads();
     if (found != NONE) break;
     if (ncand > kMaxCand) {  // too many look-alikes to be sure none was missed: no start for this chunk
@@ -436,6 +442,10 @@ __global__ __launch_bounds__(64, 6) void inf_decode_kernel(const uint8_t *__rest
                                                            const ChunkJob *__restrict__ jobs, const uint32_t *__restrict__ run,
                                                            uint16_t *symbols, ChunkResult *__restrict__ results, uint32_t experiment) {
   __shared__ Tables tb;
+  // The header arrays stay in scratch memory HERE (3-4 headers per wave): in LDS the kernel needs 123 registers instead of
+  // 80 — four waves per SIMD instead of six — and the stage took 47 ms instead of 35; the block-start search, whose time
+  // WAS these arrays, keeps them in LDS (14 -> 8 ms).
+  HeaderWork s_work;
   __shared__ uint32_t s_win[kWinBytes / 4 + 4];
   const uint32_t j = run[blockIdx.x];
   const ChunkJob job = jobs[j];
@@ -443,7 +453,7 @@ __global__ __launch_bounds__(64, 6) void inf_decode_kernel(const uint8_t *__rest
   WaveSymbolSink sink = {symbols + job.region, job.capacity, job.start_n, threadIdx.x, false, job.start_n};
   sink.skip_copies = (experiment & 1u) != 0u;
   uint64_t end = 0;
-  const Outcome r = decodeBlocksWith(in, job.from, job.to, sink, &end, &tb.lit, &tb.dist,
+  const Outcome r = decodeBlocksWith(in, job.from, job.to, sink, &end, &tb.lit, &tb.dist, &s_work,
                                      [](const WaveBits &i, uint64_t *at, const DevLit &L, const DevDist &D, WaveSymbolSink &s, uint64_t limit) {
                                        return decodeHuffBlockWave(i, at, L, D, s, limit);
                                      });
