@@ -483,7 +483,21 @@ int encode_host_impl(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int a
     const size_t sh_fpp = fpp[5];
     uint64_t cps = n;
     int sh_chunks = 0;
-    if (sh_fpp) sh_chunks = plan_chunks(n, sh_fpp * sizeof(float), &cps);
+    if (sh_fpp) {
+      // Pieces of ~480 MiB of floats (120 MB of stream, ~230 table segments: one round of the chip's CUs): a piece's table
+      // kernels take ~2 ms however few segments it has, so the 160 MiB chunks of the plain pipeline (eleven pieces of 78
+      // segments for 10 M points) spent 50 ms of kernel time on tables that take 19 ms over the whole input at once.
+      static const size_t target = []() {
+        const char *e = std::getenv("SPZ_AMD_HOST_SESSION_CHUNK_MIB");
+        const long v = e ? std::atol(e) : 0;
+        return (size_t)(v > 0 ? v : 480) << 20;
+      }();
+      const unsigned long long total = n * (unsigned long long)sh_fpp * sizeof(float);
+      unsigned long long pieces = (total + target - 1) / target;
+      pieces = pieces < 1 ? 1 : (pieces > (unsigned long long)(kPipeChunksMax - 1) ? (unsigned long long)(kPipeChunksMax - 1) : pieces);
+      cps = ((n + pieces - 1) / pieces + 1023ull) & ~1023ull;
+      sh_chunks = (int)((n + cps - 1) / cps);
+    }
     if (1 + sh_chunks > pipe->n_events) return SPZ_AMD_ERR_INVALID_ARG;
     const uint64_t small_end = lay.offset[SPZ_AMD_SEC_SH];
     auto up2 = [&](int k) -> int {

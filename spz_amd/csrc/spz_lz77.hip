@@ -148,6 +148,11 @@ struct WindowData {
     __builtin_memcpy(&v, d + (origin + pos), 4);  // one unaligned dword load
     return v;
   }
+  __device__ __forceinline__ uint64_t load8(int32_t pos) const {
+    uint64_t v;
+    __builtin_memcpy(&v, d + (origin + pos), 8);  // one unaligned dwordx2 load
+    return v;
+  }
 };
 struct WindowU16 {
   const uint16_t *s;

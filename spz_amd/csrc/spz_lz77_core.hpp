@@ -93,7 +93,7 @@ SPZ_LZ_HD uint32_t entry_distance(uint32_t e) { return (e >> 8) & 0x7fffu; }
 SPZ_LZ_HD uint32_t entry_byte(uint32_t e) { return e & 0xffu; }
 
 // Stage 2 for one position p.  Positions are in the caller's coordinates (Pos: absolute int64_t on the host,
-// window-relative int32_t in the kernel).  `data.load4(pos)`: the four input bytes at pos, little endian (pos up
+// window-relative int32_t in the kernel).  `data.load4(pos)` / `data.load8(pos)`: the four / eight input bytes at pos, little endian (pos up
 // to p + kReadAhead); `link(pos)`, `rank(pos)`: stage 1's values (ranks need a common origin only among the
 // positions one walk can reach); `base`: base_at(p) in the same coordinates (anything at or below p - W stands
 // for "not in reach").  p has a full lookahead.
@@ -105,7 +105,8 @@ SPZ_LZ_HD uint32_t entry_byte(uint32_t e) { return e & 0xffu; }
 template <class Pos, class Data, class Link, class Rank>
 SPZ_LZ_HD void find_matches(const Data &data, const Link &link, const Rank &rank, Pos p, Pos base, uint32_t *r128,
                             uint32_t *r32) {
-  const uint32_t s4 = data.load4(p);
+  const uint64_t s8 = data.load8(p);
+  const uint32_t s4 = (uint32_t)s8;
   const uint32_t none = encode_entry(0, 0, s4 & 0xffu);
   *r128 = none;
   *r32 = none;
@@ -119,8 +120,12 @@ SPZ_LZ_HD void find_matches(const Data &data, const Link &link, const Rank &rank
     if (gap == 0) break;
     cur -= (Pos)gap;
     if (cur <= base || p - cur > (Pos)MAX_DIST) break;  // out of reach for the first candidate and for any later one
-    const uint32_t m4 = data.load4(cur);
-    if (((m4 ^ s4) & 0xffffffu) != 0u) continue;        // a stranger on the hash2 chain
+    // ONE eight-byte load per candidate: the three bytes that make it a candidate at all, and — for all but the rare
+    // candidate that agrees on all eight — its match length.  (zlib's own order — the byte at the best length so far
+    // first, then the first two, then the rest — is a shortcut to the same length; as separate loads it was three
+    // dependent trips through the vector cache per candidate.)
+    const uint64_t x8 = data.load8(cur) ^ s8;
+    if ((x8 & 0xffffffull) != 0ull) continue;            // a stranger on the hash2 chain
     const uint32_t k = (rank_p - rank(cur) - 1u) & 0xffffu;  // its index in zlib's chain
     if (k >= MAX_CHAIN) break;
     if (k > 0 && cur <= limit) break;
@@ -128,17 +133,21 @@ SPZ_LZ_HD void find_matches(const Data &data, const Link &link, const Rank &rank
       *r32 = encode_entry(best, best_dist, s4 & 0xffu);  // what a budget of 32 has found
       snapped = true;
     }
-    if (best >= MIN_MATCH && ((data.load4(cur + (Pos)best) ^ data.load4(p + (Pos)best)) & 0xffu) != 0u) continue;
-    uint32_t len = MIN_MATCH;
-    while (len < MAX_MATCH) {
-      const uint32_t x = data.load4(p + (Pos)len) ^ data.load4(cur + (Pos)len);
-      if (x != 0u) {
-        len += (uint32_t)__builtin_ctz(x) >> 3;
-        break;
+    uint32_t len;
+    if (x8 != 0ull) {
+      len = (uint32_t)__builtin_ctzll(x8) >> 3;  // 3 ... 7
+    } else {
+      len = 8;
+      while (len < MAX_MATCH) {
+        const uint32_t x = data.load4(p + (Pos)len) ^ data.load4(cur + (Pos)len);
+        if (x != 0u) {
+          len += (uint32_t)__builtin_ctz(x) >> 3;
+          break;
+        }
+        len += 4;
       }
-      len += 4;
+      if (len > MAX_MATCH) len = MAX_MATCH;
     }
-    if (len > MAX_MATCH) len = MAX_MATCH;
     if (len > best) {
       best = len;
       best_dist = (uint32_t)(p - cur);

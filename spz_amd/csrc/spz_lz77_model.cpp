@@ -129,6 +129,11 @@ struct ModelParser final : HeadParser {
         std::memcpy(&v, d + pos, 4);
         return v;
       }
+      uint64_t load8(int64_t pos) const {
+        uint64_t v;
+        std::memcpy(&v, d + pos, 8);
+        return v;
+      }
     } dacc{data};
     auto lacc = [&](int64_t pos) { return static_cast<uint32_t>(link[pos]); };
     auto racc = [&](int64_t pos) { return static_cast<uint32_t>(rank[pos]); };
