@@ -484,6 +484,12 @@ int spz_amd_zlib_encode_blocks(void *ctx, const spz_amd_deflate_static *tables, 
  *      SPZ_AMD_ERR_UNSUPPORTED = declined (no usable block starts, chunks that do not link up, a chunk that expands
  *      more than 8 x, not enough device memory): the caller's host readers take over.  Blocking. ------------------- */
 int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, void **ctx, uint64_t *out_bytes);
+/* inflate_open with a callback that runs on the calling thread once the deflate data is on the device (an upload that is
+ * blocking: the data is there when it runs) and before the kernels are waited for: host-side work of the caller that would
+ * contend with the upload but not with the kernels (loadSpz maps its output pages there).  Not called when the open
+ * fails before or during the upload. */
+int spz_amd_inflate_open_ex(const uint8_t *h_deflate, uint64_t nbytes, int device, void **ctx, uint64_t *out_bytes,
+                            void (*after_upload)(void *), void *after_arg);
 /* the same for deflate data that is in device memory already; equals_device: is the result these nbytes (device memory)? */
 int spz_amd_inflate_open_device(const uint8_t *d_deflate, uint64_t nbytes, int device, void **ctx, uint64_t *out_bytes);
 int spz_amd_inflate_equals_device(void *ctx, const uint8_t *d_expected, uint64_t nbytes);

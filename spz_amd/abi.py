@@ -54,7 +54,7 @@ EXPORTS = (
     "spz_amd_zlib_parse_append", "spz_amd_zlib_block_stats", "spz_amd_zlib_encode_blocks", "spz_amd_zlib_verify_member",
     "spz_amd_zlib_encode_group", "spz_amd_zlib_encode_finish", "spz_amd_zlib_parse_open_dev", "spz_amd_encode_host_keep", "spz_amd_kept_stream_release",
     "spz_amd_zlib_block_trees", "spz_amd_zlib_encode_planned", "spz_amd_zlib_encode_finish_ex",
-    "spz_amd_inflate_open", "spz_amd_inflate_open_device", "spz_amd_inflate_equals_device", "spz_amd_inflate_crc_piece_bytes", "spz_amd_inflate_piece_crcs", "spz_amd_inflate_fetch",
+    "spz_amd_inflate_open", "spz_amd_inflate_open_ex", "spz_amd_inflate_open_device", "spz_amd_inflate_equals_device", "spz_amd_inflate_crc_piece_bytes", "spz_amd_inflate_piece_crcs", "spz_amd_inflate_fetch",
     "spz_amd_inflate_device_data", "spz_amd_inflate_close", "spz_amd_stream_to_device", "spz_amd_inflate_last_decline",
     "spz_amd_cloud_buffers_alloc", "spz_amd_cloud_buffers_free",
     "spz_amd_zlib_session_open", "spz_amd_zlib_session_feed", "spz_amd_zlib_session_close", "spz_amd_zlib_parse_open_session",

@@ -945,7 +945,8 @@ size_t inflatePrefix(const uint8_t *deflate, size_t n, uint8_t *out, size_t want
 }
 
 // Inflates the member on the device and checks length and CRC-32 against its trailer; nullptr: declined or wrong.
-void *openVerifiedDeviceInflate(const uint8_t *gz, size_t size, size_t header_len, uint64_t *out_bytes) {
+void *openVerifiedDeviceInflate(const uint8_t *gz, size_t size, size_t header_len, uint64_t *out_bytes,
+                                void (*after_upload)(void *) = nullptr, void *after_arg = nullptr) {
   if (!deviceInflateWanted(size, header_len)) return nullptr;
   const size_t nbytes = size - header_len - 8;
   auto le32 = [&](const uint8_t *q) {
@@ -955,7 +956,7 @@ void *openVerifiedDeviceInflate(const uint8_t *gz, size_t size, size_t header_le
   const uint32_t want_crc = le32(gz + size - 8), isize = le32(gz + size - 4);
   void *ctx = nullptr;
   g_inflate_decline = "";
-  const int open_rc = spz_amd_inflate_open(gz + header_len, nbytes, deviceIndex(), &ctx, out_bytes);
+  const int open_rc = spz_amd_inflate_open_ex(gz + header_len, nbytes, deviceIndex(), &ctx, out_bytes, after_upload, after_arg);
   if (open_rc != SPZ_AMD_OK) {
     g_inflate_decline = open_rc == SPZ_AMD_ERR_UNSUPPORTED ? spz_amd_inflate_last_decline() : spz_amd_status_string(open_rc);
     return nullptr;
@@ -1599,16 +1600,31 @@ GaussianCloud loadSpz(const uint8_t *data, int32_t size, const UnpackOptions &o)
     bool sized_early = false;
     if (headerLen != 0 && idx.pieceBytes.empty() && deviceInflateWanted(static_cast<size_t>(size), headerLen)) {
       uint8_t first[16];
-      if (inflatePrefix(data + headerLen, static_cast<size_t>(size) - headerLen, first, sizeof(first)) == sizeof(first) &&
-          spz_amd_peek_header_ex(first, sizeof(first), SPZ_AMD_REFERENCE_MAX_POINTS, &early) == SPZ_AMD_OK) {
-        sizeCloudArrays(&r, early.num_points, static_cast<size_t>(dimForDegree(early.sh_degree)), &prefault);
-        prefault.startBeside();
-        sized_early = true;
+      if (inflatePrefix(data + headerLen, static_cast<size_t>(size) - headerLen, first, sizeof(first)) == sizeof(first)) {
+        // the header's own fields (spz_amd_peek_header would also want the whole stream behind them); the gzip trailer's
+        // ISIZE must be what a stream of that many points takes, or the peek is not believed
+        auto u32 = [&](const uint8_t *q) {
+          return static_cast<uint32_t>(q[0]) | (static_cast<uint32_t>(q[1]) << 8) | (static_cast<uint32_t>(q[2]) << 16) |
+                 (static_cast<uint32_t>(q[3]) << 24);
+        };
+        early.version = u32(first + 4);
+        early.num_points = u32(first + 8);
+        early.sh_degree = first[12];
+        spz_amd_layout lay;
+        if (u32(first) == 0x5053474eu && early.version >= 1 && early.version <= 3 && early.sh_degree <= 3 &&
+            early.num_points > 0 && early.num_points <= SPZ_AMD_REFERENCE_MAX_POINTS &&
+            spz_amd_stream_layout(early.num_points, early.sh_degree, static_cast<int>(early.version), &lay) == SPZ_AMD_OK &&
+            static_cast<uint32_t>(lay.total_bytes & 0xffffffffull) == u32(data + size - 4)) {
+          sizeCloudArrays(&r, early.num_points, static_cast<size_t>(dimForDegree(early.sh_degree)), &prefault);
+          sized_early = true;  // mapped once the member is on the device: beside the upload the two contend (+80 ms)
+        }
       }
       lap("sized from a peek");
     }
+    auto map_pages = [](void *p) { static_cast<detail::Prefault *>(p)->startBeside(); };
     void *ctx = (headerLen != 0 && idx.pieceBytes.empty())
-                    ? openVerifiedDeviceInflate(data, static_cast<size_t>(size), headerLen, &stream_bytes)
+                    ? openVerifiedDeviceInflate(data, static_cast<size_t>(size), headerLen, &stream_bytes,
+                                                sized_early ? +map_pages : nullptr, &prefault)
                     : nullptr;
     if (ctx != nullptr) {
       lap("inflated on the device");

@@ -667,7 +667,7 @@ extern "C" {
 // The deflate data comes from the host (h_deflate) or is on the device already (d_deflate: the writer's own body,
 // spz_amd_zlib_verify_member).
 static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate, uint64_t nbytes, int device, void **ctx,
-                             uint64_t *out_bytes) {
+                             uint64_t *out_bytes, void (*after_upload)(void *) = nullptr, void *after_arg = nullptr) {
   if ((h_deflate == nullptr) == (d_deflate == nullptr) || ctx == nullptr || out_bytes == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
   *ctx = nullptr;
   g_last_decline = "";
@@ -749,6 +749,9 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
   SPZ_HIP_TRY(hipMemsetAsync(d_data + nbytes, 0, kWinBytes + 64, st));
   SPZ_HIP_TRY(hipMemsetAsync(d_bad, 0, 256, st));
   lap("upload");
+  // the caller's host-side work that must not run beside the upload (mapping output pages: the two contend in the
+  // kernel's memory management and the upload took 80 ms longer) but may run beside the kernels
+  if (after_upload) after_upload(after_arg);
   // ---- 1. block starts
   hipLaunchKernelGGL(inf_search_kernel, dim3(n_chunks - 1), dim3(256), 0, st, d_data, nbytes, chunk_bytes, n_chunks, d_starts);
   SPZ_HIP_TRY(hipGetLastError());
@@ -893,6 +896,12 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
 int spz_amd_inflate_open(const uint8_t *h_deflate, uint64_t nbytes, int device, void **ctx, uint64_t *out_bytes) {
   if (h_deflate == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
   return inflate_open_impl(h_deflate, nullptr, nbytes, device, ctx, out_bytes);
+}
+
+int spz_amd_inflate_open_ex(const uint8_t *h_deflate, uint64_t nbytes, int device, void **ctx, uint64_t *out_bytes,
+                            void (*after_upload)(void *), void *after_arg) {
+  if (h_deflate == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  return inflate_open_impl(h_deflate, nullptr, nbytes, device, ctx, out_bytes, after_upload, after_arg);
 }
 
 int spz_amd_inflate_open_device(const uint8_t *d_deflate, uint64_t nbytes, int device, void **ctx, uint64_t *out_bytes) {
