@@ -460,6 +460,15 @@ int spz_amd_zlib_parse_open_session(void *session, const uint8_t *h_data, const 
 int spz_amd_encode_host_keep_session(const spz_amd_cloud_in *h_cloud, uint64_t num_points, int sh_degree, int antialiased,
                                      int from_coord, int version, uint8_t *h_stream, size_t capacity, int device,
                                      const uint8_t **d_stream, void *zlib_session);
+/* The same for a caller with work of its own on the END of the stream (the container stage's serial tail job: ~8 ms of one
+ * host core on the last 64 ... 128 KiB): the sh of the last points go up first, and tail_ready(tail_arg) is called — on
+ * the call's download thread; it must return quickly, e.g. after starting a thread — as soon as the stream's last
+ * tail_bytes (at least) are in h_stream, long before the call returns.  Not called when tail_bytes is 0, the cloud has
+ * no sh, or it is too small for the reordering to pay (the caller then does that work after the call, as without this). */
+int spz_amd_encode_host_keep_session_tail(const spz_amd_cloud_in *h_cloud, uint64_t num_points, int sh_degree, int antialiased,
+                                          int from_coord, int version, uint8_t *h_stream, size_t capacity, int device,
+                                          const uint8_t **d_stream, void *zlib_session, size_t tail_bytes,
+                                          void (*tail_ready)(void *), void *tail_arg);
 /* Every encode_finish(_ex) returns SPZ_AMD_ERR_VERIFY instead of a body when the symbols it was coded from do not
  * reproduce the input (checked on the device for every block, always: each literal is its input byte, each match
  * copies equal bytes from at most 32 KiB back, each block covers exactly its input range).

@@ -58,7 +58,7 @@ EXPORTS = (
     "spz_amd_inflate_device_data", "spz_amd_inflate_close", "spz_amd_stream_to_device", "spz_amd_inflate_last_decline",
     "spz_amd_cloud_buffers_alloc", "spz_amd_cloud_buffers_free",
     "spz_amd_zlib_session_open", "spz_amd_zlib_session_feed", "spz_amd_zlib_session_close", "spz_amd_zlib_parse_open_session",
-    "spz_amd_encode_host_keep_session", "spz_amd_decode_gather_host_from_device",
+    "spz_amd_encode_host_keep_session", "spz_amd_encode_host_keep_session_tail", "spz_amd_decode_gather_host_from_device",
 )
 
 RCCL_UNIQUE_ID_BYTES = 128

@@ -149,6 +149,21 @@ class Workspace {
   bool open_ = false;
 };
 
+// A stream of its own for a stage: level +1 = in front of the others when both have work for the chip (the pipeline
+// whose copies the link waits for), -1 = behind them (kernels that fill idle CUs beside it), 0 = the default.
+// SPZ_AMD_STREAM_PRIORITIES=0 makes them all equal (measurements).
+inline hipError_t create_stream(hipStream_t *st, int level) {
+  static const bool use = []() {
+    const char *e = std::getenv("SPZ_AMD_STREAM_PRIORITIES");
+    return e == nullptr || std::atoi(e) != 0;
+  }();
+  int least = 0, greatest = 0;  // numerically: greatest priority = the smaller number
+  if (!use || level == 0 || hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) {
+    return hipStreamCreateWithFlags(st, hipStreamNonBlocking);
+  }
+  return hipStreamCreateWithPriority(st, hipStreamNonBlocking, level > 0 ? greatest : least);
+}
+
 // Host -> device copy of a large pageable range that the runtime has not seen before.  hipMemcpy pins such a range
 // page by page first; where the range is backed by huge pages that is cheap and the copy runs at the link's rate
 // (409 MB in 8 ms), where it is not (a fresh std::vector whose huge-page request the kernel could not honour, in whole or

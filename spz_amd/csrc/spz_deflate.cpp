@@ -41,6 +41,7 @@
 #include <cstring>
 #include <chrono>
 #include <cstdio>
+#include <new>
 #include <system_error>
 #include <thread>
 
@@ -986,11 +987,75 @@ bool compress(const uint8_t *data, size_t size, int threads, int windows_per_chu
   return finish_member(data, size, threads, parts, jobs[njobs - 1].tail_literal, crc, out, verify_prefix, lap);
 }
 
+// the serial tail job: the last 64 ... 96 KiB, with the reads past the end of the input as zlib's window has them
+struct TailAhead {
+  std::vector<uint8_t> tail;
+  Job job;
+  std::thread thread;
+  uint64_t size = 0;
+  void prepare(const uint8_t *data, uint64_t size_) {
+    size = size_;
+    const uint64_t tail_begin = (size - 2 * W) / W * W;
+    const uint64_t tail_lo = tail_begin - W;
+    tail.resize(static_cast<size_t>(size - tail_lo) + MAX_MATCH + 8);
+    std::memcpy(tail.data(), data + tail_lo, static_cast<size_t>(size - tail_lo));
+    for (uint64_t abs = size; abs < size + MAX_MATCH + 8; ++abs) tail[static_cast<size_t>(abs - tail_lo)] = data[abs - W];
+    job.size = size;
+    job.begin = tail_begin;
+    job.last = true;
+    job.stop = size;
+    job.d = tail.data() - tail_lo;
+    job.rec_succ_lo = tail_begin;
+    job.rec_succ.assign(OVERLAP + MAX_MATCH + 2, TopRec{});
+  }
+  void finish() {  // the job has run when this returns
+    if (thread.joinable()) thread.join();
+    else if (!ran) job.run();
+    ran = true;
+  }
+  bool ran = false;
+};
+
+static bool sizeInRange(uint64_t size) { return size >= 16 * W && size < (uint64_t(1) << 32) - 2 * W; }
+
+size_t tailAheadBytes(size_t size) {
+  if (!sizeInRange(size)) return 0;
+  const uint64_t tail_lo = (size - 2 * W) / W * W - W;
+  return static_cast<size_t>(size - tail_lo);
+}
+
+TailAhead *tailAheadStart(const uint8_t *data, size_t size) {
+  if (data == nullptr || !sizeInRange(size)) return nullptr;
+  TailAhead *a = new (std::nothrow) TailAhead();
+  if (a == nullptr) return nullptr;
+  a->prepare(data, size);
+  try {
+    a->thread = std::thread([a]() {
+      a->job.run();
+      a->ran = true;
+    });
+  } catch (const std::system_error &) {
+    // no thread to be had: the job runs when the writer asks for it
+  }
+  return a;
+}
+
+void tailAheadDrop(TailAhead *ahead) {
+  if (ahead == nullptr) return;
+  if (ahead->thread.joinable()) ahead->thread.join();
+  delete ahead;
+}
+
 bool compressWithHeadParser(const uint8_t *data, size_t size, int threads, HeadParser &parser,
-                            std::vector<uint8_t> *out, size_t verify_prefix) {
+                            std::vector<uint8_t> *out, size_t verify_prefix, TailAhead *ahead) {
   static_assert(sizeof(TopRec) == 8, "records travel as {state, symcount} pairs");
+  struct DropAhead {
+    TailAhead *a;
+    ~DropAhead() { tailAheadDrop(a); }
+  } drop_ahead{ahead};
   if (data == nullptr || out == nullptr || threads < 1) return false;
-  if (size < 16 * W || size >= (uint64_t(1) << 32) - 2 * W) return false;
+  if (!sizeInRange(size)) return false;
+  if (ahead != nullptr && ahead->size != size) return false;
   static const bool timing = std::getenv("SPZ_AMD_EXACT_GZIP_TIMING") != nullptr;
   auto t_prev = std::chrono::steady_clock::now();
   auto lap = [&](const char *what) {
@@ -1026,27 +1091,20 @@ bool compressWithHeadParser(const uint8_t *data, size_t size, int threads, HeadP
   }
   Joiner zlib_joiner{zlib_thread};
 
-  // the serial tail job: the last 64 ... 96 KiB, with the reads past the end of the input as zlib's window has them
   const uint64_t tail_begin = (size - 2 * W) / W * W;
-  const uint64_t tail_lo = tail_begin - W;
-  std::vector<uint8_t> tail(static_cast<size_t>(size - tail_lo) + MAX_MATCH + 8);
-  std::memcpy(tail.data(), data + tail_lo, static_cast<size_t>(size - tail_lo));
-  for (uint64_t abs = size; abs < size + MAX_MATCH + 8; ++abs) tail[static_cast<size_t>(abs - tail_lo)] = data[abs - W];
-  Job tj;
-  tj.size = size;
-  tj.begin = tail_begin;
-  tj.last = true;
-  tj.stop = size;
-  tj.d = tail.data() - tail_lo;
-  tj.rec_succ_lo = tail_begin;
-  tj.rec_succ.assign(OVERLAP + MAX_MATCH + 2, TopRec{});
-  // the tail job runs when the parser says its records can wait no longer: beside the device's first kernels
+  TailAhead own_tail;
+  TailAhead &ta = ahead ? *ahead : own_tail;
+  if (!ahead) own_tail.prepare(data, size);
+  Job &tj = ta.job;
+  // the tail job runs when the parser says its records can wait no longer: beside the device's first kernels (or has
+  // been running since the caller had the input's last bytes)
   uint64_t nhead = 0;
   uint32_t tail_first = 0;
   const uint32_t n_rec = static_cast<uint32_t>(std::min<size_t>(tj.rec_succ.size(), spz_lz::kTailWindow));
-  auto run_tail = [](void *p) { static_cast<Job *>(p)->run(); };
-  if (!parser.parseLate(data, size, tail_begin, reinterpret_cast<const uint32_t *>(tj.rec_succ.data()), n_rec, run_tail, &tj,
+  auto run_tail = [](void *p) { static_cast<TailAhead *>(p)->finish(); };
+  if (!parser.parseLate(data, size, tail_begin, reinterpret_cast<const uint32_t *>(tj.rec_succ.data()), n_rec, run_tail, &ta,
                         &nhead, &tail_first)) {
+    ta.finish();  // (nothing of it may still run when it goes)
     return false;
   }
   if (!tj.phase_ok) return false;

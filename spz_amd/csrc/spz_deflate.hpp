@@ -71,8 +71,17 @@ struct HeadParser {
     return false;
   }
 };
+// The writer's serial tail job (the last 64 ... 96 KiB of the input, 6 - 9 ms of one core on .spz data) started ahead
+// of the call, for a caller whose input's END exists before the rest does (saveSpz: the stream's last bytes come
+// with the first sh piece on purpose).  tailAheadBytes(size): how many bytes at the end of data[0, size) must be final
+// when tailAheadStart is called (0: no tail job for this size); the job runs on a thread of its own and is consumed by
+// compressWithHeadParser(..., ahead) — whatever that returns — or by tailAheadDrop.
+struct TailAhead;
+size_t tailAheadBytes(size_t size);
+TailAhead *tailAheadStart(const uint8_t *data, size_t size);
+void tailAheadDrop(TailAhead *ahead);
 bool compressWithHeadParser(const uint8_t *data, size_t size, int threads, HeadParser &parser,
-                            std::vector<uint8_t> *out, size_t verify_prefix = 0);
+                            std::vector<uint8_t> *out, size_t verify_prefix = 0, TailAhead *ahead = nullptr);
 
 // Serial host model of the data-parallel parse (stages and job geometry of spz_lz77_core.hpp), for tests.
 HeadParser *newModelHeadParser();

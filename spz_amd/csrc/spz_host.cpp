@@ -515,23 +515,27 @@ uint64_t deviceGzipParseCount() { return g_device_parses.load(); }
 uint64_t deviceGzipRejectCount() { return g_device_rejects.load(); }
 
 namespace {
-bool compressGzippedWithCopy(const uint8_t *data, size_t size, std::vector<uint8_t> *out, const uint8_t *d_copy, void **session = nullptr);
+// A saveSpz whose container stage has been fed beside the upload: the session, and the writer's tail job started as soon
+// as the stream's last bytes were on the host
+struct SaveAhead {
+  void *session = nullptr;
+  exactgz::TailAhead *tail = nullptr;
+  const uint8_t *stream = nullptr;
+  size_t size = 0;
+  ~SaveAhead() {
+    if (session) spz_amd_zlib_session_close(session);
+    exactgz::tailAheadDrop(tail);
+  }
+};
+bool compressGzippedWithCopy(const uint8_t *data, size_t size, std::vector<uint8_t> *out, const uint8_t *d_copy, SaveAhead *ahead = nullptr);
 }
 bool compressGzipped(const uint8_t *data, size_t size, std::vector<uint8_t> *out) {
   return compressGzippedWithCopy(data, size, out, nullptr);
 }
 namespace {
-// d_copy: the same bytes on the device (spz_amd_encode_host_keep), or null; *session: a parse already fed with them (taken)
-bool compressGzippedWithCopy(const uint8_t *data, size_t size, std::vector<uint8_t> *out, const uint8_t *d_copy, void **session) {
-  struct DropSession {  // whichever way this call goes, a session nobody consumed is closed
-    void **s;
-    ~DropSession() {
-      if (s && *s) {
-        spz_amd_zlib_session_close(*s);
-        *s = nullptr;
-      }
-    }
-  } drop_session{session};
+// d_copy: the same bytes on the device (spz_amd_encode_host_keep), or null; ahead: a parse already fed with them and the
+// tail job already started on them (both taken; what is not consumed here goes with *ahead)
+bool compressGzippedWithCopy(const uint8_t *data, size_t size, std::vector<uint8_t> *out, const uint8_t *d_copy, SaveAhead *ahead) {
   // Large inputs: the writer that reproduces zlib's bytes exactly with its parse on the device or on all
   // cores (it checks itself against zlib on a prefix, and declines inputs it cannot split); zlib itself
   // otherwise and as the fallback.
@@ -550,11 +554,14 @@ bool compressGzippedWithCopy(const uint8_t *data, size_t size, std::vector<uint8
         {
           DeviceHeadParser parser;
           parser.d_copy = d_copy;
-          if (session && *session && d_copy) {
-            parser.session = *session;
-            *session = nullptr;
+          exactgz::TailAhead *tail = nullptr;
+          if (ahead && d_copy) {
+            parser.session = ahead->session;
+            ahead->session = nullptr;
+            tail = ahead->tail;
+            ahead->tail = nullptr;
           }
-          ok = exactgz::compressWithHeadParser(data, size, std::max(threads, 1), parser, out, verify);
+          ok = exactgz::compressWithHeadParser(data, size, std::max(threads, 1), parser, out, verify, tail);
           if (timing) {
             std::fprintf(stderr, "[exactgz] writer     %.3f s in all\n",
                          std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
@@ -1139,7 +1146,7 @@ void sizeCloudArrays(GaussianCloud *r, size_t n, size_t shDim, detail::Prefault 
 
 namespace {
 bool packToStreamKeep(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream, const uint8_t **d_copy,
-                      void *zlib_session = nullptr);
+                      SaveAhead *ahead = nullptr);
 }
 bool packToStream(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream) {
   return packToStreamKeep(g, o, stream, nullptr);
@@ -1147,7 +1154,7 @@ bool packToStream(const GaussianCloud &g, const PackOptions &o, std::vector<uint
 namespace {
 // d_copy != null: *d_copy receives the device's copy of the stream (or null), to be given back with spz_amd_kept_stream_release
 bool packToStreamKeep(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> *stream, const uint8_t **d_copy,
-                      void *zlib_session) {
+                      SaveAhead *ahead) {
   if (d_copy) *d_copy = nullptr;
   g_last_status = SPZ_AMD_OK;
   if (!checkSizes(g)) {
@@ -1169,9 +1176,19 @@ bool packToStreamKeep(const GaussianCloud &g, const PackOptions &o, std::vector<
   prefault.start();
   spz_amd_cloud_in in = {g.positions.data(), g.scales.data(), g.rotations.data(),
                          g.alphas.data(),    g.colors.data(), g.sh.empty() ? nullptr : g.sh.data()};
-  const int rc = d_copy ? spz_amd_encode_host_keep_session(&in, static_cast<uint64_t>(g.numPoints), g.shDegree, g.antialiased ? 1 : 0,
-                                                           static_cast<int>(o.from), 3, stream->data(), stream->size(), deviceIndex(), d_copy,
-                                                           zlib_session)
+  void *zlib_session = ahead ? ahead->session : nullptr;
+  auto tail_ready = [](void *p) {
+    SaveAhead *a = static_cast<SaveAhead *>(p);
+    a->tail = exactgz::tailAheadStart(a->stream, a->size);
+  };
+  if (ahead) {
+    ahead->stream = stream->data();
+    ahead->size = stream->size();
+  }
+  const size_t tail_bytes = zlib_session ? exactgz::tailAheadBytes(stream->size()) : 0;
+  const int rc = d_copy ? spz_amd_encode_host_keep_session_tail(&in, static_cast<uint64_t>(g.numPoints), g.shDegree, g.antialiased ? 1 : 0,
+                                                                static_cast<int>(o.from), 3, stream->data(), stream->size(), deviceIndex(),
+                                                                d_copy, zlib_session, tail_bytes, tail_bytes ? +tail_ready : nullptr, ahead)
                         : spz_amd_encode_host(&in, static_cast<uint64_t>(g.numPoints), g.shDegree, g.antialiased ? 1 : 0,
                                               static_cast<int>(o.from), 3, stream->data(), stream->size(), deviceIndex());
   return !deviceFailed(rc, "encode");
@@ -1345,13 +1362,7 @@ bool saveSpz(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> 
   const int threads = e ? std::atoi(e) : 1;
   // ... and its first stages (hash chains, match tables: a pure function of the stream's bytes) run on the finished
   // sections while the rest of the floats still upload: SPZ_AMD_GZIP_OVERLAP=0 starts them after the pack, as before
-  void *session = nullptr;
-  struct CloseSession {
-    void **s;
-    ~CloseSession() {
-      if (*s) spz_amd_zlib_session_close(*s);
-    }
-  } close_session{&session};
+  SaveAhead ahead;
   static const bool overlap = [] {
     const char *v = std::getenv("SPZ_AMD_GZIP_OVERLAP");
     return !(v && v[0] == '0');
@@ -1359,13 +1370,13 @@ bool saveSpz(const GaussianCloud &g, const PackOptions &o, std::vector<uint8_t> 
   if (keep_on_device && overlap && threads <= 1 && std::strcmp(zlibVersion(), "1.2.11") == 0) {
     const size_t avail = availablePhysicalBytes();
     if ((avail == 0 || lay.total_bytes / 2 * 9 < avail) &&
-        spz_amd_zlib_session_open(lay.total_bytes, deviceIndex(), &session) != SPZ_AMD_OK) {
-      session = nullptr;  // declined (size, memory): the stage starts after the pack, or runs on the host
+        spz_amd_zlib_session_open(lay.total_bytes, deviceIndex(), &ahead.session) != SPZ_AMD_OK) {
+      ahead.session = nullptr;  // declined (size, memory): the stage starts after the pack, or runs on the host
     }
   }
-  if (!packToStreamKeep(g, o, &stream, keep_on_device ? &d_copy : nullptr, session)) return false;
+  if (!packToStreamKeep(g, o, &stream, keep_on_device ? &d_copy : nullptr, &ahead)) return false;
   if (timing) std::fprintf(stderr, "[saveSpz] pack %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-  if (threads <= 1) return compressGzippedWithCopy(stream.data(), stream.size(), out, d_copy, &session);
+  if (threads <= 1) return compressGzippedWithCopy(stream.data(), stream.size(), out, d_copy, &ahead);
   return compressGzippedParallel(stream.data(), stream.size(), out, threads);
 }
 

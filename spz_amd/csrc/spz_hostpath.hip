@@ -13,6 +13,7 @@
 #include <mutex>
 #include <system_error>
 #include <thread>
+#include <vector>
 
 #include "spz_amd.h"
 #include "spz_common.hpp"
@@ -28,8 +29,8 @@ constexpr int kPipeEvents = kPipeChunksMax;  // one event per chunk of a host ca
 
 hipError_t pipe_create(HostPipe *p) {
   if (p->up) return hipSuccess;
-  hipError_t e = hipStreamCreateWithFlags(&p->up, hipStreamNonBlocking);
-  if (e == hipSuccess) e = hipStreamCreateWithFlags(&p->down, hipStreamNonBlocking);
+  hipError_t e = create_stream(&p->up, +1);
+  if (e == hipSuccess) e = create_stream(&p->down, +1);
   if (e == hipSuccess) {
     p->events = new hipEvent_t[kPipeEvents];
     for (p->n_events = 0; p->n_events < kPipeEvents && e == hipSuccess; ++p->n_events) {
@@ -361,7 +362,8 @@ uint8_t *kept_acquire(int device, size_t bytes) {  // the current device is `dev
 }
 
 int encode_host_impl(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int antialiased, int from_coord, int version,
-                     uint8_t *h_stream, size_t capacity, int device, const uint8_t **d_keep, void *zlib_session = nullptr);
+                     uint8_t *h_stream, size_t capacity, int device, const uint8_t **d_keep, void *zlib_session = nullptr,
+                     size_t tail_bytes = 0, void (*tail_ready)(void *) = nullptr, void *tail_arg = nullptr);
 }  // namespace
 
 namespace spz_amd_detail {
@@ -408,11 +410,21 @@ int spz_amd_encode_host_keep_session(const spz_amd_cloud_in *h, uint64_t n, int 
   return encode_host_impl(h, n, sh_degree, antialiased, from_coord, version, h_stream, capacity, device, d_stream, zlib_session);
 }
 
+int spz_amd_encode_host_keep_session_tail(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int antialiased, int from_coord,
+                                          int version, uint8_t *h_stream, size_t capacity, int device, const uint8_t **d_stream,
+                                          void *zlib_session, size_t tail_bytes, void (*tail_ready)(void *), void *tail_arg) {
+  if (d_stream == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
+  *d_stream = nullptr;
+  return encode_host_impl(h, n, sh_degree, antialiased, from_coord, version, h_stream, capacity, device, d_stream, zlib_session, tail_bytes,
+                          tail_ready, tail_arg);
+}
+
 }  // extern "C"
 
 namespace {
 int encode_host_impl(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int antialiased, int from_coord, int version,
-                     uint8_t *h_stream, size_t capacity, int device, const uint8_t **d_keep, void *zlib_session) {
+                     uint8_t *h_stream, size_t capacity, int device, const uint8_t **d_keep, void *zlib_session, size_t tail_bytes,
+                     void (*tail_ready)(void *), void *tail_arg) {
   if (h == nullptr || h_stream == nullptr || !valid_coord(from_coord)) return SPZ_AMD_ERR_INVALID_ARG;
   spz_amd_layout lay;
   int rc = spz_amd_stream_layout(n, sh_degree, version, &lay);
@@ -481,37 +493,80 @@ int encode_host_impl(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int a
     // chunks 1.. = sh ranges, each extending the finished prefix.  After every launch the session is told how far the
     // stream is final; its table and match kernels then run beside the remaining uploads.
     const size_t sh_fpp = fpp[5];
-    uint64_t cps = n;
+    std::vector<uint64_t> sh_first;  // piece k covers points [sh_first[k], sh_first[k + 1])
     int sh_chunks = 0;
+    uint64_t n_tail = 0, n_main = n;  // the last n_tail points' sh go first (see below); the pieces cover [0, n_main)
     if (sh_fpp) {
       // Pieces of ~480 MiB of floats (120 MB of stream, ~230 table segments: one round of the chip's CUs): a piece's table
       // kernels take ~2 ms however few segments it has, so the 160 MiB chunks of the plain pipeline (eleven pieces of 78
       // segments for 10 M points) spent 50 ms of kernel time on tables that take 19 ms over the whole input at once.
+      // The LAST pieces shrink (each half of what is left, down to 48 MiB): what the container stage still has to do
+      // when the upload ends is the last piece's tables and matches, 7 ms for a full piece.
       static const size_t target = []() {
         const char *e = std::getenv("SPZ_AMD_HOST_SESSION_CHUNK_MIB");
         const long v = e ? std::atol(e) : 0;
         return (size_t)(v > 0 ? v : 480) << 20;
       }();
-      const unsigned long long total = n * (unsigned long long)sh_fpp * sizeof(float);
-      unsigned long long pieces = (total + target - 1) / target;
-      pieces = pieces < 1 ? 1 : (pieces > (unsigned long long)(kPipeChunksMax - 1) ? (unsigned long long)(kPipeChunksMax - 1) : pieces);
-      cps = ((n + pieces - 1) / pieces + 1023ull) & ~1023ull;
-      sh_chunks = (int)((n + cps - 1) / cps);
+      static const size_t smallest = []() {
+        const char *e = std::getenv("SPZ_AMD_HOST_SESSION_LAST_MIB");
+        const long v = e ? std::atol(e) : 0;
+        return (size_t)(v > 0 ? v : 48) << 20;
+      }();
+      const size_t point_bytes = sh_fpp * sizeof(float);
+      // a caller that wants the stream's END early (its container stage's serial tail job: the last tail_bytes of the
+      // stream) gets the last points' sh as the first sh piece
+      if (tail_ready != nullptr && tail_bytes > 0) {
+        const uint64_t pts = ((tail_bytes + lay.bytes_per_point[SPZ_AMD_SEC_SH] - 1) / lay.bytes_per_point[SPZ_AMD_SEC_SH] + 1023ull) & ~1023ull;
+        if (pts * 4 <= n) n_tail = pts;  // (a cloud this small has no use for it)
+      }
+      n_main = n - n_tail;
+      uint64_t at = 0;
+      while (at < n_main && (int)sh_first.size() < kPipeChunksMax - 5) {
+        sh_first.push_back(at);
+        const unsigned long long left = (n_main - at) * (unsigned long long)point_bytes;
+        unsigned long long want = std::min<unsigned long long>(target, std::max<unsigned long long>(smallest, left / 2));
+        uint64_t count = (want / point_bytes + 1023ull) & ~1023ull;
+        if (count >= n_main - at || (n_main - at - count) * (unsigned long long)point_bytes < smallest / 2) count = n_main - at;  // no sliver at the end
+        at += count;
+      }
+      if (at < n_main) at = n_main;  // (more pieces than events: the last one takes the rest)
+      sh_first.push_back(n_main);
+      sh_chunks = (int)sh_first.size() - 1;
     }
-    if (1 + sh_chunks > pipe->n_events) return SPZ_AMD_ERR_INVALID_ARG;
+    // The five small sections go up in three steps in the stream's order — positions; alphas, colours and scales;
+    // rotations — so that the container stage starts after 120 MB of floats (2 ms) and not after all 560 MB (10 ms:
+    // a fifth of the whole upload, during which the GPU had nothing to do and which it then lacked at the end).
+    constexpr int kSmallSteps = 3;
+    struct SmallStep {
+      int n_arrays, arrays[3];  // spz_amd_cloud_in order: positions 0, scales 1, rotations 2, alphas 3, colors 4
+      unsigned mask;
+      int next_section;         // the stream is final up to this section's offset afterwards
+    };
+    static const SmallStep small_steps[kSmallSteps] = {
+        {1, {0, 0, 0}, 1u << SPZ_AMD_SEC_POSITIONS, SPZ_AMD_SEC_ALPHAS},
+        {3, {3, 4, 1}, (1u << SPZ_AMD_SEC_ALPHAS) | (1u << SPZ_AMD_SEC_COLORS) | (1u << SPZ_AMD_SEC_SCALES), SPZ_AMD_SEC_ROTATIONS},
+        {1, {2, 0, 0}, 1u << SPZ_AMD_SEC_ROTATIONS, SPZ_AMD_SEC_SH}};
+    const int tail_steps = n_tail ? 1 : 0, first_sh_step = kSmallSteps + tail_steps;
+    if (first_sh_step + sh_chunks > pipe->n_events) return SPZ_AMD_ERR_INVALID_ARG;
     const uint64_t small_end = lay.offset[SPZ_AMD_SEC_SH];
+    const uint64_t sh_bpp = lay.bytes_per_point[SPZ_AMD_SEC_SH];
     auto up2 = [&](int k) -> int {
-      if (k == 0) {
-        for (int i = 0; i < 5; ++i) {
+      if (k < kSmallSteps) {
+        const SmallStep &st = small_steps[k];
+        for (int j = 0; j < st.n_arrays; ++j) {
+          const int i = st.arrays[j];
           SPZ_HIP_TRY(hipMemcpyAsync(fb[i], src[i], n * fpp[i] * sizeof(float), hipMemcpyHostToDevice, pipe->up));
         }
         const spz_amd_cloud_in d = {fb[0], fb[1], fb[2], fb[3], fb[4], fb[5]};
-        const int erc = spz_amd_encode_shard_sections_device(&d, 0, n, n, sh_degree, antialiased, from_coord, version, 1, 0x1fu, sb,
-                                                             lay.total_bytes, pipe->up);
+        const int erc = spz_amd_encode_shard_sections_device(&d, 0, n, n, sh_degree, antialiased, from_coord, version, k == 0 ? 1 : 0, st.mask,
+                                                             sb, lay.total_bytes, pipe->up);
         if (erc != SPZ_AMD_OK) return erc;
-        return spz_amd_zlib_session_feed(zlib_session, sb, sh_fpp ? small_end : lay.total_bytes, pipe->up);
+        const bool last = k + 1 == kSmallSteps && !sh_fpp;
+        return spz_amd_zlib_session_feed(zlib_session, sb, last ? lay.total_bytes : lay.offset[st.next_section], pipe->up);
       }
-      const uint64_t first = (uint64_t)(k - 1) * cps, count = std::min<uint64_t>(cps, n - first);
+      const bool tail_piece = k < first_sh_step;
+      const uint64_t first = tail_piece ? n_main : sh_first[k - first_sh_step];
+      const uint64_t count = tail_piece ? n_tail : sh_first[k - first_sh_step + 1] - first;
       SPZ_HIP_TRY(hipMemcpyAsync(fb[5] + first * sh_fpp, src[5] + first * sh_fpp, count * sh_fpp * sizeof(float), hipMemcpyHostToDevice,
                                  pipe->up));
       const spz_amd_cloud_in d = {fb[0] + first * 3, fb[1] + first * 3, fb[2] + first * 4, fb[3] + first, fb[4] + first * 3,
@@ -519,20 +574,29 @@ int encode_host_impl(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int a
       const int erc = spz_amd_encode_shard_sections_device(&d, first, count, n, sh_degree, antialiased, from_coord, version, 0, 0x20u, sb,
                                                            lay.total_bytes, pipe->up);
       if (erc != SPZ_AMD_OK) return erc;
-      const uint64_t upto = first + count == n ? lay.total_bytes : small_end + (first + count) * lay.bytes_per_point[SPZ_AMD_SEC_SH];
+      if (tail_piece) return SPZ_AMD_OK;  // not a prefix of the stream: the session gets it with its last feed
+      const uint64_t upto = first + count == n ? lay.total_bytes : small_end + (first + count) * sh_bpp;
       return spz_amd_zlib_session_feed(zlib_session, sb, upto, pipe->up);
     };
     auto down2 = [&](int k) -> int {
-      if (k == 0) {
-        SPZ_HIP_TRY(hipMemcpyAsync(h_stream, sb, small_end, hipMemcpyDeviceToHost, pipe->down));  // header + five sections
+      if (k < kSmallSteps) {
+        const uint64_t from = k == 0 ? 0 : lay.offset[small_steps[k - 1].next_section];  // the header with the first
+        const uint64_t to = lay.offset[small_steps[k].next_section];
+        if (to > from) SPZ_HIP_TRY(hipMemcpyAsync(h_stream + from, sb + from, to - from, hipMemcpyDeviceToHost, pipe->down));
         return SPZ_AMD_OK;
       }
-      const uint64_t first = (uint64_t)(k - 1) * cps, count = std::min<uint64_t>(cps, n - first);
-      const uint64_t off = small_end + first * lay.bytes_per_point[SPZ_AMD_SEC_SH], len = count * lay.bytes_per_point[SPZ_AMD_SEC_SH];
+      const bool tail_piece = k < first_sh_step;
+      const uint64_t first = tail_piece ? n_main : sh_first[k - first_sh_step];
+      const uint64_t count = tail_piece ? n_tail : sh_first[k - first_sh_step + 1] - first;
+      const uint64_t off = small_end + first * sh_bpp, len = count * sh_bpp;
       if (len) SPZ_HIP_TRY(hipMemcpyAsync(h_stream + off, sb + off, len, hipMemcpyDeviceToHost, pipe->down));
+      if (tail_piece) {  // the stream's last bytes are on the host: the caller's work on them starts now
+        SPZ_HIP_TRY(hipStreamSynchronize(pipe->down));
+        tail_ready(tail_arg);
+      }
       return SPZ_AMD_OK;
     };
-    rc = run_pipeline(pipe, device, 1 + sh_chunks, up2, down2);
+    rc = run_pipeline(pipe, device, first_sh_step + sh_chunks, up2, down2);
   } else {
     rc = run_pipeline(pipe, device, chunks, up, down);
   }

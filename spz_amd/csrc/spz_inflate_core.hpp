@@ -12,6 +12,12 @@
 #else
 #define SPZ_INF_HD inline
 #endif
+// header loops stay rolled in the kernels (unrolled they cost registers the decode loop needs); gcc has no such pragma
+#if defined(__clang__)
+#define SPZ_INF_NO_UNROLL _Pragma("clang loop unroll(disable)")
+#else
+#define SPZ_INF_NO_UNROLL
+#endif
 
 namespace spz {
 namespace pinflate {
@@ -83,14 +89,14 @@ struct HuffT {
 
   // returns false for an over-subscribed set, or an incomplete one that is not a single code
   SPZ_INF_HD bool build(const uint8_t *lens, int n) {
-    _Pragma("clang loop unroll(disable)")
+    SPZ_INF_NO_UNROLL
     for (int i = 0; i < 16; ++i) count[i] = 0;
-    _Pragma("clang loop unroll(disable)")
+    SPZ_INF_NO_UNROLL
     for (int i = 0; i < n; ++i) count[lens[i]]++;
     ncodes = n - count[0];
     count[0] = 0;
     int left = 1;
-    _Pragma("clang loop unroll(disable)")
+    SPZ_INF_NO_UNROLL
     for (int len = 1; len <= 15; ++len) {
       left <<= 1;
       left -= count[len];
@@ -99,25 +105,25 @@ struct HuffT {
     if (left > 0 && ncodes != 1 && ncodes != 0) return false;
     offs[0] = 0;
     offs[1] = 0;
-    _Pragma("clang loop unroll(disable)")
+    SPZ_INF_NO_UNROLL
     for (int len = 1; len < 15; ++len) offs[len + 1] = static_cast<uint16_t>(offs[len] + count[len]);
-    _Pragma("clang loop unroll(disable)")
+    SPZ_INF_NO_UNROLL
     for (int i = 0; i < n; ++i) {
       if (lens[i]) symbol[offs[lens[i]]++] = static_cast<uint16_t>(i);
     }
-    _Pragma("clang loop unroll(disable)")
+    SPZ_INF_NO_UNROLL
     for (int i = 0; i < (1 << FAST); ++i) fast[i] = 0;
     unsigned code = 0;
     int idx = 0;
-    _Pragma("clang loop unroll(disable)")
+    SPZ_INF_NO_UNROLL
     for (int len = 1; len <= fastbits; ++len) {
-      _Pragma("clang loop unroll(disable)")
+      SPZ_INF_NO_UNROLL
       for (int k = 0; k < count[len]; ++k, ++code, ++idx) {
         unsigned rev = 0;  // codes are sent most significant bit first
-        _Pragma("clang loop unroll(disable)")
+        SPZ_INF_NO_UNROLL
         for (int b = 0; b < len; ++b) rev |= ((code >> b) & 1u) << (len - 1 - b);
         const uint16_t e = static_cast<uint16_t>((symbol[idx] << 4) | len);
-        _Pragma("clang loop unroll(disable)")
+        SPZ_INF_NO_UNROLL
         for (unsigned j = rev; j < (1u << fastbits); j += (1u << len)) fast[j] = e;
       }
       code <<= 1;
@@ -127,7 +133,7 @@ struct HuffT {
   // Builds the packed tables from fast[]; `dist` selects the distance alphabet's bases.
   SPZ_INF_HD void pack(bool dist) {
     const int nsym = dist ? 32 : 288;
-    _Pragma("clang loop unroll(disable)")
+    SPZ_INF_NO_UNROLL
     for (int sym = 0; sym < nsym; ++sym) {
       uint32_t e;
       if (dist) e = sym < 30 ? (distExtra(sym) << 4) | (distBase(sym) << 16) : ENT_INVALID;
@@ -138,7 +144,7 @@ struct HuffT {
       ent[sym] = e;
     }
     const uint32_t n = 1u << fastbits;
-    _Pragma("clang loop unroll(disable)")
+    SPZ_INF_NO_UNROLL
     for (uint32_t i = 0; i < n; ++i) {
       const uint16_t f = fast[i];
       packed[i] = f ? (ent[f >> 4] | (f & 15u)) : 0u;
@@ -161,7 +167,7 @@ struct HuffT {
       return e >> 4;
     }
     int code = 0, first = 0, index = 0;
-    _Pragma("clang loop unroll(disable)")
+    SPZ_INF_NO_UNROLL
     for (int l = 1; l <= 15; ++l) {
       code |= static_cast<int>(bits & 1);
       bits >>= 1;
@@ -186,18 +192,18 @@ using HuffDist = HuffT<FAST_D, 32>;
 template <class HL, class HD>
 SPZ_INF_HD void buildStatic(HL *lit, HD *dist, uint8_t *lens /* 316 bytes of the caller's */) {
   uint8_t *l = lens;
-  _Pragma("clang loop unroll(disable)")
+  SPZ_INF_NO_UNROLL
   for (int i = 0; i < 144; ++i) l[i] = 8;
-  _Pragma("clang loop unroll(disable)")
+  SPZ_INF_NO_UNROLL
   for (int i = 144; i < 256; ++i) l[i] = 9;
-  _Pragma("clang loop unroll(disable)")
+  SPZ_INF_NO_UNROLL
   for (int i = 256; i < 280; ++i) l[i] = 7;
-  _Pragma("clang loop unroll(disable)")
+  SPZ_INF_NO_UNROLL
   for (int i = 280; i < 288; ++i) l[i] = 8;
   lit->build(l, 288);
   lit->pack(false);
   uint8_t *d = lens;
-  _Pragma("clang loop unroll(disable)")
+  SPZ_INF_NO_UNROLL
   for (int i = 0; i < 30; ++i) d[i] = 5;
   dist->build(d, 30);
   dist->pack(true);
@@ -215,13 +221,13 @@ struct HeaderWork {
 
 // Same acceptance rule as HuffT::build(): not over-subscribed, and complete unless it has at most one code.
 SPZ_INF_HD bool completeCode(const uint8_t *lens, int n, int *ncodes, uint16_t *count) {
-  _Pragma("clang loop unroll(disable)")
+  SPZ_INF_NO_UNROLL
   for (int i = 0; i < 16; ++i) count[i] = 0;
-  _Pragma("clang loop unroll(disable)")
+  SPZ_INF_NO_UNROLL
   for (int i = 0; i < n; ++i) count[lens[i]]++;
   const int codes = n - count[0];
   int left = 1;
-  _Pragma("clang loop unroll(disable)")
+  SPZ_INF_NO_UNROLL
   for (int len = 1; len <= 15; ++len) {
     left <<= 1;
     left -= count[len];
@@ -245,11 +251,11 @@ SPZ_INF_HD bool readCodeLengths(const In &in, uint64_t *at, HeaderWork *w, int *
             hclen = static_cast<int>((v >> 10) & 15) + 4;
   if (hlit > 286 || hdist > 30) return false;
   pos += 14;
-  _Pragma("clang loop unroll(disable)")
+  SPZ_INF_NO_UNROLL
   for (int i = 0; i < 19; ++i) cl[i] = 0;
   if (pos + 3 * static_cast<uint64_t>(hclen) > in.nbits) return false;
   v = in.peek(pos);
-  _Pragma("clang loop unroll(disable)")
+  SPZ_INF_NO_UNROLL
   for (int i = 0; i < hclen; ++i) {  // 19 * 3 = 57 bits: one peek is not always enough
     if (i == 16) v = in.peek(pos + 48);
     cl[clOrder(i)] = static_cast<uint8_t>((v >> (3 * (i & 15))) & 7);
@@ -259,7 +265,7 @@ SPZ_INF_HD bool readCodeLengths(const In &in, uint64_t *at, HeaderWork *w, int *
   if (clh.ncodes < 1) return false;
   int n = 0;
   const int total = hlit + hdist;
-  _Pragma("clang loop unroll(disable)")
+  SPZ_INF_NO_UNROLL
   for (int i = 0; i < 286 + 30; ++i) lens[i] = 0;
   // Kraft sums of the two sets as they come, in units of 2^-15: an over-subscribed set (which build() would refuse
   // in the end anyway) ends the reading at once — random bits that look like a header get there within a few
@@ -267,7 +273,7 @@ SPZ_INF_HD bool readCodeLengths(const In &in, uint64_t *at, HeaderWork *w, int *
   uint32_t kraft_lit = 0, kraft_dist = 0;
   auto add = [&](int from, int to, int len) {
     if (len == 0) return true;
-    _Pragma("clang loop unroll(disable)")
+    SPZ_INF_NO_UNROLL
     for (int i = from; i < to; ++i) {
       if (i < hlit) kraft_lit += 32768u >> len;
       else kraft_dist += 32768u >> len;

@@ -132,73 +132,194 @@ __global__ __launch_bounds__(512) void lz_table_kernel(const uint8_t *__restrict
   }
 }
 
+// ---- stage 1b: chain steps ------------------------------------------------------------------------------
+// delta[p] = how far along zlib's chain p's link goes (spz_lz77_core.hpp: chain_delta): two gathers per position
+// (the link target's rank and bytes), all of them independent — the same reads as dependent steps of stage 2's walks
+// cost it a trip to the vector cache per candidate.
+__global__ __launch_bounds__(256) void lz_chain_kernel(const uint8_t *__restrict__ d, const uint16_t *__restrict__ link,
+                                                       const uint16_t *__restrict__ rank_slabs, uint8_t *__restrict__ delta,
+                                                       uint64_t first, uint64_t end, uint64_t n_pos) {
+  // four consecutive positions per thread: one dword of deltas
+  const uint64_t p0 = first + ((uint64_t)blockIdx.x * 256u + threadIdx.x) * 4u;
+  if (p0 >= end) return;
+  uint32_t out = 0;
+  uint64_t own;
+  __builtin_memcpy(&own, d + p0, 8);  // the bytes of the four positions' triples (the input is padded)
+#pragma unroll
+  for (uint32_t i = 0; i < 4; ++i) {
+    const uint64_t p = p0 + i;
+    uint32_t v = 0;
+    const uint32_t gap = p < n_pos ? link[p] : 0u;
+    if (gap != 0u) {
+      const uint64_t seg = p / kLinkSegment;
+      const uint16_t *slab = rank_slabs + seg * kRankSlab;  // entry i is position seg * kLinkSegment - W + i
+      const uint64_t at = p + W - seg * kLinkSegment;
+      uint32_t theirs;
+      __builtin_memcpy(&theirs, d + (p - gap), 4);
+      const uint32_t mine = (uint32_t)(own >> (8 * i));
+      v = chain_delta(slab[at], slab[at - gap], ((mine ^ theirs) & 0xffffffu) == 0u);
+    }
+    out |= v << (8 * i);
+  }
+  *reinterpret_cast<uint32_t *>(delta + p0) = out;
+}
+
 // ---- stage 2: match tables -----------------------------------------------------------------------------
-// One workgroup per 4 KiB of positions: the links and ranks of the 36 KiB of positions those can reach are staged
-// in LDS (144 KiB of the CU's 160); the input bytes themselves are read through the vector cache (a walk looks
-// at them only where it stops).  (Input bytes in LDS instead of the ranks, with the ranks reduced to one byte of
-// chain steps per link, measured 10 % slower all told: profiles/r02_gzip_device_laps.txt.)
+// One workgroup per 4 KiB of positions: the links, chain steps and input bytes of the 36 KiB of positions those can
+// reach are staged in LDS (144 KiB of the CU's 160).  A walk's step reads link and delta at the current position and
+// the candidate's eight bytes — all from LDS, and only the first two on the chain of dependent reads; global memory
+// is touched for the 16-bit ranks after a stranger and for matches longer than eight bytes.
 constexpr uint32_t kMatchTile = 4096, kMatchThreads = 1024;
-constexpr uint32_t kMatchWindowDwords = (W + kMatchTile) / 2;
+constexpr uint32_t kMatchWindow = W + kMatchTile;
+constexpr uint32_t kMatchDataDwords = kMatchWindow / 4 + 4;  // a position's eight bytes are read as three aligned dwords (a multiple of 4)
 
 struct WindowData {
-  const uint8_t *d;   // the input
-  long long origin;   // absolute position of window position 0
-  __device__ __forceinline__ uint32_t load4(int32_t pos) const {
+  const uint8_t *d;       // the input
+  long long origin;       // absolute position of window position 0
+  const uint32_t *s_data; // the window's bytes in LDS
+  __device__ __forceinline__ uint32_t load4(int32_t pos) const {  // anywhere (the long compares run past the window)
     uint32_t v;
     __builtin_memcpy(&v, d + (origin + pos), 4);  // one unaligned dword load
     return v;
   }
-  __device__ __forceinline__ uint64_t load8(int32_t pos) const {
-    uint64_t v;
-    __builtin_memcpy(&v, d + (origin + pos), 8);  // one unaligned dwordx2 load
-    return v;
+  __device__ __forceinline__ uint64_t load8(int32_t pos) const {  // a window position
+    const uint32_t i = (uint32_t)pos >> 2, sh = (uint32_t)pos & 3u;
+    const uint32_t d0 = s_data[i], d1 = s_data[i + 1], d2 = s_data[i + 2];
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sh), hi = __builtin_amdgcn_alignbyte(d2, d1, sh);
+    return ((uint64_t)hi << 32) | lo;
   }
 };
 struct WindowU16 {
   const uint16_t *s;
   __device__ __forceinline__ uint32_t operator()(int32_t pos) const { return s[(uint32_t)pos]; }
 };
+struct WindowU8 {
+  const uint8_t *s;
+  __device__ __forceinline__ uint32_t operator()(int32_t pos) const { return s[(uint32_t)pos]; }
+};
+struct WindowRank {  // the tile's segment's slab from the window's first position on, in global memory
+  const uint16_t *g;
+  __device__ __forceinline__ uint32_t operator()(int32_t pos) const { return g[pos]; }
+};
 
 __global__ __launch_bounds__(1024) void lz_match_kernel(const uint8_t *__restrict__ d, const uint16_t *__restrict__ link,
-                                                        const uint16_t *__restrict__ rank_slabs, uint64_t n_pos, uint64_t size,
-                                                        uint32_t *__restrict__ r128, uint32_t *__restrict__ r32, uint32_t first_tile) {
-  __shared__ uint32_t s_link[kMatchWindowDwords];
-  __shared__ uint32_t s_rank[kMatchWindowDwords];
-  __shared__ uint32_t s_next_chunk;
+                                                        const uint8_t *__restrict__ delta, const uint16_t *__restrict__ rank_slabs,
+                                                        uint64_t n_pos, uint64_t size, uint32_t *__restrict__ r128,
+                                                        uint32_t *__restrict__ r32, uint32_t first_tile,
+                                                        unsigned long long *__restrict__ stats) {
+  // one array, so that the order is this one: the bytes and the deltas within reach of a 16-bit instruction offset
+  __shared__ uint4 s_all[(kMatchDataDwords * 4 + kMatchWindow + kMatchWindow * 2) / 16 + 1];
+  uint32_t *const s_data = reinterpret_cast<uint32_t *>(s_all);
+  uint4 *const s_delta = s_all + kMatchDataDwords / 4;
+  uint4 *const s_link = s_delta + kMatchWindow / 16;
+  uint32_t &s_next = *reinterpret_cast<uint32_t *>(s_link + kMatchWindow / 8);
   const uint32_t tid = threadIdx.x;
-  if (tid == 0) s_next_chunk = 0u;
+  if (tid == 0) s_next = 0u;
   const uint64_t t0 = (uint64_t)(blockIdx.x + first_tile) * kMatchTile;
   const long long origin = (long long)t0 - (long long)W;  // window position 0; a multiple of 4 KiB
   const uint64_t seg = t0 / kLinkSegment;
-  const uint32_t *l32 = reinterpret_cast<const uint32_t *>(link);
-  // the segment's slab starts at position seg * kLinkSegment - W: the window starts (t0 - seg * kLinkSegment) entries in
-  const uint32_t *k32 = reinterpret_cast<const uint32_t *>(rank_slabs + seg * kRankSlab + (t0 - seg * kLinkSegment));
-  for (uint32_t i = tid; i < kMatchWindowDwords; i += kMatchThreads) {
-    const long long pos = origin + 2ll * i;
-    s_link[i] = pos >= 0 ? l32[pos >> 1] : 0u;
-    s_rank[i] = k32[i];
+  {
+    // 144 KiB in nine 16-byte loads per thread, all requested before the first is written to LDS (one load, one wait,
+    // one write at a time this took a fifth of the tile's time)
+    constexpr uint32_t kLinkVecs = kMatchWindow / 8, kDeltaVecs = kMatchWindow / 16, kDataVecs = kMatchWindow / 16;
+    constexpr uint32_t kVecs = kLinkVecs + kDeltaVecs + kDataVecs, kPer = kVecs / kMatchThreads;
+    static_assert(kVecs % kMatchThreads == 0, "the staging loop has no remainder");
+    const uint4 *gl = reinterpret_cast<const uint4 *>(link + origin);    // (origin < 0: not dereferenced below 0)
+    const uint4 *gk = reinterpret_cast<const uint4 *>(delta + origin);
+    const uint4 *gd = reinterpret_cast<const uint4 *>(d + origin);
+    uint4 v[kPer];
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; ++j) {
+      const uint32_t i = tid + j * kMatchThreads;
+      v[j] = make_uint4(0u, 0u, 0u, 0u);
+      if (i < kLinkVecs) {
+        if (origin + 8ll * i >= 0) v[j] = gl[i];
+      } else if (i < kLinkVecs + kDeltaVecs) {
+        if (origin + 16ll * (i - kLinkVecs) >= 0) v[j] = gk[i - kLinkVecs];
+      } else {
+        if (origin + 16ll * (i - kLinkVecs - kDeltaVecs) >= 0) v[j] = gd[i - kLinkVecs - kDeltaVecs];
+      }
+    }
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; ++j) {
+      const uint32_t i = tid + j * kMatchThreads;
+      if (i < kLinkVecs) s_link[i] = v[j];
+      else if (i < kLinkVecs + kDeltaVecs) s_delta[i - kLinkVecs] = v[j];
+      else reinterpret_cast<uint4 *>(s_data)[i - kLinkVecs - kDeltaVecs] = v[j];
+    }
+    if (tid < 4) s_data[kMatchWindow / 4 + tid] = reinterpret_cast<const uint32_t *>(d + origin)[kMatchWindow / 4 + tid];  // the last positions' read-ahead
   }
   __syncthreads();
-  const WindowData data = {d, origin};
+  const WindowData data = {d, origin, s_data};
   const WindowU16 lk = {reinterpret_cast<const uint16_t *>(s_link)};
-  const WindowU16 rk = {reinterpret_cast<const uint16_t *>(s_rank)};
-  // 64 positions at a time, taken by whichever wave is free: walks differ in length by orders of magnitude, and the
-  // workgroup — alone on its CU — lasts as long as its slowest wave
+  const WindowU8 dk = {reinterpret_cast<const uint8_t *>(s_delta)};
+  // the segment's slab starts at position seg * kLinkSegment - W: the window starts (t0 - seg * kLinkSegment) entries in
+  const WindowRank rk = {rank_slabs + seg * kRankSlab + (t0 - seg * kLinkSegment)};
+  // The window base (which positions zlib's window has dropped) is a step function of the position with steps only at
+  // positions = -262 and -261 modulo W (base_at: through (s + 261) / W and s + 262 >= ...), so a tile — 4 KiB, aligned —
+  // has at most three stretches of one value: evaluated once here (scalars) instead of in 64-bit arithmetic per position.
+  const uint64_t step_b = ((t0 + 262u) / W + 1u) * W - 262u, step_a = step_b + 1u;  // the first such pair at or after t0
+  const uint32_t local_b = step_b - t0 < kMatchTile ? (uint32_t)(step_b - t0) : kMatchTile;
+  const uint32_t local_a = step_a - t0 < kMatchTile ? (uint32_t)(step_a - t0) : kMatchTile;
+  auto window_base = [&](uint64_t p) {  // in window coordinates; a base below the window is out of every candidate's reach
+    const long long b = (long long)base_at(p, size) - origin;
+    return (int32_t)(b > 0 ? b : 0);
+  };
+  const int32_t base_0 = window_base(t0), base_b = window_base(step_b), base_a = window_base(step_a);
+  const uint32_t n_local = n_pos - t0 < kMatchTile ? (uint32_t)(n_pos - t0) : kMatchTile;  // (the caller launches no tile past n_pos)
+  // Walks differ in length by two orders of magnitude (ten candidates on average for an .spz stream, two hundred for
+  // the longest), so a wave that gave each lane one position and waited for the slowest had one lane in twelve at
+  // work.  Every lane is a walker of its own instead: one candidate per round; once kRefill lanes of the wave have
+  // finished theirs, they write their results and take the tile's next positions (in any order: a position's entries
+  // depend on nothing but the input).  Results are written then and not when a walk ends: some walk ends in nearly
+  // every round, and the wave would run the store's address arithmetic each time for the sake of three lanes.
+  constexpr uint32_t kRefill = 16;
+  const uint32_t lane = tid & 63u;
+  const unsigned long long below_me = (1ull << lane) - 1ull;
+  MatchWalk<int32_t> walk;
+  bool active = false, loaded = false, dry = false;
+  uint32_t local = 0;
+  uint32_t n_rounds = 0, n_steps = 0;  // for SPZ_AMD_LZ_WALK_STATS' report (stats == nullptr otherwise)
+  uint32_t *const o128 = r128 + t0, *const o32 = r32 + t0;
   for (;;) {
-    uint32_t chunk = 0;
-    if ((tid & 63u) == 0u) chunk = atomicAdd(&s_next_chunk, 1u);
-    chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)chunk);
-    if (chunk >= kMatchTile / 64u) break;
-    const uint32_t local = chunk * 64u + (tid & 63u);
-    const uint64_t p = t0 + local;
-    if (p < n_pos) {
-      // the window base in window coordinates; a base below the window is out of every candidate's reach
-      const long long b = (long long)base_at(p, size) - origin;
+    // ---- the idle lanes write what they found and take new positions
+    const unsigned long long idle = __ballot(!active);
+    const uint32_t n_idle = (uint32_t)__popcll(idle);
+    if (!active && loaded) {
       uint32_t e128, e32;
-      find_matches<int32_t>(data, lk, rk, (int32_t)(W + local), (int32_t)(b > 0 ? b : 0), &e128, &e32);
-      r128[p] = e128;
-      r32[p] = e32;
+      walk.finish(&e128, &e32);
+      o128[local] = e128;
+      o32[local] = e32;
+      loaded = false;
     }
+    if (dry) break;  // (all lanes are idle: the loop below ran until they were)
+    uint32_t first = 0;
+    if (lane == 0) first = atomicAdd(&s_next, n_idle);
+    first = (uint32_t)__builtin_amdgcn_readfirstlane((int)first);
+    if (!active) {
+      local = first + (uint32_t)__popcll(idle & below_me);
+      if (local < n_local) {
+        walk.start(data, (int32_t)(W + local), local >= local_a ? base_a : (local >= local_b ? base_b : base_0));
+        active = true;
+        loaded = true;
+      }
+    }
+    dry = first + n_idle >= n_local;  // the tile's positions are all given out: the walks are run to their ends
+    // ---- one candidate per lane and round, until enough lanes are idle again (a loop of its own: the walks' state
+    // stays where it is, which it did not when taking positions was a branch of the same loop)
+    const uint32_t enough = dry ? 64u : kRefill;
+    for (;;) {
+      const unsigned long long walking = __ballot(active);
+      if (64u - (uint32_t)__popcll(walking) >= enough) break;
+      ++n_rounds;
+      n_steps += (uint32_t)__popcll(walking);
+      if (active) active = walk.step(data, lk, dk, rk);
+    }
+  }
+  if (stats != nullptr && lane == 0) {
+    atomicAdd(&stats[0], (unsigned long long)n_rounds);
+    atomicAdd(&stats[1], (unsigned long long)n_steps);
+    atomicMax(&stats[2], (unsigned long long)n_rounds);
   }
 }
 
@@ -825,7 +946,7 @@ struct LzSession {
   uint64_t size = 0, tail_begin = 0, n_pos = 0;
   uint32_t max_jobs = 0, n_tiles = 0, n_seg = 0;
   size_t pos_padded = 0, data_bytes = 0, rec_words = 0;
-  size_t o_data = 0, o_link = 0, o_rank = 0, o_r128 = 0, o_r32 = 0, o_rec = 0, o_sd = 0, o_sl = 0, o_xd = 0, o_xl = 0, o_info = 0, o_goff = 0;
+  size_t o_data = 0, o_link = 0, o_delta = 0, o_rank = 0, o_r128 = 0, o_r32 = 0, o_rec = 0, o_sd = 0, o_sl = 0, o_xd = 0, o_xl = 0, o_info = 0, o_goff = 0, o_stats = 0;
   char *block = nullptr;
   // A session fed in pieces runs its stages on three streams of its own: the table kernels of one piece are a few dozen
   // workgroups (one per 512 KiB, alone on their CUs for ~2 ms whatever the piece's size) and would leave the chip idle
@@ -842,6 +963,7 @@ struct LzSession {
   uint8_t *d_data() const { return reinterpret_cast<uint8_t *>(block + o_data); }
   uint16_t *d_link() const { return reinterpret_cast<uint16_t *>(block + o_link); }
   uint16_t *d_rank() const { return reinterpret_cast<uint16_t *>(block + o_rank); }
+  uint8_t *d_delta() const { return reinterpret_cast<uint8_t *>(block + o_delta); }
   uint32_t *d_r128() const { return reinterpret_cast<uint32_t *>(block + o_r128); }
   uint32_t *d_r32() const { return reinterpret_cast<uint32_t *>(block + o_r32); }
 };
@@ -895,6 +1017,7 @@ static int lz_session_create(uint64_t size, uint64_t tail_begin, int device, boo
   q->n_seg = (uint32_t)((n_pos + kLinkSegment - 1) / kLinkSegment);
   q->o_link = carve(q->pos_padded * sizeof(uint16_t));
   q->o_rank = carve((size_t)q->n_seg * kRankSlab * sizeof(uint16_t));
+  q->o_delta = carve(q->pos_padded);
   q->o_r128 = carve(q->pos_padded * sizeof(uint32_t));
   q->o_r32 = carve(q->pos_padded * sizeof(uint32_t));
   q->rec_words = (size_t)tail_begin + kTailWindow;
@@ -906,15 +1029,15 @@ static int lz_session_create(uint64_t size, uint64_t tail_begin, int device, boo
   q->o_xl = carve(sym_entries);
   q->o_info = carve((size_t)(q->max_jobs + 1) * sizeof(JobInfo));
   q->o_goff = carve((size_t)q->max_jobs * sizeof(unsigned long long));
+  q->o_stats = carve(64);
   const size_t total = off;
   size_t free_b = 0;
   int rc = device_free_bytes(device, &free_b);
   if (rc == SPZ_AMD_OK && total + (size_t(256) << 20) > free_b) rc = SPZ_AMD_ERR_UNSUPPORTED;  // the caller parses on the host
   if (rc == SPZ_AMD_OK) rc = scratch_acquire(device, total, reinterpret_cast<void **>(&q->block));
   if (rc == SPZ_AMD_OK && own_stream) {
-    if (hipStreamCreateWithFlags(&q->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&q->rank_stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&q->match_stream, hipStreamNonBlocking) != hipSuccess ||
+    if (create_stream(&q->stream, -1) != hipSuccess || create_stream(&q->rank_stream, -1) != hipSuccess ||
+        create_stream(&q->match_stream, -1) != hipSuccess ||
         hipEventCreateWithFlags(&q->producer_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&q->copy_done, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&q->link_done, hipEventDisableTiming) != hipSuccess ||
@@ -939,6 +1062,7 @@ static int lz_session_feed(LzSession *q, const uint8_t *d_src, const uint8_t *h_
   if (upto > q->size) upto = q->size;
   if (!q->zeroed) {
     SPZ_HIP_TRY(hipMemsetAsync(q->d_link(), 0, q->pos_padded * sizeof(uint16_t), st));
+    SPZ_HIP_TRY(hipMemsetAsync(q->block + q->o_stats, 0, 64, st));
     q->zeroed = true;
   }
   if (upto > q->fed) {
@@ -972,13 +1096,21 @@ static int lz_session_feed(LzSession *q, const uint8_t *d_src, const uint8_t *h_
     hipLaunchKernelGGL(lz_table_kernel<TABLE_RANK>, dim3(seg_to - q->seg_done), dim3(kLinkThreads), 0, rst, q->d_data(), q->n_pos, q->d_rank(),
                        q->seg_done);
     SPZ_HIP_TRY(hipGetLastError());
-    q->seg_done = seg_to;
-    if (q->own_stream) {  // the match tiles wait for both tables (and, through them, for the bytes)
+    if (q->own_stream) {  // the chain steps and the match tiles wait for both tables (and, through them, for the bytes)
       SPZ_HIP_TRY(hipEventRecord(q->link_done, st));
       SPZ_HIP_TRY(hipEventRecord(q->rank_done, rst));
       SPZ_HIP_TRY(hipStreamWaitEvent(mst, q->link_done, 0));
       SPZ_HIP_TRY(hipStreamWaitEvent(mst, q->rank_done, 0));
     }
+    {
+      const uint64_t c_first = (uint64_t)q->seg_done * kLinkSegment;
+      const uint64_t c_end = seg_to == q->n_seg ? (uint64_t)q->pos_padded : (uint64_t)seg_to * kLinkSegment;  // multiples of 4 KiB
+      const uint32_t blocks = (uint32_t)((c_end - c_first + 1023) / 1024);
+      hipLaunchKernelGGL(lz_chain_kernel, dim3(blocks), dim3(256), 0, mst, q->d_data(), q->d_link(), q->d_rank(), q->d_delta(), c_first, c_end,
+                         q->n_pos);
+      SPZ_HIP_TRY(hipGetLastError());
+    }
+    q->seg_done = seg_to;
   }
   // a tile's walks read links and ranks up to its last position and input bytes kReadAhead + a dword beyond it
   const uint64_t tables_to = all ? q->pos_padded : (uint64_t)q->seg_done * kLinkSegment;
@@ -989,8 +1121,9 @@ static int lz_session_feed(LzSession *q, const uint8_t *d_src, const uint8_t *h_
     if (q->own_stream) {  // tiles whose tables were done in an earlier feed still need this feed's bytes (their read-ahead)
       SPZ_HIP_TRY(hipStreamWaitEvent(mst, q->copy_done, 0));
     }
-    hipLaunchKernelGGL(lz_match_kernel, dim3(tile_to - q->tile_done), dim3(kMatchThreads), 0, mst, q->d_data(), q->d_link(), q->d_rank(), q->n_pos,
-                       q->size, q->d_r128(), q->d_r32(), q->tile_done);
+    hipLaunchKernelGGL(lz_match_kernel, dim3(tile_to - q->tile_done), dim3(kMatchThreads), 0, mst, q->d_data(), q->d_link(), q->d_delta(), q->d_rank(), q->n_pos,
+                       q->size, q->d_r128(), q->d_r32(), q->tile_done,
+                       std::getenv("SPZ_AMD_LZ_WALK_STATS") ? reinterpret_cast<unsigned long long *>(q->block + q->o_stats) : nullptr);
     SPZ_HIP_TRY(hipGetLastError());
     q->tile_done = tile_to;
   }
@@ -1111,7 +1244,11 @@ static int parse_open_impl(LzSession *q, const uint8_t *h_data, const uint8_t *d
   rc = lz_session_feed(q, d_copy, d_copy ? nullptr : h_data, size, q->stream);
   if (rc != SPZ_AMD_OK) return rc;
   // the caller's tail parse can run now, beside the kernels above: its records are not read before this point
-  if (produce_tail_rec) produce_tail_rec(produce_arg);
+  if (produce_tail_rec) {
+    const auto t0 = std::chrono::steady_clock::now();
+    produce_tail_rec(produce_arg);
+    if (timing) std::fprintf(stderr, "[lz77] the caller's tail parse %.4f s (beside the kernels)\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+  }
   std::vector<uint32_t> tail_states(kTailWindow);
   for (uint32_t k = 0; k < kTailWindow; ++k) tail_states[k] = h_tail_rec[2 * k];
   if (q->own_stream) {  // the later stages run on the default stream
@@ -1120,6 +1257,13 @@ static int parse_open_impl(LzSession *q, const uint8_t *h_data, const uint8_t *d
     SPZ_HIP_TRY(hipStreamSynchronize(q->match_stream));
   }
   lap("tables+matches");
+  if (std::getenv("SPZ_AMD_LZ_WALK_STATS")) {  // (the counting itself costs the match kernel a third of its time)
+    unsigned long long h[3] = {0, 0, 0};
+    SPZ_HIP_TRY(hipMemcpy(h, q->block + q->o_stats, sizeof(h), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "[lz77] walks: %llu positions, %llu candidates (%.1f each), %llu rounds of a wave (%.1f per tile and wave, longest %llu), %.0f %% of the lanes at work\n",
+                 (unsigned long long)q->n_pos, h[1], (double)h[1] / (double)q->n_pos, h[0], (double)h[0] / ((double)q->n_tiles * (kMatchThreads / 64)), h[2],
+                 h[0] ? 100.0 * (double)h[1] / (64.0 * (double)h[0]) : 0.0);
+  }
   hipStream_t st = nullptr;
   // stage 3, with larger jobs if two neighbours do not meet (the tables do not depend on the jobs)
   uint32_t n_jobs = 0, job_bytes = 0;

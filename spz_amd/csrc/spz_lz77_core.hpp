@@ -102,41 +102,84 @@ SPZ_LZ_HD uint32_t entry_byte(uint32_t e) { return e & 0xffu; }
 // the window base and at most MAX_DIST back, every later one strictly above `limit`; positions only fall along
 // the chain, so the first position that fails ends the walk for every later one too, whether it is a stranger or
 // not; the budget ends it at chain index 128; strangers can never be taken (a candidate needs 3 equal bytes).
-template <class Pos, class Data, class Link, class Rank>
-SPZ_LZ_HD void find_matches(const Data &data, const Link &link, const Rank &rank, Pos p, Pos base, uint32_t *r128,
-                            uint32_t *r32) {
-  const uint64_t s8 = data.load8(p);
-  const uint32_t s4 = (uint32_t)s8;
-  const uint32_t none = encode_entry(0, 0, s4 & 0xffu);
-  *r128 = none;
-  *r32 = none;
-  const Pos limit = (p - base > (Pos)MAX_DIST) ? p - (Pos)MAX_DIST : base;
-  const uint32_t rank_p = rank(p);
-  uint32_t best = MIN_MATCH - 1, best_dist = 0;
-  bool snapped = false;
-  Pos cur = p;
-  for (;;) {
+// How far along zlib's chain a step of the hash2 chain goes, in one byte per position (stage 1b): for a position c
+// whose link leads to t,
+//   1 ... kChainFar   rank(c) - rank(t), the steps zlib's own walk needs from c to t, when t has c's three bytes
+//                     (kChainFar: that many or more — the walk's budget is MAX_CHAIN, so it ends there either way);
+//   kChainStranger    t has other bytes (it shares only the hash2 value): the walk passes over it.
+// A walk adds these up instead of reading two ranks per candidate; after a stranger it finds its place again from the
+// 16-bit ranks (rare: 1.5 % of an .spz stream's candidates).
+constexpr uint32_t kChainFar = 250, kChainStranger = 255;
+SPZ_LZ_HD uint32_t chain_delta(uint32_t rank_c, uint32_t rank_t, bool same_bytes) {
+  if (!same_bytes) return kChainStranger;
+  const uint32_t d = (rank_c - rank_t) & 0xffffu;
+  return d < kChainFar ? d : kChainFar;
+}
+
+// The walk is a state machine of one candidate per step, so that the kernel can give a lane whose walk has ended the
+// next position while its neighbours are still walking (walks differ in length by two orders of magnitude); the host
+// model runs the same steps in a plain loop.  A step's next position and chain index come from link[] and delta[] at the
+// CURRENT position, so the candidate's bytes are off the chain of dependent reads.
+template <class Pos>
+struct MatchWalk {
+  uint64_t s8;  // the eight bytes at p
+  Pos p, base, limit, cur;
+  uint32_t k;   // chain index of cur, + 1 (0 at p itself)
+  uint32_t best, best_dist, best32, dist32;  // ..32: what a budget of SHORT_CHAIN had found
+  bool snapped, synced;
+
+  template <class Data>
+  SPZ_LZ_HD void start(const Data &data, Pos p_, Pos base_) {
+    p = p_;
+    base = base_;
+    s8 = data.load8(p);
+    limit = (p - base > (Pos)MAX_DIST) ? p - (Pos)MAX_DIST : base;
+    k = 0;
+    best = MIN_MATCH - 1;
+    best_dist = 0;
+    best32 = 0;
+    dist32 = 0;
+    snapped = false;
+    synced = true;
+    cur = p;
+  }
+
+  // One position of the hash2 chain.  false: the walk is over.  Written as selects rather than nested conditions: on
+  // the GPU every nested condition is a handful of scalar mask instructions per round for the whole wave, and those —
+  // not the reads — were what a round's time went to (profiles/README.md, round 3: 100 scalar instructions per round).
+  // Two real branches are left, both rare: finding the chain index again after a stranger, and matches of 8+ bytes.
+  template <class Data, class Link, class Delta, class Rank>
+  SPZ_LZ_HD bool step(const Data &data, const Link &link, const Delta &delta, const Rank &rank) {
     const uint32_t gap = link(cur);
-    if (gap == 0) break;
-    cur -= (Pos)gap;
-    if (cur <= base || p - cur > (Pos)MAX_DIST) break;  // out of reach for the first candidate and for any later one
-    // ONE eight-byte load per candidate: the three bytes that make it a candidate at all, and — for all but the rare
-    // candidate that agrees on all eight — its match length.  (zlib's own order — the byte at the best length so far
-    // first, then the first two, then the rest — is a shortcut to the same length; as separate loads it was three
-    // dependent trips through the vector cache per candidate.)
+    const uint32_t dk = delta(cur);
+    cur -= (Pos)gap;  // gap 0: cur itself, whose bytes are read and ignored
+    // ONE eight-byte read per candidate: its match length for all but the rare candidate that agrees on all eight
+    // (zlib's own order — the byte at the best length so far first, then the first two, then the rest — is a shortcut
+    // to the same length), and, after a stranger, whether this one has p's three bytes again.
     const uint64_t x8 = data.load8(cur) ^ s8;
-    if ((x8 & 0xffffffull) != 0ull) continue;            // a stranger on the hash2 chain
-    const uint32_t k = (rank_p - rank(cur) - 1u) & 0xffffu;  // its index in zlib's chain
-    if (k >= MAX_CHAIN) break;
-    if (k > 0 && cur <= limit) break;
-    if (k >= SHORT_CHAIN && !snapped) {
-      *r32 = encode_entry(best, best_dist, s4 & 0xffu);  // what a budget of 32 has found
-      snapped = true;
-    }
-    uint32_t len;
-    if (x8 != 0ull) {
-      len = (uint32_t)__builtin_ctzll(x8) >> 3;  // 3 ... 7
+    // out of reach for the first candidate and for any later one
+    const bool reach = (gap != 0u) & (cur > base) & (p - cur <= (Pos)MAX_DIST);
+    const bool same = (x8 & 0xffffffull) == 0ull;
+    // passed over: not p's bytes (known from delta[] while the walk is among p's bytes, from the bytes after a stranger,
+    // when delta[] is about the stranger's bytes)
+    const bool skip = synced ? dk == kChainStranger : !same;
+    if (!synced & !skip & reach) {
+      const uint32_t far = (rank(p) - rank(cur)) & 0xffffu;
+      k = far < kChainFar ? far : kChainFar;
     } else {
+      k += (synced & !skip) ? dk : 0u;
+    }
+    synced = !skip;
+    const bool cand = reach & !skip;
+    // chain index k - 1 >= MAX_CHAIN, or a later candidate at or below the limit
+    bool over = (!reach) | (cand & ((k > MAX_CHAIN) | ((k > 1u) & (cur <= limit))));
+    const bool take = cand & !over;
+    const bool snap = take & (k > SHORT_CHAIN) & !snapped;  // what a budget of 32 has found
+    best32 = snap ? best : best32;
+    dist32 = snap ? best_dist : dist32;
+    snapped |= snap;
+    uint32_t len = (uint32_t)__builtin_ctzll(x8 | (1ull << 63)) >> 3;  // 3 ... 7 for a candidate
+    if (take & (x8 == 0ull)) {
       len = 8;
       while (len < MAX_MATCH) {
         const uint32_t x = data.load4(p + (Pos)len) ^ data.load4(cur + (Pos)len);
@@ -148,15 +191,28 @@ SPZ_LZ_HD void find_matches(const Data &data, const Link &link, const Rank &rank
       }
       if (len > MAX_MATCH) len = MAX_MATCH;
     }
-    if (len > best) {
-      best = len;
-      best_dist = (uint32_t)(p - cur);
-      if (len >= NICE_MATCH) break;
-    }
+    const bool better = take & (len > best);
+    best = better ? len : best;
+    best_dist = better ? (uint32_t)(p - cur) : best_dist;
+    over |= better & (len >= NICE_MATCH);
+    return !over;
   }
-  const uint32_t r = encode_entry(best, best_dist, s4 & 0xffu);
-  if (!snapped) *r32 = r;  // the walk ended inside the short budget
-  *r128 = r;
+
+  SPZ_LZ_HD void finish(uint32_t *r128, uint32_t *r32) const {
+    const uint32_t r = encode_entry(best, best_dist, (uint32_t)s8 & 0xffu);
+    *r32 = snapped ? encode_entry(best32, dist32, (uint32_t)s8 & 0xffu) : r;  // not snapped: the walk ended inside the short budget
+    *r128 = r;
+  }
+};
+
+template <class Pos, class Data, class Link, class Delta, class Rank>
+SPZ_LZ_HD void find_matches(const Data &data, const Link &link, const Delta &delta, const Rank &rank, Pos p, Pos base, uint32_t *r128,
+                            uint32_t *r32) {
+  MatchWalk<Pos> w;
+  w.start(data, p, base);
+  while (w.step(data, link, delta, rank)) {
+  }
+  w.finish(r128, r32);
 }
 
 // ---- stage 3 -------------------------------------------------------------------------------------------

@@ -120,6 +120,13 @@ struct ModelParser final : HeadParser {
         rank[p] = count[hash3(data[p], data[p + 1], data[p + 2])]++;
       }
     }
+    // ---- stage 1b: zlib's chain steps per link
+    std::vector<uint8_t> delta(n_pos, 0);
+    for (uint64_t p = 0; p < n_pos; ++p) {
+      if (link[p] == 0) continue;
+      const uint64_t t = p - link[p];
+      delta[p] = static_cast<uint8_t>(chain_delta(rank[p], rank[t], data[p] == data[t] && data[p + 1] == data[t + 1] && data[p + 2] == data[t + 2]));
+    }
     // ---- stage 2: match tables
     std::vector<uint32_t> r128(n_pos), r32(n_pos);
     struct Data {
@@ -137,8 +144,9 @@ struct ModelParser final : HeadParser {
     } dacc{data};
     auto lacc = [&](int64_t pos) { return static_cast<uint32_t>(link[pos]); };
     auto racc = [&](int64_t pos) { return static_cast<uint32_t>(rank[pos]); };
+    auto kacc = [&](int64_t pos) { return static_cast<uint32_t>(delta[pos]); };
     for (uint64_t p = 0; p < n_pos; ++p) {
-      find_matches<int64_t>(dacc, lacc, racc, static_cast<int64_t>(p), static_cast<int64_t>(base_at(p, size)), &r128[p], &r32[p]);
+      find_matches<int64_t>(dacc, lacc, kacc, racc, static_cast<int64_t>(p), static_cast<int64_t>(base_at(p, size)), &r128[p], &r32[p]);
     }
     // ---- stage 3, with larger jobs if two neighbours do not meet
     auto a128 = [&](uint64_t pos) { return r128[pos]; };
