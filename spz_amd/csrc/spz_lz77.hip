@@ -10,10 +10,12 @@
 //   lz_table_kernel   (twice) one workgroup per 512 KiB of input: a 65536-entry table in LDS gives every position the
 //                     distance to the previous position with the same well-mixed hash of its three bytes (link[])
 //                     and its running count among the positions with the same zlib hash (rank[]).
-//   lz_match_kernel   one workgroup per 4 KiB of positions, their reach of links and ranks in LDS (144 KiB): every
-//                     thread walks link[] — positions with the same three bytes, where zlib's own chain of 128 is
-//                     mostly strangers for .spz data — and knows from two ranks how far along zlib's chain a
-//                     candidate is; it writes the two results per position (chain budget 128 and 32).
+//   lz_chain_kernel   per position, how many steps of zlib's chain its link is worth (delta[], one byte).
+//   lz_match_kernel   one workgroup per 4 KiB of positions, their reach of links, deltas and input bytes in LDS
+//                     (144 KiB): every lane walks link[] — positions with the same three bytes, where zlib's own
+//                     chain of 128 is mostly strangers for .spz data — adding up delta[] to know how far along
+//                     zlib's chain a candidate is, and takes the tile's next position when its walk ends; two
+//                     results per position (chain budget 128 and 32).
 //   lz_parse_kernel   one lane per 8 KiB job: deflate_slow's loop with the table lookup in place of the search
 //                     (each lane keeps the 32 entries around its position in LDS: one HBM latency per 32 positions),
 //                     recording the lazy state at every loop top (one word per input position).
@@ -23,7 +25,7 @@
 //
 // The last 64-96 KiB of the input (where zlib's lookahead runs out and its window's stale bytes matter) are
 // parsed by spz_deflate.cpp's serial job on the host; its records arrive here as the last job's successor.
-// HBM per input byte: 1 (input) + 4.1 (links, ranks) + 8 (tables) + 4 (records) + 6 (job and stitch symbols); the dense symbol
+// HBM per input byte: 1 (input) + 5.1 (links, ranks, deltas) + 8 (tables) + 4 (records) + 6 (job and stitch symbols); the dense symbol
 // arrays reuse the tables' memory.
 #include <hip/hip_runtime.h>
 
@@ -97,6 +99,10 @@ __global__ __launch_bounds__(512) void lz_table_kernel(const uint8_t *__restrict
       const uint8_t b0 = (uint8_t)bytes, b1 = (uint8_t)(bytes >> 8), b2 = (uint8_t)(bytes >> 16);
       h = MODE == TABLE_LINK ? hash2(b0, b1, b2) : hash3(b0, b1, b2);
     }
+    // (The table divided among the waves by key instead of the positions — every wave looks through all 512 keys of a
+    // round for its own, queues them and handles 64 at a time, so that no wave ever waits for another's table accesses
+    // and a round has one barrier instead of eight — was built and measured in round 3: 12.0 + 9.9 ms against this
+    // kernel's 10.5 + 8.3; the queueing costs more instructions than the barriers cost time.)
     // lanes of this wave with the same key
     // bit by bit: the lanes that agree with this one on bit b are the ballot of that bit or its complement
     // (17 ballots instead of 64 readlane / compare rounds)
@@ -204,8 +210,8 @@ struct WindowRank {  // the tile's segment's slab from the window's first positi
 
 __global__ __launch_bounds__(1024) void lz_match_kernel(const uint8_t *__restrict__ d, const uint16_t *__restrict__ link,
                                                         const uint8_t *__restrict__ delta, const uint16_t *__restrict__ rank_slabs,
-                                                        uint64_t n_pos, uint64_t size, uint32_t *__restrict__ r128,
-                                                        uint32_t *__restrict__ r32, uint32_t first_tile,
+                                                        uint64_t n_pos, uint64_t size, uint2 *__restrict__ r,
+                                                        uint32_t first_tile,
                                                         unsigned long long *__restrict__ stats) {
   // one array, so that the order is this one: the bytes and the deltas within reach of a 16-bit instruction offset
   __shared__ uint4 s_all[(kMatchDataDwords * 4 + kMatchWindow + kMatchWindow * 2) / 16 + 1];
@@ -280,7 +286,7 @@ __global__ __launch_bounds__(1024) void lz_match_kernel(const uint8_t *__restric
   bool active = false, loaded = false, dry = false;
   uint32_t local = 0;
   uint32_t n_rounds = 0, n_steps = 0;  // for SPZ_AMD_LZ_WALK_STATS' report (stats == nullptr otherwise)
-  uint32_t *const o128 = r128 + t0, *const o32 = r32 + t0;
+  uint2 *const o = r + t0;  // {budget 128, budget 32} per position: one store (a lane's store is a cache line of its own)
   for (;;) {
     // ---- the idle lanes write what they found and take new positions
     const unsigned long long idle = __ballot(!active);
@@ -288,8 +294,7 @@ __global__ __launch_bounds__(1024) void lz_match_kernel(const uint8_t *__restric
     if (!active && loaded) {
       uint32_t e128, e32;
       walk.finish(&e128, &e32);
-      o128[local] = e128;
-      o32[local] = e32;
+      o[local] = make_uint2(e128, e32);
       loaded = false;
     }
     if (dry) break;  // (all lanes are idle: the loop below ran until they were)
@@ -334,6 +339,11 @@ struct JobInfo {
 };
 
 constexpr uint32_t kParseWindow = 32;  // table entries a lane fetches at a time
+// A job records its lazy state at the loop tops of its first kRecordWindow positions only: its predecessor's continuation
+// meets it within a few hundred positions, a few thousand after long runs — and one that has not by then sends the
+// stage to the next job size, as one that never does.  (Each record is a scattered 4-byte store, 64 cache lines per
+// instruction: recorded at every loop top they were a third of what the kernel's stores cost.)
+constexpr uint32_t kRecordWindow = 2048;  // for the smallest jobs; larger ones (the second attempt on) record throughout
 
 // The loop's next position depends on the entry it has just read, so a read from HBM per loop top would be all
 // latency: each lane keeps the 32 entries from its position on in LDS ([entry][lane]: conflict-free), for both tables.
@@ -346,22 +356,22 @@ struct EntryWindow {
   __device__ __forceinline__ uint32_t operator()(uint32_t pos) const { return s_win[(pos - base) * 64 + lane]; }
 };
 
-__device__ __forceinline__ void fill_window(uint32_t *s_win, const uint32_t *table, uint32_t from, uint32_t lane) {
+__device__ __forceinline__ void fill_windows(uint32_t *s_win128, uint32_t *s_win32, const uint2 *table, uint32_t from, uint32_t lane) {
 #pragma unroll
-  for (uint32_t q = 0; q < kParseWindow / 4; ++q) {
+  for (uint32_t q = 0; q < kParseWindow / 2; ++q) {
     uint4 v;
-    __builtin_memcpy(&v, table + from + 4 * q, sizeof(v));  // dword-aligned
-    s_win[(4 * q + 0) * 64 + lane] = v.x;
-    s_win[(4 * q + 1) * 64 + lane] = v.y;
-    s_win[(4 * q + 2) * 64 + lane] = v.z;
-    s_win[(4 * q + 3) * 64 + lane] = v.w;
+    __builtin_memcpy(&v, table + from + 2 * q, sizeof(v));  // 8-byte aligned
+    s_win128[(2 * q + 0) * 64 + lane] = v.x;
+    s_win32[(2 * q + 0) * 64 + lane] = v.y;
+    s_win128[(2 * q + 1) * 64 + lane] = v.z;
+    s_win32[(2 * q + 1) * 64 + lane] = v.w;
   }
 }
 
-__global__ __launch_bounds__(64) void lz_parse_kernel(const uint32_t *__restrict__ r128, const uint32_t *__restrict__ r32,
+__global__ __launch_bounds__(64) void lz_parse_kernel(const uint2 *__restrict__ r,
                                                       uint32_t job_bytes, uint32_t head_end, uint32_t n_jobs,
-                                                      uint32_t *__restrict__ rec, uint16_t *__restrict__ sym_dist,
-                                                      uint8_t *__restrict__ sym_lc, JobInfo *__restrict__ info, uint32_t first_job) {
+                                                      uint32_t *__restrict__ rec, uint32_t *__restrict__ sym,
+                                                      JobInfo *__restrict__ info, uint32_t first_job) {
   __shared__ uint32_t s_win128[kParseWindow * 64];
   __shared__ uint32_t s_win32[kParseWindow * 64];
   const uint32_t lane = threadIdx.x;
@@ -369,14 +379,21 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint32_t *__restrict
   const bool mine = j < n_jobs;
   const uint32_t begin = mine ? j * job_bytes : 0u;
   const uint32_t next = mine ? (begin + job_bytes < head_end ? begin + job_bytes : head_end) : 0u;
+  const uint32_t record = job_bytes <= kSmallestJob ? kRecordWindow : job_bytes;
   EntryWindow e128 = {s_win128, lane, 0u}, e32 = {s_win32, lane, 0u};
-  uint16_t *od = sym_dist + (size_t)j * job_symbol_stride(job_bytes);
-  uint8_t *ol = sym_lc + (size_t)j * job_symbol_stride(job_bytes);
+  // A job's symbols, one word each (distance | length or literal << 16), are stored four at a time: the lanes' symbol
+  // arrays are 32 KiB apart, so a store is 64 cache lines whatever its width, and as 2 + 1 bytes per symbol the stores
+  // were what the kernel's time went to.
+  uint32_t *const o = sym + (size_t)j * job_symbol_stride(job_bytes);  // 16-byte aligned (the stride is a multiple of 4)
   uint32_t s = begin, nsym = 0, base = 0xffffffffu - kParseWindow;  // no window yet
   LazyState<uint32_t> st;
+  uint4 last4 = make_uint4(0u, 0u, 0u, 0u);  // the last symbols, newest in .w
   auto emit = [&](uint32_t dist, uint32_t lc) {
-    od[nsym] = (uint16_t)dist;
-    ol[nsym] = (uint8_t)lc;
+    last4.x = last4.y;
+    last4.y = last4.z;
+    last4.z = last4.w;
+    last4.w = dist | (lc << 16);
+    if ((nsym & 3u) == 3u) *reinterpret_cast<uint4 *>(o + (nsym - 3u)) = last4;
     ++nsym;
   };
   for (;;) {
@@ -385,27 +402,32 @@ __global__ __launch_bounds__(64) void lz_parse_kernel(const uint32_t *__restrict
     if (__any(active && s - base >= kParseWindow)) {
       if (active) {
         base = s;  // the tables are padded past the last position a job reads
-        fill_window(s_win128, r128, s, lane);
-        fill_window(s_win32, r32, s, lane);
+        fill_windows(s_win128, s_win32, r, s, lane);
         e128.base = e32.base = s;
       }
     }
     if (active) {
-      rec[s] = pack_state(st, s);
+      if (s - begin < record) rec[s] = pack_state(st, s);
       lazy_step(s, st, e128, e32, emit);
     }
   }
   if (!mine) return;
-  JobInfo &o = info[j];
-  o.n = nsym;
-  o.end_s = s;
-  o.end_available = st.match_available;
-  o.end_length = st.match_length;
-  o.end_byte = st.byte_before;
-  o.end_start = st.match_start;
+  {  // the symbols since the last full four
+    const uint32_t left = nsym & 3u;
+    if (left >= 3u) o[nsym - 3u] = last4.y;
+    if (left >= 2u) o[nsym - 2u] = last4.z;
+    if (left >= 1u) o[nsym - 1u] = last4.w;
+  }
+  JobInfo &ji = info[j];
+  ji.n = nsym;
+  ji.end_s = s;
+  ji.end_available = st.match_available;
+  ji.end_length = st.match_length;
+  ji.end_byte = st.byte_before;
+  ji.end_start = st.match_start;
 }
 
-__global__ __launch_bounds__(64) void lz_stitch_kernel(const uint32_t *__restrict__ r128, const uint32_t *__restrict__ r32,
+__global__ __launch_bounds__(64) void lz_stitch_kernel(const uint2 *__restrict__ r,
                                                        uint32_t job_bytes, uint32_t head_end, uint32_t n_jobs,
                                                        const uint32_t *__restrict__ rec, uint16_t *__restrict__ x_dist,
                                                        uint8_t *__restrict__ x_lc, JobInfo *__restrict__ info) {
@@ -413,8 +435,8 @@ __global__ __launch_bounds__(64) void lz_stitch_kernel(const uint32_t *__restric
   if (j >= n_jobs) return;
   const uint32_t next = (j + 1) * job_bytes < head_end ? (j + 1) * job_bytes : head_end;
   const uint32_t stop = (uint32_t)stitch_end(j, n_jobs, job_bytes, head_end);
-  auto e128 = [&](uint32_t pos) { return r128[pos]; };
-  auto e32 = [&](uint32_t pos) { return r32[pos]; };
+  auto e128 = [&](uint32_t pos) { return r[pos].x; };
+  auto e32 = [&](uint32_t pos) { return r[pos].y; };
   uint16_t *od = x_dist + (size_t)j * job_symbol_stride(job_bytes);
   uint8_t *ol = x_lc + (size_t)j * job_symbol_stride(job_bytes);
   uint32_t s = info[j].end_s, nsym = 0, spliced = 0;
@@ -449,8 +471,7 @@ __global__ __launch_bounds__(64) void lz_stitch_kernel(const uint32_t *__restric
 }
 
 // ---- stage 4: the contributed ranges, concatenated ---------------------------------------------------------
-__global__ __launch_bounds__(256) void lz_compact_kernel(const uint16_t *__restrict__ sym_dist,
-                                                         const uint8_t *__restrict__ sym_lc,
+__global__ __launch_bounds__(256) void lz_compact_kernel(const uint32_t *__restrict__ sym,
                                                          const uint16_t *__restrict__ x_dist, const uint8_t *__restrict__ x_lc,
                                                          const JobInfo *__restrict__ info, uint32_t job_bytes,
                                                          const unsigned long long *__restrict__ goff,
@@ -460,8 +481,9 @@ __global__ __launch_bounds__(256) void lz_compact_kernel(const uint16_t *__restr
   const size_t src = (size_t)j * job_symbol_stride(job_bytes) + lo, xsrc = (size_t)j * job_symbol_stride(job_bytes);
   const unsigned long long dst = goff[j];
   for (uint32_t i = threadIdx.x; i < n; i += 256) {
-    dense_dist[dst + i] = sym_dist[src + i];
-    dense_lc[dst + i] = sym_lc[src + i];
+    const uint32_t v = sym[src + i];
+    dense_dist[dst + i] = (uint16_t)v;
+    dense_lc[dst + i] = (uint8_t)(v >> 16);
   }
   for (uint32_t i = threadIdx.x; i < x; i += 256) {
     dense_dist[dst + n + i] = x_dist[xsrc + i];
@@ -1018,13 +1040,13 @@ static int lz_session_create(uint64_t size, uint64_t tail_begin, int device, boo
   q->o_link = carve(q->pos_padded * sizeof(uint16_t));
   q->o_rank = carve((size_t)q->n_seg * kRankSlab * sizeof(uint16_t));
   q->o_delta = carve(q->pos_padded);
-  q->o_r128 = carve(q->pos_padded * sizeof(uint32_t));
-  q->o_r32 = carve(q->pos_padded * sizeof(uint32_t));
+  q->o_r128 = carve(q->pos_padded * sizeof(uint2));  // {budget 128, budget 32} per position
+  q->o_r32 = q->o_r128 + q->pos_padded * sizeof(uint32_t);  // (the second half, for the dense literal / length array later)
   q->rec_words = (size_t)tail_begin + kTailWindow;
   q->o_rec = carve(q->rec_words * sizeof(uint32_t));
   const size_t sym_entries = (size_t)q->max_jobs * job_symbol_stride(kSmallestJob);  // larger jobs need fewer
-  q->o_sd = carve(sym_entries * sizeof(uint16_t));
-  q->o_sl = carve(sym_entries);
+  q->o_sd = carve(sym_entries * sizeof(uint32_t));  // a word per symbol: distance | length or literal << 16
+  q->o_sl = q->o_sd;
   q->o_xd = carve(sym_entries * sizeof(uint16_t));
   q->o_xl = carve(sym_entries);
   q->o_info = carve((size_t)(q->max_jobs + 1) * sizeof(JobInfo));
@@ -1122,7 +1144,7 @@ static int lz_session_feed(LzSession *q, const uint8_t *d_src, const uint8_t *h_
       SPZ_HIP_TRY(hipStreamWaitEvent(mst, q->copy_done, 0));
     }
     hipLaunchKernelGGL(lz_match_kernel, dim3(tile_to - q->tile_done), dim3(kMatchThreads), 0, mst, q->d_data(), q->d_link(), q->d_delta(), q->d_rank(), q->n_pos,
-                       q->size, q->d_r128(), q->d_r32(), q->tile_done,
+                       q->size, reinterpret_cast<uint2 *>(q->d_r128()), q->tile_done,
                        std::getenv("SPZ_AMD_LZ_WALK_STATS") ? reinterpret_cast<unsigned long long *>(q->block + q->o_stats) : nullptr);
     SPZ_HIP_TRY(hipGetLastError());
     q->tile_done = tile_to;
@@ -1234,8 +1256,7 @@ static int parse_open_impl(LzSession *q, const uint8_t *h_data, const uint8_t *d
   uint8_t *d_data = q->d_data();
   uint32_t *d_r128 = q->d_r128(), *d_r32 = q->d_r32();
   uint32_t *d_rec = reinterpret_cast<uint32_t *>(block + o_rec);
-  uint16_t *d_sd = reinterpret_cast<uint16_t *>(block + q->o_sd);
-  uint8_t *d_sl = reinterpret_cast<uint8_t *>(block + q->o_sl);
+  uint32_t *d_sym = reinterpret_cast<uint32_t *>(block + q->o_sd);
   uint16_t *d_xd = reinterpret_cast<uint16_t *>(block + q->o_xd);
   uint8_t *d_xl = reinterpret_cast<uint8_t *>(block + q->o_xl);
   JobInfo *d_info = reinterpret_cast<JobInfo *>(block + q->o_info);
@@ -1278,11 +1299,11 @@ static int parse_open_impl(LzSession *q, const uint8_t *h_data, const uint8_t *d
     SPZ_HIP_TRY(hipMemsetAsync(d_rec, 0, rec_words * sizeof(uint32_t), st));
     SPZ_HIP_TRY(hipMemcpyAsync(d_rec + tail_begin, tail_states.data(), (size_t)kTailWindow * sizeof(uint32_t), hipMemcpyHostToDevice, st));
     SPZ_HIP_TRY(hipMemsetAsync(d_info, 0, (size_t)(n_jobs + 1) * sizeof(JobInfo), st));
-    hipLaunchKernelGGL(lz_parse_kernel, dim3(parse_blocks), dim3(64), 0, st, d_r128, d_r32, job_bytes, (uint32_t)tail_begin, n_jobs, d_rec,
-                       d_sd, d_sl, d_info, 0u);
+    hipLaunchKernelGGL(lz_parse_kernel, dim3(parse_blocks), dim3(64), 0, st, reinterpret_cast<const uint2 *>(d_r128), job_bytes, (uint32_t)tail_begin, n_jobs, d_rec,
+                       d_sym, d_info, 0u);
     SPZ_HIP_TRY(hipGetLastError());
     lap("parse");
-    hipLaunchKernelGGL(lz_stitch_kernel, dim3(parse_blocks), dim3(64), 0, st, d_r128, d_r32, job_bytes, (uint32_t)tail_begin, n_jobs,
+    hipLaunchKernelGGL(lz_stitch_kernel, dim3(parse_blocks), dim3(64), 0, st, reinterpret_cast<const uint2 *>(d_r128), job_bytes, (uint32_t)tail_begin, n_jobs,
                        d_rec, d_xd, d_xl, d_info);
     SPZ_HIP_TRY(hipGetLastError());
     info.resize(n_jobs + 1);
@@ -1312,7 +1333,7 @@ static int parse_open_impl(LzSession *q, const uint8_t *h_data, const uint8_t *d
   // the tables are done with: their memory takes the dense arrays (2 B and 1 B per symbol, at most one symbol per position)
   uint16_t *dense_dist = reinterpret_cast<uint16_t *>(d_r128);
   uint8_t *dense_lc = reinterpret_cast<uint8_t *>(d_r32);
-  hipLaunchKernelGGL(lz_compact_kernel, dim3(n_jobs), dim3(256), 0, st, d_sd, d_sl, d_xd, d_xl, d_info, job_bytes, d_goff, dense_dist,
+  hipLaunchKernelGGL(lz_compact_kernel, dim3(n_jobs), dim3(256), 0, st, d_sym, d_xd, d_xl, d_info, job_bytes, d_goff, dense_dist,
                      dense_lc);
   SPZ_HIP_TRY(hipGetLastError());
   SPZ_HIP_TRY(hipStreamSynchronize(st));

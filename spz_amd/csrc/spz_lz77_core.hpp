@@ -9,7 +9,8 @@
 //               link[p] = distance to the nearest earlier position with the same value of a DIFFERENT, well-mixed
 //               hash of the triple (hash2), and rank[p] = how many earlier positions share p's zlib hash (mod 2^16).
 //               Walking link[] visits (almost) only positions with the same three bytes, and the difference of
-//               two ranks says how many steps zlib's own walk needs from one to the other.
+//               two ranks says how many steps zlib's own walk needs from one to the other — kept per link as one
+//               byte, delta[p] (chain_delta below), so that a walk adds bytes up and reads ranks only after a stranger.
 //   2. matches  r128[p] / r32[p] = the input byte at p and what longest_match() returns at a loop top at p with a
 //               chain budget of 128 / 32 (the budget is 32 when the previous match is >= good_match) and no
 //               previous match.  A
@@ -94,8 +95,8 @@ SPZ_LZ_HD uint32_t entry_byte(uint32_t e) { return e & 0xffu; }
 
 // Stage 2 for one position p.  Positions are in the caller's coordinates (Pos: absolute int64_t on the host,
 // window-relative int32_t in the kernel).  `data.load4(pos)` / `data.load8(pos)`: the four / eight input bytes at pos, little endian (pos up
-// to p + kReadAhead); `link(pos)`, `rank(pos)`: stage 1's values (ranks need a common origin only among the
-// positions one walk can reach); `base`: base_at(p) in the same coordinates (anything at or below p - W stands
+// to p + kReadAhead); `link(pos)`, `delta(pos)`, `rank(pos)`: stage 1's values (ranks need a common origin only among
+// the positions one walk can reach, and are read only after a stranger); `base`: base_at(p) in the same coordinates (anything at or below p - W stands
 // for "not in reach").  p has a full lookahead.
 //
 // zlib's walk, restated on the positions with p's three bytes: its first candidate (chain index 0) must lie above
