@@ -45,7 +45,9 @@ def test_large_clouds_are_timed_and_the_choice_is_never_the_slowest(cuda):
     n, deg = 6_000_000, 3
     p_out = D.alloc_placed(n, deg, cuda, 3, None, "decode", max_candidates=4)
     r = p_out.report
-    assert 1 <= r["sh_placements_timed"] <= 4
+    # up to three rounds (each with a new block for the other arrays) of up to max_candidates placements of the sh array:
+    # a box on which no placement of a round is clearly faster than the round's slowest goes through all of them
+    assert 1 <= r["sh_placements_timed"] <= 3 * 4
     assert 0.0 < r["probe_ms_chosen"] <= r["probe_ms_first"] <= r["probe_ms_slowest"]
     cloud = make_cloud_torch(n, deg, 9, cuda)
     lay = abi.stream_layout(n, deg, 3)
