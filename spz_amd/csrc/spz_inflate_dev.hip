@@ -752,7 +752,9 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
   // the caller's host-side work that must not run beside the upload (mapping output pages: the two contend in the
   // kernel's memory management and the upload took 80 ms longer) but may run beside the kernels
   if (after_upload) after_upload(after_arg);
-  // ---- 1. block starts
+  // ---- 1. block starts.  (Searching the chunks of an uploaded prefix while the next part of the member uploads — four
+  // parts, a stream of its own, low priority — was measured in round 3: upload + search 25 ms instead of 7 + 10; the
+  // upload of pageable memory and a kernel that fills the chip get in each other's way on this system.)
   hipLaunchKernelGGL(inf_search_kernel, dim3(n_chunks - 1), dim3(256), 0, st, d_data, nbytes, chunk_bytes, n_chunks, d_starts);
   SPZ_HIP_TRY(hipGetLastError());
   std::vector<unsigned long long> starts(n_chunks);
