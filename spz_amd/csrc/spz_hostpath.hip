@@ -497,20 +497,21 @@ int encode_host_impl(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int a
     int sh_chunks = 0;
     uint64_t n_tail = 0, n_main = n;  // the last n_tail points' sh go first (see below); the pieces cover [0, n_main)
     if (sh_fpp) {
-      // Pieces of ~480 MiB of floats (120 MB of stream, ~230 table segments: one round of the chip's CUs): a piece's table
-      // kernels take ~2 ms however few segments it has, so the 160 MiB chunks of the plain pipeline (eleven pieces of 78
-      // segments for 10 M points) spent 50 ms of kernel time on tables that take 19 ms over the whole input at once.
-      // The LAST pieces shrink (each half of what is left, down to 48 MiB): what the container stage still has to do
-      // when the upload ends is the last piece's tables and matches, 7 ms for a full piece.
+      // Pieces of ~240 MiB of floats (60 MB of stream, ~110 table segments), the last ones shrinking (each half of what
+      // is left, down to 64 MiB).  A piece's table kernels take ~2 ms however few segments it has (one workgroup walks
+      // its 512 KiB serially), so small pieces cost kernel time — the 160 MiB chunks of the plain pipeline, eleven
+      // pieces of 78 segments for 10 M points, spent 50 ms on tables that take 19 ms over the whole input at once — and
+      // large ones leave the container stage a large last piece to do when the upload ends.  profiles/README.md (round 3)
+      // has the scan: every choice from 96 to 480 MiB is within 4 % now that the match kernel is short.
       static const size_t target = []() {
         const char *e = std::getenv("SPZ_AMD_HOST_SESSION_CHUNK_MIB");
         const long v = e ? std::atol(e) : 0;
-        return (size_t)(v > 0 ? v : 480) << 20;
+        return (size_t)(v > 0 ? v : 240) << 20;
       }();
       static const size_t smallest = []() {
         const char *e = std::getenv("SPZ_AMD_HOST_SESSION_LAST_MIB");
         const long v = e ? std::atol(e) : 0;
-        return (size_t)(v > 0 ? v : 48) << 20;
+        return (size_t)(v > 0 ? v : 64) << 20;
       }();
       const size_t point_bytes = sh_fpp * sizeof(float);
       // a caller that wants the stream's END early (its container stage's serial tail job: the last tail_bytes of the
@@ -575,7 +576,8 @@ int encode_host_impl(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int a
                                                            lay.total_bytes, pipe->up);
       if (erc != SPZ_AMD_OK) return erc;
       if (tail_piece) return SPZ_AMD_OK;  // not a prefix of the stream: the session gets it with its last feed
-      const uint64_t upto = first + count == n ? lay.total_bytes : small_end + (first + count) * sh_bpp;
+      // (the last points' sh, if they went first, are final by now as well: the last piece completes the stream)
+      const uint64_t upto = first + count == n_main ? lay.total_bytes : small_end + (first + count) * sh_bpp;
       return spz_amd_zlib_session_feed(zlib_session, sb, upto, pipe->up);
     };
     auto down2 = [&](int k) -> int {
