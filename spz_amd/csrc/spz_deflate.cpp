@@ -751,7 +751,9 @@ bool finish_member_on_parser(HeadParser &parser, const uint8_t *data, size_t siz
     if (!parser.encodePlanned(st, static_cast<uint32_t>(BLOCK_SYMS), static_cast<uint32_t>(nblocks), desc.data(), deflate_bytes)) {
       return false;
     }
-    // while the device writes headers and symbols: the output buffer, its pages mapped
+    // while the device writes headers and symbols: the output buffer, its pages mapped.  (Mapping a buffer of a guessed
+    // size from the start of the writer, beside the device's parse, takes these 3 - 4 ms away and costs 10: the small
+    // copies of the stages in between wait for the mapping threads in the kernel's memory management.  Round 3.)
     out->clear();
     detail::resizeUninitialized(out, static_cast<size_t>(10 + deflate_bytes + 8));
     {

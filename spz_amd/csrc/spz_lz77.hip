@@ -48,7 +48,7 @@ namespace {
 using namespace spz_lz;
 
 // ---- stage 1: chains -------------------------------------------------------------------------------------
-// One table of 65536 16-bit entries in LDS (128 KiB), one workgroup per 512 KiB of input (+32 KiB warm-up), 512
+// One table of 16-bit entries in LDS (LINK: 32768 of them, 64 KiB; RANK: 65536, 128 KiB), one workgroup per 512 KiB of input (+32 KiB warm-up), 512
 // positions per round: each wave finds the equal keys among its 64 positions with a readlane/ballot loop, then
 // the eight waves take the table in position order.
 //   LINK: key = hash2, entry = low 16 bits of the newest position; out = distance to it (0: none within 32 KiB).
@@ -63,14 +63,15 @@ enum TableMode { TABLE_LINK = 0, TABLE_RANK = 1 };
 template <int MODE>
 __global__ __launch_bounds__(512) void lz_table_kernel(const uint8_t *__restrict__ d, uint64_t n_pos,
                                                        uint16_t *__restrict__ out, uint32_t first_segment) {
-  __shared__ uint16_t table[HASH_MASK + 1];
+  constexpr uint32_t kEntries = MODE == TABLE_LINK ? (1u << HASH2_BITS) : HASH_MASK + 1;  // 64 KiB (two workgroups per CU) / 128 KiB
+  __shared__ uint16_t table[kEntries];
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint32_t segment = blockIdx.x + first_segment;
   const uint64_t s0 = (uint64_t)segment * kLinkSegment;
   const uint64_t s1 = (s0 + kLinkSegment < n_pos) ? s0 + kLinkSegment : n_pos;
   const uint64_t start = s0 >= W ? s0 - W : 0;  // the walks of the first positions reach 32 KiB back
   const uint16_t fresh = MODE == TABLE_LINK ? (uint16_t)((uint32_t)start - kRetiredAge) : (uint16_t)0;
-  for (uint32_t i = tid; i <= HASH_MASK; i += kLinkThreads) table[i] = fresh;
+  for (uint32_t i = tid; i < kEntries; i += kLinkThreads) table[i] = fresh;
   __syncthreads();
   uint16_t *slab = out + (size_t)segment * kRankSlab;  // RANK: entry i is position s0 - W + i
   // The workgroup is alone on its CU (the table takes 128 KiB of LDS), so nothing hides a load's latency for it: the
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(512) void lz_table_kernel(const uint8_t *__restrict
     bytes_next = load3(P + kLinkThreads + tid);
     if (MODE == TABLE_LINK && P != start && ((P - start) & (kSweepEvery - 1)) == 0) {
       // retire what no later position can reach: an entry never gets 65536 positions old
-      for (uint32_t i = tid; i <= HASH_MASK; i += kLinkThreads) {
+      for (uint32_t i = tid; i < kEntries; i += kLinkThreads) {
         const uint16_t age = (uint16_t)((uint32_t)P - table[i]);
         if (age >= W) table[i] = (uint16_t)((uint32_t)P - kRetiredAge);
       }

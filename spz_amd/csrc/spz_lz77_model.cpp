@@ -110,7 +110,7 @@ struct ModelParser final : HeadParser {
     // ---- stage 1: link[] along hash2, rank[] along zlib's hash
     std::vector<uint16_t> link(n_pos, 0), rank(n_pos, 0);
     {
-      std::vector<uint64_t> head(HASH_MASK + 1, ~uint64_t(0));
+      std::vector<uint64_t> head(size_t(1) << HASH2_BITS, ~uint64_t(0));
       std::vector<uint16_t> count(HASH_MASK + 1, 0);
       for (uint64_t p = 0; p < n_pos; ++p) {
         const uint32_t h2 = hash2(data[p], data[p + 1], data[p + 2]);
