@@ -102,7 +102,7 @@ int spz_amd_device_count(void);
 int spz_amd_last_hip_error(void);
 
 /* Frees what the library keeps on the devices between calls (decode tables / thresholds, the cached
- * workspace of the *_host entry points, up to three large blocks of the gzip container stage: ~23 bytes per byte of
+ * workspace of the *_host entry points, up to three large blocks of the gzip container stage: ~25 bytes per byte of
  * the largest stream compressed so far).  Optional: everything is re-created on demand.  Must not
  * run concurrently with other calls into the library. */
 int spz_amd_release_device_memory(void);
@@ -356,7 +356,7 @@ int spz_amd_selftest_device(int mode, uint64_t begin, uint64_t count, uint64_t r
  *      open: uploads, runs the stages (spz_lz77.hip), returns the symbol count and the index of the first symbol
  *      the tail parse contributes; fetch: copies the symbols out (distance, 0 = literal; literal byte or
  *      length - 3); close: frees the device memory.  SPZ_AMD_ERR_UNSUPPORTED = declined (two neighbouring jobs did not
- *      meet even with parse jobs of 1 MiB, or not enough free device memory: ~23 bytes per input byte): the caller parses on
+ *      meet even with parse jobs of 1 MiB, or not enough free device memory: ~25 bytes per input byte): the caller parses on
  *      the host, with the same result.  Blocking; Huffman coding and the gzip framing stay on the host. ---------- */
 int spz_amd_zlib_parse_open(const uint8_t *h_data, uint64_t size, uint64_t tail_begin, const uint32_t *h_tail_rec,
                             uint32_t n_rec, int device, void **ctx, uint64_t *num_symbols,
