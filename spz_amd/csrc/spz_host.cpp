@@ -929,11 +929,15 @@ bool deviceInflateWanted(size_t size, size_t header_len) {
   const char *e = std::getenv("SPZ_AMD_GUNZIP_DEVICE");
   if (e && e[0] == '0') return false;
   const bool forced = e && e[0] == '1';
-  // profiles/r03_size_sweep.json (16 usable CPUs): the parallel host reader wins below a member of ~60 MB (41 MB member:
-  // 46 ms host, 55 ms device; 82 MB: 70 / 58; 163 MB: 181 / 105; 409 MB: 380 / 150) — a wave takes as long for its
-  // chunk whether there are 300 chunks or 5 000 — and scales with cores, which the device reader does not
-  if (size < header_len + 8 + (forced ? (size_t(1) << 20) : (size_t(56) << 20))) return false;
-  if (!forced && detail::effectiveCpuCount() >= 32) return false;
+  if (size < header_len + 8 + (size_t(1) << 20)) return false;
+  if (!forced) {
+    // profiles/r03_load_sweep.txt (16 usable CPUs; file MB: device / host ms): 10: 26 / 15, 20: 32 / 21, 41: 25 / 41,
+    // 82: 37 / 71, 163: 80 / 165, 409: 99 / 353.  The device reader costs ~20 ms whatever the size (a wave takes that
+    // long for one of zlib's blocks) and 0.2 ms per MB; the parallel host reader 13.9 ms per MB and core, if it scales
+    // (it does to 16).  The faster of the two by that account: from ~30 MB with 16 cores, ~85 MB with 32.
+    const double mb = static_cast<double>(size) / 1e6, cores = static_cast<double>(std::max(1u, detail::effectiveCpuCount()));
+    if (20.0 + 0.2 * mb >= 13.9 * mb / cores) return false;
+  }
   return spz_amd_device_count() > 0;
 }
 

@@ -265,8 +265,8 @@ SPZ_INF_HD bool readCodeLengths(const In &in, uint64_t *at, HeaderWork *w, int *
   if (clh.ncodes < 1) return false;
   int n = 0;
   const int total = hlit + hdist;
-  SPZ_INF_NO_UNROLL
-  for (int i = 0; i < 286 + 30; ++i) lens[i] = 0;
+  // (lens[] is not cleared: every entry below hlit + hdist is written before it is read — a repeat code reads the one
+  // before it, the tables are built from exactly that many — and clearing all 316 was a fifth of a header check's work)
   // Kraft sums of the two sets as they come, in units of 2^-15: an over-subscribed set (which build() would refuse
   // in the end anyway) ends the reading at once — random bits that look like a header get there within a few
   // dozen lengths, and the block-start searches spend most of their time on those.
@@ -452,11 +452,13 @@ SPZ_INF_HD Outcome decodeBlocks(const In &in, uint64_t start, uint64_t stop, Sin
 
 // The cheap part of the block-start test at bit position p: BFINAL = 0, BTYPE = 2, code counts in range and a
 // complete code-length code (zlib's always is: Kraft sum over its 3-bit lengths).
+// ... in two parts, for a caller that tests many positions in lockstep (the device's search): the fields of the first 13
+// bits, which one position in nine passes, and the code-length code's Kraft sum, a loop of up to 19 steps.
+SPZ_INF_HD bool dynamicHeaderFieldsInRange(uint64_t v) {  // v: the bits from the block's first on
+  return (v & 7) == 4 && ((v >> 3) & 31) <= 29 && ((v >> 8) & 31) <= 29;
+}
 template <class In>
-SPZ_INF_HD bool plausibleDynamicHeader(const In &in, uint64_t p) {
-  const uint64_t v = in.peek(p);
-  if ((v & 7) != 4) return false;
-  if (((v >> 3) & 31) > 29 || ((v >> 8) & 31) > 29) return false;
+SPZ_INF_HD bool codeLengthCodeComplete(const In &in, uint64_t p, uint64_t v) {  // v = in.peek(p)
   const int hclen = static_cast<int>((v >> 13) & 15) + 4;
   uint64_t c = v >> 17;  // 39+ valid bits = 13 lengths; the rest from a second peek
   unsigned kraft = 0;
@@ -467,6 +469,11 @@ SPZ_INF_HD bool plausibleDynamicHeader(const In &in, uint64_t p) {
     if (l) kraft += 128u >> l;
   }
   return kraft == 128;
+}
+template <class In>
+SPZ_INF_HD bool plausibleDynamicHeader(const In &in, uint64_t p) {
+  const uint64_t v = in.peek(p);
+  return dynamicHeaderFieldsInRange(v) && codeLengthCodeComplete(in, p, v);
 }
 
 // Header and both code-length sets valid — exactly what readDynamic() accepts, without building tables or decoding

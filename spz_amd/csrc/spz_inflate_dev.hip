@@ -39,7 +39,11 @@ namespace {
 
 using namespace spz::pinflate;
 
-constexpr uint32_t kMinChunkBytes = 65536;  // compressed bytes per chunk, at least; more when that lets every chunk's wave be resident at once
+// Compressed bytes per chunk, at least (more when that lets every chunk's wave be resident at once).  About one block
+// of zlib's (38 KB of an .spz stream): smaller chunks find the same block starts and become one job; 64 KiB — until
+// round 3 — left a member of 40 - 200 MB with few, long jobs: a wave takes as long for 64 KiB whether the chip holds
+// 600 of them or 5 000.
+constexpr uint32_t kMinChunkBytes = 32768;
 constexpr uint32_t kDecodeWavesPerCU = 23;  // what the decode kernel's registers and LDS allow
 constexpr uint32_t kSearchBytes = 131072;  // how far past its chunk's first byte a block start is looked for
 constexpr uint32_t kExpand = 8;            // symbols a chunk may produce per compressed byte
@@ -72,8 +76,31 @@ struct RegBits {
   }
 };
 
+// The member's bits for one serial reader (a header check): 128 of them in registers, reloaded when the reader has
+// moved 72 on — a check reads some 300 code lengths one after the other, and a load from global memory per length,
+// each waited for, was three quarters of the search kernel's time.
+struct SlidingBits {
+  const uint8_t *p;
+  uint64_t nbits;
+  size_t nbytes;
+  mutable uint64_t lo = 0, hi = 0, base = ~0ull;  // bits [base, base + 128), base a multiple of 8; ~0: nothing loaded
+  __device__ __forceinline__ uint32_t uniform(uint32_t v) const { return v; }
+  __device__ __forceinline__ uint64_t peek(uint64_t at) const {
+    if (at < base || at - base > 72) {  // (the data is padded: 16 bytes can be read from any byte of it)
+      base = at & ~7ull;
+      __builtin_memcpy(&lo, p + (base >> 3), 8);
+      __builtin_memcpy(&hi, p + (base >> 3) + 8, 8);
+    }
+    const uint32_t s = (uint32_t)(at - base);  // <= 72: 56 valid bits at least
+    if (s == 0) return lo;
+    if (s < 64) return (lo >> s) | (hi << (64u - s));
+    return hi >> (s - 64u);
+  }
+};
+
 __global__ __launch_bounds__(256) void inf_search_kernel(const uint8_t *__restrict__ d, uint64_t nbytes, uint32_t chunk_bytes,
-                                                         uint32_t n_chunks, unsigned long long *__restrict__ starts) {
+                                                         uint32_t n_chunks, unsigned long long *__restrict__ starts,
+                                                         unsigned long long *__restrict__ stats) {
   __shared__ unsigned long long cand[kMaxCand];
   __shared__ uint32_t ncand;
   __shared__ unsigned long long found;
@@ -86,26 +113,44 @@ __global__ __launch_bounds__(256) void inf_search_kernel(const uint8_t *__restri
   if (hi > in.nbits) hi = in.nbits;
   if (tid == 0) found = NONE;
   __syncthreads();
+  long long t_mark = stats ? clock64() : 0, t_stored = 0, t_scan = 0, t_check = 0;
   // Inside a run of stored blocks (an incompressible section) there is no dynamic header to find, but the blocks start
   // at byte boundaries with 00 LEN ~LEN, one after the other: a position whose LEN leads to another such header (or to
   // the final one) is a block start.  Looked for in the chunk's own bytes only; the lowest wins against a dynamic
   // header found below.
   {
     const uint64_t b0 = (uint64_t)chunk_bytes * chunk;
-    for (uint32_t k = tid; k < chunk_bytes; k += 256) {
-      const uint64_t b = b0 + k;
-      if (b + 5 > nbytes || d[b] != 0) continue;
-      const uint32_t len = (uint32_t)d[b + 1] | ((uint32_t)d[b + 2] << 8), nlen = (uint32_t)d[b + 3] | ((uint32_t)d[b + 4] << 8);
-      if ((len ^ nlen) != 0xffffu || len < 1024) continue;   // zlib's stored blocks carry tens of kilobytes
-      const uint64_t b2 = b + 5 + len;
-      if (b2 + 5 > nbytes) continue;
-      const uint32_t h2 = d[b2], len2 = (uint32_t)d[b2 + 1] | ((uint32_t)d[b2 + 2] << 8),
-                     nlen2 = (uint32_t)d[b2 + 3] | ((uint32_t)d[b2 + 4] << 8);
-      const bool stored_next = (h2 == 0 || h2 == 1) && (len2 ^ nlen2) == 0xffffu;
-      const bool dynamic_next = (h2 & 6u) == 4u && plausibleDynamicHeader(in, 8 * b2);
-      if (stored_next || dynamic_next) atomicMin(&found, 8ull * b);
+    // sixteen bytes per lane and load (one byte per lane and load, each waited for, was a quarter of the kernel's time);
+    // only a zero byte is looked at further (chunk_bytes is a multiple of 4096, the data is padded)
+    for (uint32_t k16 = tid * 16u; k16 < chunk_bytes; k16 += 256u * 16u) {
+      uint4 q;
+      __builtin_memcpy(&q, d + b0 + k16, 16);
+      const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+      // a byte of the word is zero: the classic (w - 0x01010101) & ~w & 0x80808080
+      uint32_t zeros = 0;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) zeros |= ((w[j] - 0x01010101u) & ~w[j] & 0x80808080u) ? (1u << j) : 0u;
+      if (zeros == 0u) continue;
+      for (uint32_t k = k16; k < k16 + 16u; ++k) {
+        const uint64_t b = b0 + k;
+        if (b + 5 > nbytes || d[b] != 0) continue;
+        const uint32_t len = (uint32_t)d[b + 1] | ((uint32_t)d[b + 2] << 8), nlen = (uint32_t)d[b + 3] | ((uint32_t)d[b + 4] << 8);
+        if ((len ^ nlen) != 0xffffu || len < 1024) continue;   // zlib's stored blocks carry tens of kilobytes
+        const uint64_t b2 = b + 5 + len;
+        if (b2 + 5 > nbytes) continue;
+        const uint32_t h2 = d[b2], len2 = (uint32_t)d[b2 + 1] | ((uint32_t)d[b2 + 2] << 8),
+                       nlen2 = (uint32_t)d[b2 + 3] | ((uint32_t)d[b2 + 4] << 8);
+        const bool stored_next = (h2 == 0 || h2 == 1) && (len2 ^ nlen2) == 0xffffu;
+        const bool dynamic_next = (h2 & 6u) == 4u && plausibleDynamicHeader(in, 8 * b2);
+        if (stored_next || dynamic_next) atomicMin(&found, 8ull * b);
+      }
     }
     __syncthreads();
+  }
+  if (stats) {
+    const long long t = clock64();
+    t_stored = t - t_mark;
+    t_mark = t;
   }
   const unsigned long long stored_start = found;
   if (stored_start != NONE && stored_start < hi) hi = stored_start;   // a dynamic header counts only below it
@@ -114,17 +159,47 @@ __global__ __launch_bounds__(256) void inf_search_kernel(const uint8_t *__restri
     if (tid == 0) ncand = 0;
     __syncthreads();
     {
-      // 16 bit positions at a time: they start at a byte boundary, and 16 bytes from there cover every test (padded data)
-      for (uint32_t g = 0; g < kSearchPerThread / 16; ++g) {
-        const uint64_t p0 = base + ((uint64_t)tid * (kSearchPerThread / 16) + g) * 16;
-        RegBits rb;
-        __builtin_memcpy(&rb.lo, d + (p0 >> 3), 8);
-        __builtin_memcpy(&rb.hi, d + (p0 >> 3) + 8, 8);
-        rb.base = p0;
-        rb.nbits = in.nbits;
+      // In two passes, because the test's second part is a loop of up to 19 steps that one position in nine gets to: run
+      // position by position, some lane of the wave got there at nearly every position and the other 56 waited (13 % of
+      // the lanes at work, and this scan was the kernel's time).  First every lane marks which of its 64 positions have
+      // the header's fields in range — 16 at a time: they start at a byte boundary, and 16 bytes from there cover the
+      // fields (padded data); then the lanes go through their marked positions together, one each per step.
+      const uint64_t first = base + (uint64_t)tid * kSearchPerThread;
+      constexpr uint32_t kGroups = kSearchPerThread / 16;
+      uint64_t glo[kGroups], ghi[kGroups];  // 128 bits from each group's first position: all requested before the first is used
+#pragma unroll
+      for (uint32_t g = 0; g < kGroups; ++g) {
+        const uint64_t p0 = first + g * 16;
+        __builtin_memcpy(&glo[g], d + (p0 >> 3), 8);
+        __builtin_memcpy(&ghi[g], d + (p0 >> 3) + 8, 8);
+      }
+      uint64_t marked = 0;
+#pragma unroll
+      for (uint32_t g = 0; g < kGroups; ++g) {
+        const uint64_t p0 = first + g * 16;
+        const RegBits rb = {glo[g], ghi[g], p0, in.nbits};
+#pragma unroll
         for (uint32_t k = 0; k < 16; ++k) {
           const uint64_t p = p0 + k;
-          if (p < hi && p + 64 < in.nbits && plausibleDynamicHeader(rb, p)) {
+          if (p < hi && p + 64 < in.nbits && dynamicHeaderFieldsInRange(rb.peek(p))) marked |= 1ull << (g * 16 + k);
+        }
+      }
+      while (__any(marked != 0ull)) {
+        if (marked != 0ull) {
+          const uint32_t bit = (uint32_t)__builtin_ctzll(marked);
+          marked &= marked - 1ull;
+          const uint32_t g = bit >> 4;
+          // the group's 128 bits hold the 74 from any of its positions on (15 + 74 < 128); picked by selects, not by an
+          // index (an indexed register array would go to scratch memory)
+          uint64_t lo = glo[0], hi2 = ghi[0];
+#pragma unroll
+          for (uint32_t j = 1; j < kGroups; ++j) {
+            lo = g == j ? glo[j] : lo;
+            hi2 = g == j ? ghi[j] : hi2;
+          }
+          const RegBits rb = {lo, hi2, first + (uint64_t)g * 16, in.nbits};
+          const uint64_t p = first + bit;
+          if (codeLengthCodeComplete(rb, p, rb.peek(p))) {
             const uint32_t slot = atomicAdd(&ncand, 1u);
             if (slot < kMaxCand) cand[slot] = p;
           }
@@ -132,20 +207,44 @@ __global__ __launch_bounds__(256) void inf_search_kernel(const uint8_t *__restri
       }
     }
     __syncthreads();
+    if (stats) {
+      const long long t = clock64();
+      t_scan += t - t_mark;
+      t_mark = t;
+    }
     // one candidate per thread: header and both code-length sets valid?  The lowest position that is wins.
     const uint32_t n = ncand < kMaxCand ? ncand : kMaxCand;
-    for (uint32_t base = 0; base < n; base += kValidateSlots) {   // kValidateSlots at a time: their arrays are in LDS
-      if (tid < kValidateSlots && base + tid < n && hasValidDynamicHeader(in, cand[base + tid], &s_work[tid])) {
-        atomicMin(&found, cand[base + tid]);
+    if (stats != nullptr && tid == 0) {  // SPZ_AMD_LZ_TIMING: batches of 16384 bit positions, and the candidates in them
+      atomicAdd(&stats[0], 1ull);
+      atomicAdd(&stats[1], (unsigned long long)ncand);
+    }
+    // kValidateSlots at a time (their arrays are in LDS), four to each of the workgroup's waves: a check is a serial
+    // walk over up to 316 code lengths, a wave lasts as long as its slowest lane, and sixteen in ONE wave with the other
+    // three waiting at the barrier was where the kernel's time went (13 % of its lanes at work)
+    const uint32_t slot = (tid & 63u) < kValidateSlots / 4u ? (tid >> 6) * (kValidateSlots / 4u) + (tid & 63u) : kValidateSlots;
+    for (uint32_t base = 0; base < n; base += kValidateSlots) {
+      if (slot < kValidateSlots && base + slot < n) {
+        const SlidingBits sb = {d, in.nbits, in.nbytes};
+        if (hasValidDynamicHeader(sb, cand[base + slot], &s_work[slot])) atomicMin(&found, cand[base + slot]);
       }
     }
     __syncthreads();
+    if (stats) {
+      const long long t = clock64();
+      t_check += t - t_mark;
+      t_mark = t;
+    }
     if (found != NONE) break;
     if (ncand > kMaxCand) {  // too many look-alikes to be sure none was missed: no start for this chunk
       break;
     }
   }
   if (tid == 0) starts[chunk] = found;
+  if (stats != nullptr && tid == 0) {
+    atomicAdd(&stats[2], (unsigned long long)t_stored);
+    atomicAdd(&stats[3], (unsigned long long)t_scan);
+    atomicAdd(&stats[4], (unsigned long long)t_check);
+  }
 }
 
 // ---- decode -----------------------------------------------------------------------------------------------
@@ -673,7 +772,7 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
   if ((h_deflate == nullptr) == (d_deflate == nullptr) || ctx == nullptr || out_bytes == nullptr) return SPZ_AMD_ERR_INVALID_ARG;
   *ctx = nullptr;
   g_last_decline = "";
-  if (nbytes < 4ull * kMinChunkBytes || nbytes >= (1ull << 32)) return decline("size");  // under 256 KiB of deflate data, or 4 GiB and more
+  if (nbytes < 4ull * kMinChunkBytes || nbytes >= (1ull << 32)) return decline("size");  // under 128 KiB of deflate data, or 4 GiB and more
   DeviceGuard guard;
   int rc = guard.enter(device);
   if (rc != SPZ_AMD_OK) return rc;
@@ -699,9 +798,7 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
   SPZ_HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device));
   const uint64_t slots = (uint64_t)(cus > 0 ? cus : 256) * kDecodeWavesPerCU;
   uint32_t chunk_bytes = kMinChunkBytes;
-  if (nbytes / kMinChunkBytes > slots * 95 / 100 && nbytes / kMinChunkBytes <= 2 * slots) {
-    chunk_bytes = (uint32_t)((nbytes / (slots * 95 / 100) + 4095) / 4096 * 4096);
-  }
+  if (nbytes / kMinChunkBytes > slots * 95 / 100) chunk_bytes = (uint32_t)((nbytes / (slots * 95 / 100) + 4095) / 4096 * 4096);
   const uint32_t n_chunks = (uint32_t)(nbytes / chunk_bytes);  // the last one takes the remainder
   // one allocation: the deflate data, block starts, jobs/results/places, symbols, windows; the output and CRCs later
   const size_t sym_capacity = (size_t)nbytes * kExpand + (size_t)n_chunks * 128;
@@ -757,13 +854,22 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
   // ---- 1. block starts.  (Searching the chunks of an uploaded prefix while the next part of the member uploads — four
   // parts, a stream of its own, low priority — was measured in round 3: upload + search 25 ms instead of 7 + 10; the
   // upload of pageable memory and a kernel that fills the chip get in each other's way on this system.)
-  hipLaunchKernelGGL(inf_search_kernel, dim3(n_chunks - 1), dim3(256), 0, st, d_data, nbytes, chunk_bytes, n_chunks, d_starts);
+  unsigned long long *d_search_stats = timing ? reinterpret_cast<unsigned long long *>(d_bad + 16) : nullptr;  // (zeroed above)
+  hipLaunchKernelGGL(inf_search_kernel, dim3(n_chunks - 1), dim3(256), 0, st, d_data, nbytes, chunk_bytes, n_chunks, d_starts, d_search_stats);
   SPZ_HIP_TRY(hipGetLastError());
   std::vector<unsigned long long> starts(n_chunks);
   SPZ_HIP_TRY(hipMemcpyAsync(starts.data(), d_starts, (size_t)n_chunks * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
   SPZ_HIP_TRY(hipStreamSynchronize(st));
   starts[0] = 0;
   lap("search");
+  if (timing) {
+    unsigned long long h[5] = {0, 0, 0, 0, 0};
+    SPZ_HIP_TRY(hipMemcpy(h, d_search_stats, sizeof(h), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "[inflate] search: clock ticks per chunk: stored-block scan %.0f, header scan %.0f, full checks %.0f\n", (double)h[2] / (n_chunks - 1),
+                 (double)h[3] / (n_chunks - 1), (double)h[4] / (n_chunks - 1));
+    std::fprintf(stderr, "[inflate] search: %llu batches of 16384 bit positions for %u chunks, %llu candidates for the full check (%.1f per batch)\n", h[0],
+                 n_chunks - 1, h[1], h[0] ? (double)h[1] / (double)h[0] : 0.0);
+  }
   std::vector<ChunkJob> jobs;
   jobs.reserve(n_chunks);
   for (uint32_t i = 0; i < n_chunks; ++i) {
