@@ -11,7 +11,7 @@
 //
 // The per-Gaussian quantise / dequantise work runs on the GPU through libspz_amd.so.  The gzip container
 // (load-spz.cc:141-214) keeps zlib's bytes and zlib's verdicts, but where it runs depends on the size: streams of
-// 2 MiB and more are deflated, and members of 56 MiB and more inflated, ON THE DEVICE by default (spz_lz77.hip / spz_inflate_dev.hip: zlib
+// 2 MiB and more are deflated, and members from about 30 MB (on 16 cores) inflated, ON THE DEVICE by default (spz_lz77.hip / spz_inflate_dev.hip: zlib
 // 1.2.11's level-6 output reproduced bit for bit, every member's symbols checked against the input on the device;
 // SPZ_AMD_GZIP_DEVICE / SPZ_AMD_GUNZIP_DEVICE = 0 keep the stage on the host), smaller ones and every case the device
 // declines on the host (multi-threaded exact writer / parallel reader from 1 / 4 MiB, zlib itself below and as the last
@@ -251,7 +251,7 @@ uint64_t deviceGzipParseCount();
 // bytes instead, and a "[SPZ ERROR] spz_amd: the device gzip writer ..." line.  Anything but 0 is a defect to report.
 uint64_t deviceGzipRejectCount();
 // Members decompressGzipped has inflated on the device in this process (spz_inflate_dev.hip; SPZ_AMD_GUNZIP_DEVICE = 0
-// never, 1 from 1 MiB, unset: members from 56 MiB on hosts with fewer than 32 usable CPUs); believed only after the CRC-32 and ISIZE of the trailer matched.
+// never, 1 from 1 MiB, unset: by size and usable CPUs, from about 30 MB on 16 cores); believed only after the CRC-32 and ISIZE of the trailer matched.
 uint64_t deviceInflateCount();
 // Why the device reader stood down the last time this thread asked it ("" = it did not, or was not asked): the names
 // spz_amd_inflate_last_decline() documents, or "crc" when it inflated something the trailer does not confirm.
