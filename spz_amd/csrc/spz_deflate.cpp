@@ -1033,8 +1033,13 @@ TailAhead *tailAheadStart(const uint8_t *data, size_t size) {
   a->prepare(data, size);
   try {
     a->thread = std::thread([a]() {
+      const auto t0 = std::chrono::steady_clock::now();
       a->job.run();
       a->ran = true;
+      if (std::getenv("SPZ_AMD_EXACT_GZIP_TIMING")) {
+        std::fprintf(stderr, "[exactgz] tail job, started ahead: %.4f s on its thread\n",
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+      }
     });
   } catch (const std::system_error &) {
     // no thread to be had: the job runs when the writer asks for it

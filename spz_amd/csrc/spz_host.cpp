@@ -522,6 +522,7 @@ struct SaveAhead {
   exactgz::TailAhead *tail = nullptr;
   const uint8_t *stream = nullptr;
   size_t size = 0;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
   ~SaveAhead() {
     if (session) spz_amd_zlib_session_close(session);
     exactgz::tailAheadDrop(tail);
@@ -1184,10 +1185,15 @@ bool packToStreamKeep(const GaussianCloud &g, const PackOptions &o, std::vector<
   auto tail_ready = [](void *p) {
     SaveAhead *a = static_cast<SaveAhead *>(p);
     a->tail = exactgz::tailAheadStart(a->stream, a->size);
+    if (std::getenv("SPZ_AMD_EXACT_GZIP_TIMING")) {
+      std::fprintf(stderr, "[saveSpz] the stream's end is on the host %.4f s into the pack\n",
+                   std::chrono::duration<double>(std::chrono::steady_clock::now() - a->t0).count());
+    }
   };
   if (ahead) {
     ahead->stream = stream->data();
     ahead->size = stream->size();
+    ahead->t0 = std::chrono::steady_clock::now();
   }
   const size_t tail_bytes = zlib_session ? exactgz::tailAheadBytes(stream->size()) : 0;
   const int rc = d_copy ? spz_amd_encode_host_keep_session_tail(&in, static_cast<uint64_t>(g.numPoints), g.shDegree, g.antialiased ? 1 : 0,
