@@ -1030,7 +1030,12 @@ TailAhead *tailAheadStart(const uint8_t *data, size_t size) {
   if (data == nullptr || !sizeInRange(size)) return nullptr;
   TailAhead *a = new (std::nothrow) TailAhead();
   if (a == nullptr) return nullptr;
-  a->prepare(data, size);
+  try {
+    a->prepare(data, size);
+  } catch (const std::bad_alloc &) {  // (called from a C callback: nothing may leave it)
+    delete a;
+    return nullptr;
+  }
   try {
     a->thread = std::thread([a]() {
       const auto t0 = std::chrono::steady_clock::now();

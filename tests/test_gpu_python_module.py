@@ -487,3 +487,34 @@ def test_whole_file_of_a_large_cloud_equals_the_reference_file(spz, reference):
     assert back.num_points == n and back.antialiased is True
     for k in FIELDS:
         assert_bits_equal(getattr(back, k), ref[k], k)
+
+
+def test_file_name_overloads_of_a_file_above_16_mib(spz, tmp_path):
+    """saveSpz(cloud, options, path) / loadSpz(path) of a 700 k-point SH3 cloud (a 28 MB file: above the size from which
+    the file is read in pieces by several threads into a buffer that was never zero-filled, load-spz.cc:652-668 being one
+    ifstream): the file is the vector overload's bytes, loading it by name gives what loading those bytes gives, and
+    a directory as the target fails as the reference's ofstream does."""
+    from spz_amd.synth import make_cloud_numpy
+    n, deg = 700_000, 3
+    c = make_cloud_numpy(n, deg, 78)
+    g = spz.GaussianCloud()
+    g.sh_degree = deg
+    for k in FIELDS:
+        setattr(g, k, c[k])
+    o = spz.PackOptions()
+    o.from_coord = spz.RUB
+    want = spz._save_spz_bytes(g, o)
+    assert len(want) > (16 << 20)
+    path = str(tmp_path / "big.spz")
+    with open(path, "wb") as f:
+        f.write(b"x" * (len(want) + 12345))   # an older, longer file at that name: truncated, not overwritten in place
+    assert spz.save_spz(g, o, path) is True
+    with open(path, "rb") as f:
+        assert f.read() == want
+    u = spz.UnpackOptions()
+    u.to_coord = spz.RDF
+    a, b = spz.load_spz(path, u), spz._load_spz_bytes(want, u)
+    assert a.num_points == n
+    for k in FIELDS:
+        assert_bits_equal(getattr(a, k), getattr(b, k), k)
+    assert spz.save_spz(g, o, str(tmp_path)) is False
