@@ -142,48 +142,9 @@ bool peekHeaderLogged(const uint8_t *stream, size_t size, spz_amd_header *hdr) {
 // pages then uploads at a tenth of the link's rate: the buffer is sized without being written, mapped with huge pages by
 // several threads, and filled in 8 MiB pieces by several threads with pread: 409 MB 0.247 -> 0.133 s for the whole
 // loadSpz(name).  Anything that is not a regular file of 16 MiB or more takes the reference's stream route.
-constexpr size_t kParallelIoMin = size_t(16) << 20, kIoPiece = size_t(8) << 20;
-unsigned fileIoThreads() {  // SPZ_AMD_FILE_IO_THREADS: 0 = the reference's stream route always; default 8 (at most the usable CPUs)
-  static const unsigned n = []() {
-    const char *e = std::getenv("SPZ_AMD_FILE_IO_THREADS");
-    const long v = e ? std::atol(e) : 8;
-    return static_cast<unsigned>(std::max(0l, std::min(v, static_cast<long>(std::max(1u, detail::effectiveCpuCount())))));
-  }();
-  return n;
-}
-
-bool parallelRead(int fd, uint8_t *buf, size_t size) {
-  const size_t pieces = (size + kIoPiece - 1) / kIoPiece;
-  const unsigned threads = static_cast<unsigned>(std::min<size_t>(std::max(1u, fileIoThreads()), pieces));
-  std::atomic<size_t> next{0};
-  std::atomic<bool> ok{true};
-  auto work = [&]() {
-    for (;;) {
-      const size_t i = next.fetch_add(1);
-      if (i >= pieces || !ok.load()) return;
-      size_t off = i * kIoPiece;
-      const size_t end = std::min(size, off + kIoPiece);
-      while (off < end) {
-        const ssize_t n = ::pread(fd, buf + off, end - off, static_cast<off_t>(off));
-        if (n < 0 && errno == EINTR) continue;
-        if (n <= 0) {  // an error, or a file that has become shorter
-          ok.store(false);
-          return;
-        }
-        off += static_cast<size_t>(n);
-      }
-    }
-  };
-  std::vector<std::thread> pool;
-  try {
-    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work);
-  } catch (const std::system_error &) {
-    // fewer threads than asked for: this one does what they would have
-  }
-  work();
-  for (auto &t : pool) t.join();
-  return ok.load();
-}
+using detail::fileIoThreads;
+using detail::kParallelIoMin;
+using detail::parallelRead;
 
 bool readFileStream(const std::string &filename, std::vector<uint8_t> *data, bool log) {
   std::ifstream in(filename, std::ios::binary | std::ios::ate);

@@ -7,12 +7,15 @@
 // Prefault maps the fresh pages from several threads while the first transfer is under way.
 #pragma once
 
+#include <fcntl.h>
 #include <sched.h>
 #include <sys/mman.h>
+#include <sys/stat.h>
 #include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
+#include <cerrno>
 #include <cstddef>
 #include <cstdint>
 #include <cstdio>
@@ -189,6 +192,53 @@ class Prefault {
   std::vector<std::thread> pool_;
   std::atomic<size_t> next_{0};
 };
+
+// SPZ_AMD_FILE_IO_THREADS: threads that read a large file (0 = the reference's single stream read always; default 8, at
+// most the usable CPUs).
+inline unsigned fileIoThreads() {
+  static const unsigned n = []() {
+    const char *e = std::getenv("SPZ_AMD_FILE_IO_THREADS");
+    const long v = e ? std::atol(e) : 8;
+    return static_cast<unsigned>(std::max(0l, std::min(v, static_cast<long>(std::max(1u, effectiveCpuCount())))));
+  }();
+  return n;
+}
+constexpr size_t kParallelIoMin = size_t(16) << 20, kIoPiece = size_t(8) << 20;
+
+// `size` bytes of the file from `file_offset` on into buf, in 8 MiB pieces by several threads (pread).  false: a read
+// failed or the file is shorter.
+inline bool parallelRead(int fd, uint8_t *buf, size_t size, size_t file_offset = 0) {
+  const size_t pieces = (size + kIoPiece - 1) / kIoPiece;
+  const unsigned threads = static_cast<unsigned>(std::min<size_t>(std::max(1u, fileIoThreads()), pieces));
+  std::atomic<size_t> next{0};
+  std::atomic<bool> ok{true};
+  auto work = [&]() {
+    for (;;) {
+      const size_t i = next.fetch_add(1);
+      if (i >= pieces || !ok.load()) return;
+      size_t off = i * kIoPiece;
+      const size_t end = std::min(size, off + kIoPiece);
+      while (off < end) {
+        const ssize_t n = ::pread(fd, buf + off, end - off, static_cast<off_t>(file_offset + off));
+        if (n < 0 && errno == EINTR) continue;
+        if (n <= 0) {  // an error, or a file that is (or has become) shorter
+          ok.store(false);
+          return;
+        }
+        off += static_cast<size_t>(n);
+      }
+    }
+  };
+  std::vector<std::thread> pool;
+  try {
+    for (unsigned t = 1; t < threads; ++t) pool.emplace_back(work);
+  } catch (const std::system_error &) {
+    // fewer threads than asked for: this one does what they would have
+  }
+  work();
+  for (auto &t : pool) t.join();
+  return ok.load();
+}
 
 }  // namespace detail
 }  // namespace spz

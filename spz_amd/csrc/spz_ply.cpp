@@ -18,6 +18,7 @@
 
 #include "spz_amd.h"
 #include "spz_amd_host.hpp"
+#include "spz_host_util.hpp"
 
 namespace spz {
 namespace {
@@ -136,11 +137,42 @@ GaussianCloud loadSplatFromPly(const std::string &filename, const UnpackOptions 
   }
   const int shDim = static_cast<int>(cRest.size() / 3);
 
-  std::vector<float> rows(static_cast<size_t>(numPoints) * stride);
-  in.read(reinterpret_cast<char *>(rows.data()), static_cast<std::streamsize>(rows.size() * sizeof(float)));
-  if (!in.good()) {
-    plyLog("[SPZ ERROR] Unable to load data from: %s", filename.c_str());
-    return {};
+  // The vertex rows (load-spz.cc:803-812: one read into a resized vector).  Large files — 2.5 GB for 10 M SH3 points,
+  // whose zero fill and single read() took 1.4 s where the device needs 0.1 — go into a buffer that is sized without
+  // being written and mapped with huge pages, by pread from several threads.
+  std::vector<float> rows;
+  const size_t row_bytes = static_cast<size_t>(numPoints) * stride * sizeof(float);
+  const std::streamoff data_at = in.tellg();
+  bool have_rows = false;
+  if (row_bytes >= detail::kParallelIoMin && detail::fileIoThreads() > 0 && data_at > 0) {
+    const int fd = ::open(filename.c_str(), O_RDONLY | O_CLOEXEC);
+    struct stat st;
+    if (fd >= 0 && ::fstat(fd, &st) == 0 && S_ISREG(st.st_mode)) {
+      detail::resizeUninitialized(&rows, row_bytes / sizeof(float));
+      {
+        detail::Prefault pf;
+        pf.add(rows.data(), row_bytes);
+        pf.start();
+        pf.join();
+      }
+      const bool ok = detail::parallelRead(fd, reinterpret_cast<uint8_t *>(rows.data()), row_bytes, static_cast<size_t>(data_at));
+      ::close(fd);
+      if (!ok) {
+        plyLog("[SPZ ERROR] Unable to load data from: %s", filename.c_str());
+        return {};
+      }
+      have_rows = true;
+    } else if (fd >= 0) {
+      ::close(fd);
+    }
+  }
+  if (!have_rows) {
+    rows.resize(static_cast<size_t>(numPoints) * stride);
+    in.read(reinterpret_cast<char *>(rows.data()), static_cast<std::streamsize>(rows.size() * sizeof(float)));
+    if (!in.good()) {
+      plyLog("[SPZ ERROR] Unable to load data from: %s", filename.c_str());
+      return {};
+    }
   }
 
   if (stride > 255) {
@@ -163,12 +195,17 @@ GaussianCloud loadSplatFromPly(const std::string &filename, const UnpackOptions 
   g.numPoints = numPoints;
   g.shDegree = degreeForDim(shDim);
   const size_t n = static_cast<size_t>(numPoints);
-  g.positions.resize(n * 3);
-  g.scales.resize(n * 3);
-  g.rotations.resize(n * 4);
-  g.alphas.resize(n);
-  g.colors.resize(n * 3);
-  g.sh.resize(n * static_cast<size_t>(shDim) * 3);
+  {  // every element is written by the device copy: no zero fill, pages mapped by several threads
+    std::vector<float> *arrays[6] = {&g.positions, &g.scales, &g.rotations, &g.alphas, &g.colors, &g.sh};
+    const size_t counts[6] = {n * 3, n * 3, n * 4, n, n * 3, n * static_cast<size_t>(shDim) * 3};
+    detail::Prefault pf;
+    for (int i = 0; i < 6; ++i) {
+      detail::resizeUninitialized(arrays[i], counts[i]);
+      pf.add(arrays[i]->data(), counts[i] * sizeof(float));
+    }
+    pf.start();
+    pf.join();
+  }
   spz_amd_cloud_out out = {g.positions.data(), g.scales.data(), g.rotations.data(),
                            g.alphas.data(),    g.colors.data(), g.sh.empty() ? nullptr : g.sh.data()};
   // rows -> cloud with convertCoordinates(RDF, o.to) fused (load-spz.cc:814-842)
@@ -202,7 +239,16 @@ bool saveSplatToPly(const GaussianCloud &data, const PackOptions &o, const std::
     plyLog("[SPZ ERROR] spz_amd: saveSplatToPly: %d sh coefficients per channel (max 15)", shDim);
     return false;
   }
-  std::vector<float> rows(n * D, 0.0f);
+  // every field of every row, the three normals' zeros included, is written by the device copy: no zero fill of what is
+  // 2.5 GB for 10 M SH3 points, its pages mapped by several threads
+  std::vector<float> rows;
+  detail::resizeUninitialized(&rows, n * D);
+  {
+    detail::Prefault pf;
+    pf.add(rows.data(), rows.size() * sizeof(float));
+    pf.start();
+    pf.join();
+  }
   if (n) {
     spz_amd_cloud_in in = {data.positions.data(), data.scales.data(), data.rotations.data(),
                            data.alphas.data(),    data.colors.data(), data.sh.empty() ? nullptr : data.sh.data()};

@@ -197,3 +197,39 @@ def test_gpu_python_module_files_equal_reference_files(cuda, tmp_path):
         open(bad, "wb").write(blob)
         assert spz.load_splat_from_ply(bad, spz.UnpackOptions()).num_points == 0
     assert spz.load_splat_from_ply(str(tmp_path / "missing.ply"), spz.UnpackOptions()).num_points == 0
+
+
+@pytest.mark.gpu
+def test_gpu_large_ply_files_round_trip(cuda, oracle, tmp_path):
+    """A 400 k-point SH3 cloud as a .ply (99 MB: above the size from which loadSplatFromPly reads the vertex rows by
+    several threads into an unwritten buffer, and saveSplatToPly no longer zero-fills its rows): the file is header + the
+    oracle's rows (load-spz.cc:856-893), loading it gives the oracle's arrays for the rows (:814-842) for two target
+    systems, and a file cut short is the reference's error (an empty cloud), not a crash."""
+    import spz_amd.spz as spz
+    from spz_amd.synth import make_cloud_numpy
+    n, deg, shd = 400_000, 3, 15
+    c = make_cloud_numpy(n, deg, 5)
+    g = spz.GaussianCloud()
+    g.sh_degree = deg
+    for k in FIELDS:
+        setattr(g, k, c[k])
+    o = spz.PackOptions()
+    o.from_coord = spz.RUB
+    f = str(tmp_path / "big.ply")
+    assert spz.save_splat_to_ply(g, o, f) is True
+    blob = open(f, "rb").read()
+    props, rows, count = split_ply(np.frombuffer(blob, np.uint8))
+    assert count == n and rows.size == n * (17 + 3 * shd)
+    want_rows = oracle.cloud_to_ply_rows(c, n, shd, int(spz.RUB))
+    assert_bits_equal(rows, want_rows, "rows")
+    cols = columns_from(props)
+    for to in (int(spz.RDF), int(spz.LUF)):
+        u = spz.UnpackOptions()
+        u.to_coord = spz.CoordinateSystem(to)
+        d = spz.load_splat_from_ply(f, u)
+        assert d.num_points == n and d.sh_degree == deg
+        want = oracle.ply_rows_to_cloud(want_rows, n, cols, to)
+        for k in FIELDS:
+            assert_bits_equal(getattr(d, k), want[k], f"to={to} {k}")
+    open(f, "wb").write(blob[:len(blob) - 4096])
+    assert spz.load_splat_from_ply(f, spz.UnpackOptions()).num_points == 0
