@@ -995,6 +995,7 @@ struct TailAhead {
   Job job;
   std::thread thread;
   uint64_t size = 0;
+  std::chrono::steady_clock::time_point asked = std::chrono::steady_clock::now();
   void prepare(const uint8_t *data, uint64_t size_) {
     size = size_;
     const uint64_t tail_begin = (size - 2 * W) / W * W;
@@ -1042,8 +1043,9 @@ TailAhead *tailAheadStart(const uint8_t *data, size_t size) {
       a->job.run();
       a->ran = true;
       if (std::getenv("SPZ_AMD_EXACT_GZIP_TIMING")) {
-        std::fprintf(stderr, "[exactgz] tail job, started ahead: %.4f s on its thread\n",
-                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        std::fprintf(stderr, "[exactgz] tail job, started ahead: %.4f s on its thread, which began %.4f s after it was asked for\n",
+                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(),
+                     std::chrono::duration<double>(t0 - a->asked).count());
       }
     });
   } catch (const std::system_error &) {

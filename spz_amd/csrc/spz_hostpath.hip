@@ -514,6 +514,9 @@ int encode_host_impl(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int a
         return (size_t)(v > 0 ? v : 64) << 20;
       }();
       const size_t point_bytes = sh_fpp * sizeof(float);
+      // (a small cloud — under 1 GiB of floats, 20 ms of upload — is not cut finer than that: every feed is a round of
+      // table kernels of ~2 ms however little it covers, and they follow one another)
+      const bool small_cloud = n * (14 + sh_fpp) * sizeof(float) < (size_t(1) << 30);
       // a caller that wants the stream's END early (its container stage's serial tail job: the last tail_bytes of the
       // stream) gets the last points' sh as the first sh piece
       if (tail_ready != nullptr && tail_bytes > 0) {
@@ -525,7 +528,7 @@ int encode_host_impl(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int a
       while (at < n_main && (int)sh_first.size() < kPipeChunksMax - 5) {
         sh_first.push_back(at);
         const unsigned long long left = (n_main - at) * (unsigned long long)point_bytes;
-        unsigned long long want = std::min<unsigned long long>(target, std::max<unsigned long long>(smallest, left / 2));
+        unsigned long long want = small_cloud ? target : std::min<unsigned long long>(target, std::max<unsigned long long>(smallest, left / 2));
         uint64_t count = (want / point_bytes + 1023ull) & ~1023ull;
         if (count >= n_main - at || (n_main - at - count) * (unsigned long long)point_bytes < smallest / 2) count = n_main - at;  // no sliver at the end
         at += count;
@@ -537,16 +540,20 @@ int encode_host_impl(const spz_amd_cloud_in *h, uint64_t n, int sh_degree, int a
     // The five small sections go up in three steps in the stream's order — positions; alphas, colours and scales;
     // rotations — so that the container stage starts after 120 MB of floats (2 ms) and not after all 560 MB (10 ms:
     // a fifth of the whole upload, during which the GPU had nothing to do and which it then lacked at the end).
-    constexpr int kSmallSteps = 3;
     struct SmallStep {
-      int n_arrays, arrays[3];  // spz_amd_cloud_in order: positions 0, scales 1, rotations 2, alphas 3, colors 4
+      int n_arrays, arrays[5];  // spz_amd_cloud_in order: positions 0, scales 1, rotations 2, alphas 3, colors 4
       unsigned mask;
       int next_section;         // the stream is final up to this section's offset afterwards
     };
-    static const SmallStep small_steps[kSmallSteps] = {
-        {1, {0, 0, 0}, 1u << SPZ_AMD_SEC_POSITIONS, SPZ_AMD_SEC_ALPHAS},
-        {3, {3, 4, 1}, (1u << SPZ_AMD_SEC_ALPHAS) | (1u << SPZ_AMD_SEC_COLORS) | (1u << SPZ_AMD_SEC_SCALES), SPZ_AMD_SEC_ROTATIONS},
-        {1, {2, 0, 0}, 1u << SPZ_AMD_SEC_ROTATIONS, SPZ_AMD_SEC_SH}};
+    static const SmallStep three_steps[3] = {
+        {1, {0, 0, 0, 0, 0}, 1u << SPZ_AMD_SEC_POSITIONS, SPZ_AMD_SEC_ALPHAS},
+        {3, {3, 4, 1, 0, 0}, (1u << SPZ_AMD_SEC_ALPHAS) | (1u << SPZ_AMD_SEC_COLORS) | (1u << SPZ_AMD_SEC_SCALES), SPZ_AMD_SEC_ROTATIONS},
+        {1, {2, 0, 0, 0, 0}, 1u << SPZ_AMD_SEC_ROTATIONS, SPZ_AMD_SEC_SH}};
+    static const SmallStep one_step[1] = {{5, {0, 1, 2, 3, 4}, 0x1fu, SPZ_AMD_SEC_SH}};
+    // (for a cloud whose whole upload is a few milliseconds, one step: see the sh pieces above)
+    const bool few_steps = n * (14 + sh_fpp) * sizeof(float) < (size_t(1) << 30);
+    const SmallStep *const small_steps = few_steps ? one_step : three_steps;
+    const int kSmallSteps = few_steps ? 1 : 3;
     const int tail_steps = n_tail ? 1 : 0, first_sh_step = kSmallSteps + tail_steps;
     if (first_sh_step + sh_chunks > pipe->n_events) return SPZ_AMD_ERR_INVALID_ARG;
     const uint64_t small_end = lay.offset[SPZ_AMD_SEC_SH];

@@ -34,6 +34,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -979,7 +980,7 @@ struct LzSession {
   hipStream_t stream = nullptr;    // copies and LINK tables (null: the default stream)
   hipStream_t rank_stream = nullptr, match_stream = nullptr;
   hipEvent_t producer_done = nullptr, copy_done = nullptr, link_done = nullptr, rank_done = nullptr;
-  bool own_stream = false;
+  bool own_stream = false, streams_from_cache = false;
   uint64_t fed = 0;                // input bytes copied into the block
   uint32_t seg_done = 0, tile_done = 0;
   bool zeroed = false;
@@ -993,20 +994,67 @@ struct LzSession {
 
 static uint64_t lz_tail_begin(uint64_t size) { return (size - 2ull * W) / W * W; }  // spz_deflate.cpp: compressWithHeadParser
 
+// A fed session's three streams and four events, kept per device between sessions: creating and destroying them per
+// saveSpz (a stream is a hardware queue) was 7 - 10 ms of every call — more than a cloud under 4 M points gains from
+// starting its container stage beside the upload.  One set per device; a second session at the same time on the same
+// device makes (and destroys) its own.
+namespace {
+struct LzStreamSet {
+  hipStream_t stream = nullptr, rank_stream = nullptr, match_stream = nullptr;
+  hipEvent_t producer_done = nullptr, copy_done = nullptr, link_done = nullptr, rank_done = nullptr;
+  bool made() const { return stream && rank_stream && match_stream && producer_done && copy_done && link_done && rank_done; }
+  void destroy() {
+    for (hipStream_t st : {stream, rank_stream, match_stream}) {
+      if (st) {
+        (void)hipStreamSynchronize(st);
+        (void)hipStreamDestroy(st);
+      }
+    }
+    for (hipEvent_t e : {producer_done, copy_done, link_done, rank_done}) {
+      if (e) (void)hipEventDestroy(e);
+    }
+    *this = LzStreamSet();
+  }
+  bool make() {  // the current device's
+    if (create_stream(&stream, -1) != hipSuccess || create_stream(&rank_stream, -1) != hipSuccess ||
+        create_stream(&match_stream, -1) != hipSuccess || hipEventCreateWithFlags(&producer_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&copy_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&link_done, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&rank_done, hipEventDisableTiming) != hipSuccess) {
+      destroy();
+      return false;
+    }
+    return true;
+  }
+};
+std::mutex g_lz_streams_mutex;
+LzStreamSet g_lz_streams[kMaxDevices];
+bool g_lz_streams_in_use[kMaxDevices] = {};
+}  // namespace
+
 static void lz_session_destroy(LzSession *q) {
   if (q == nullptr) return;
   DeviceGuard guard;
   if (guard.enter(q->device) == SPZ_AMD_OK) {
     if (q->own_stream) {
+      LzStreamSet set;
+      set.stream = q->stream;
+      set.rank_stream = q->rank_stream;
+      set.match_stream = q->match_stream;
+      set.producer_done = q->producer_done;
+      set.copy_done = q->copy_done;
+      set.link_done = q->link_done;
+      set.rank_done = q->rank_done;
       for (hipStream_t st : {q->stream, q->rank_stream, q->match_stream}) {
-        if (st) {
-          (void)hipStreamSynchronize(st);
-          (void)hipStreamDestroy(st);
-        }
+        if (st) (void)hipStreamSynchronize(st);  // nothing of this session may still be queued when its block goes
       }
-    }
-    for (hipEvent_t e : {q->producer_done, q->copy_done, q->link_done, q->rank_done}) {
-      if (e) (void)hipEventDestroy(e);
+      bool kept = false;
+      if (q->streams_from_cache) {
+        std::lock_guard<std::mutex> lock(g_lz_streams_mutex);
+        g_lz_streams_in_use[q->device] = false;
+        kept = true;
+      }
+      if (!kept) set.destroy();
     }
     if (q->block) scratch_release(q->device, q->block);
   }
@@ -1059,14 +1107,28 @@ static int lz_session_create(uint64_t size, uint64_t tail_begin, int device, boo
   if (rc == SPZ_AMD_OK && total + (size_t(256) << 20) > free_b) rc = SPZ_AMD_ERR_UNSUPPORTED;  // the caller parses on the host
   if (rc == SPZ_AMD_OK) rc = scratch_acquire(device, total, reinterpret_cast<void **>(&q->block));
   if (rc == SPZ_AMD_OK && own_stream) {
-    if (create_stream(&q->stream, -1) != hipSuccess || create_stream(&q->rank_stream, -1) != hipSuccess ||
-        create_stream(&q->match_stream, -1) != hipSuccess ||
-        hipEventCreateWithFlags(&q->producer_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&q->copy_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&q->link_done, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&q->rank_done, hipEventDisableTiming) != hipSuccess) {
-      rc = SPZ_AMD_ERR_HIP;
+    LzStreamSet set;
+    bool have = false;
+    if (device >= 0 && device < kMaxDevices) {
+      std::lock_guard<std::mutex> lock(g_lz_streams_mutex);
+      if (!g_lz_streams_in_use[device]) {
+        if (!g_lz_streams[device].made()) (void)g_lz_streams[device].make();
+        if (g_lz_streams[device].made()) {
+          set = g_lz_streams[device];
+          g_lz_streams_in_use[device] = true;
+          q->streams_from_cache = true;
+          have = true;
+        }
+      }
     }
+    if (!have && !set.make()) rc = SPZ_AMD_ERR_HIP;
+    q->stream = set.stream;
+    q->rank_stream = set.rank_stream;
+    q->match_stream = set.match_stream;
+    q->producer_done = set.producer_done;
+    q->copy_done = set.copy_done;
+    q->link_done = set.link_done;
+    q->rank_done = set.rank_done;
     q->own_stream = true;
   }
   if (rc != SPZ_AMD_OK) {
