@@ -197,8 +197,10 @@ void scratch_release(int device, void *block) {
 }
 
 void kept_stream_free_idle();
+void lz_streams_free_idle();  // spz_lz77.hip: the container stage's per-device streams
 void workspace_free_all() {
   kept_stream_free_idle();
+  lz_streams_free_idle();
   int prev = 0;
   if (hipGetDevice(&prev) != hipSuccess) return;
   for (int d = 0; d < kMaxDevices; ++d) {

@@ -1032,6 +1032,20 @@ LzStreamSet g_lz_streams[kMaxDevices];
 bool g_lz_streams_in_use[kMaxDevices] = {};
 }  // namespace
 
+extern "C++" {
+namespace spz_amd_detail {
+void lz_streams_free_idle() {  // spz_amd_release_device_memory(): the sets no session holds go
+  int prev = 0;
+  if (hipGetDevice(&prev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lock(g_lz_streams_mutex);
+  for (int d = 0; d < kMaxDevices; ++d) {
+    if (!g_lz_streams_in_use[d] && g_lz_streams[d].stream != nullptr && hipSetDevice(d) == hipSuccess) g_lz_streams[d].destroy();
+  }
+  (void)hipSetDevice(prev);
+}
+}  // namespace spz_amd_detail
+}  // extern "C++"
+
 static void lz_session_destroy(LzSession *q) {
   if (q == nullptr) return;
   DeviceGuard guard;
