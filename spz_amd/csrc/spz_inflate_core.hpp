@@ -217,6 +217,7 @@ struct HeaderWork {
   uint8_t lens[286 + 30];
   uint8_t cl[19];
   uint16_t count[16];
+  uint32_t walked;  // code-length symbols the last header check decoded (statistics of the device's search)
 };
 
 // Same acceptance rule as HuffT::build(): not over-subscribed, and complete unless it has at most one code.
@@ -479,13 +480,81 @@ SPZ_INF_HD bool plausibleDynamicHeader(const In &in, uint64_t p) {
 // Header and both code-length sets valid — exactly what readDynamic() accepts, without building tables or decoding
 // the block: what the device's search takes; the chunk before it has to end exactly there, which is the rest of
 // the proof.
+// The same verdict as readCodeLengths() + completeCode() on both sets + "two literal / length codes at least", without
+// storing a single code length: a check only needs the two Kraft sums (units of 2^-15: lengths are at most 15), the
+// numbers of codes, the last length (what a repeat code repeats) and whether the end-of-block symbol has a code.  The
+// block-start searches spend most of their time here — a position that passes the cheap test is usually walked to its
+// last code length, random bits decoding mostly to zero runs that never over-subscribe — and the 316 byte stores and
+// two counting passes per candidate were most of that.
 template <class In>
 SPZ_INF_HD bool hasValidDynamicHeader(const In &in, uint64_t p, HeaderWork *w) {
   if (p + 64 >= in.nbits || !plausibleDynamicHeader(in, p)) return false;
+  uint8_t *cl = w->cl;
+  HuffT<7, 19> &clh = w->clh;
   uint64_t pos = p + 3;
-  int hlit = 0, hdist = 0, nl = 0, nd = 0;
-  if (!readCodeLengths(in, &pos, w, &hlit, &hdist)) return false;
-  return completeCode(w->lens, hlit, &nl, w->count) && completeCode(w->lens + hlit, hdist, &nd, w->count) && nl >= 2;
+  if (pos + 14 > in.nbits) return false;
+  uint64_t v = in.peek(pos);
+  const int hlit = static_cast<int>(v & 31) + 257, hdist = static_cast<int>((v >> 5) & 31) + 1,
+            hclen = static_cast<int>((v >> 10) & 15) + 4;
+  if (hlit > 286 || hdist > 30) return false;
+  pos += 14;
+  SPZ_INF_NO_UNROLL
+  for (int i = 0; i < 19; ++i) cl[i] = 0;
+  if (pos + 3 * static_cast<uint64_t>(hclen) > in.nbits) return false;
+  v = in.peek(pos);
+  SPZ_INF_NO_UNROLL
+  for (int i = 0; i < hclen; ++i) {
+    if (i == 16) v = in.peek(pos + 48);
+    cl[clOrder(i)] = static_cast<uint8_t>((v >> (3 * (i & 15))) & 7);
+  }
+  pos += 3 * static_cast<uint64_t>(hclen);
+  if (!clh.build(cl, 19)) return false;
+  if (clh.ncodes < 1) return false;
+  const int total = hlit + hdist;
+  int n = 0, prev = 0, codes_lit = 0, codes_dist = 0;
+  uint32_t kraft_lit = 0, kraft_dist = 0;
+  bool eob_has_code = false;
+  w->walked = 0;
+  // One code length symbol per step, written as selects: the device's search runs sixteen of these walks side by side in
+  // lockstep lanes, and with a branch per kind of symbol the lanes took turns (measured: the checks' time was that of
+  // all their symbols one after the other).  The code-length code is complete (the cheap test's Kraft sum) and at most
+  // 7 bits long, so every pattern is in its direct table: an empty entry cannot happen for a header that passes, and is
+  // the end of the walk if it does.
+  bool bad = false;
+  while (n < total && !bad) {
+    ++w->walked;
+    bad |= pos >= in.nbits;
+    v = in.peek(pos);
+    const uint32_t e = clh.fast[v & 127u];
+    bad |= e == 0u;
+    const int len = static_cast<int>(e & 15u), sym = static_cast<int>(e >> 4);
+    v >>= len;
+    const bool is16 = sym == 16, is17 = sym == 17, is18 = sym == 18;
+    const int extra_bits = is16 ? 2 : (is17 ? 3 : (is18 ? 7 : 0));
+    const int extra = static_cast<int>(v & ((1u << extra_bits) - 1u));
+    const int rep = sym < 16 ? 1 : (is18 ? 11 : 3) + extra;
+    const int val = sym < 16 ? sym : (is16 ? prev : 0);
+    bad |= is16 & (n == 0);
+    pos += static_cast<uint64_t>(len + extra_bits);
+    bad |= n + rep > total;
+    // entries [n, n + rep): those below hlit are literal / length codes, the rest distance codes
+    const int below = hlit - n;
+    const int in_lit = below <= 0 ? 0 : (rep < below ? rep : below);
+    const uint32_t unit = val != 0 ? 32768u >> val : 0u;
+    kraft_lit += unit * static_cast<uint32_t>(in_lit);
+    kraft_dist += unit * static_cast<uint32_t>(rep - in_lit);
+    bad |= (kraft_lit > 32768u) | (kraft_dist > 32768u);  // over-subscribed
+    codes_lit += val != 0 ? in_lit : 0;
+    codes_dist += val != 0 ? rep - in_lit : 0;
+    eob_has_code |= (val != 0) & (n <= 256) & (256 < n + rep);
+    prev = val;
+    n += rep;
+  }
+  if (bad) return false;
+  if (pos > in.nbits || !eob_has_code) return false;
+  // complete, unless it has at most one code (HuffT::build()'s rule); two literal / length codes at least
+  const bool lit_ok = kraft_lit == 32768u || codes_lit <= 1, dist_ok = kraft_dist == 32768u || codes_dist <= 1;
+  return lit_ok && dist_ok && codes_lit >= 2;
 }
 
 // The full test: a non-final dynamic block starts at p, decodes to its end-of-block and is followed by a

@@ -49,7 +49,8 @@ constexpr uint32_t kSearchBytes = 131072;  // how far past its chunk's first byt
 constexpr uint32_t kExpand = 8;            // symbols a chunk may produce per compressed byte
 constexpr uint32_t kCrcPiece = 262144;
 constexpr uint32_t kMaxCand = 192;
-constexpr uint32_t kSearchPerThread = 64;  // bit positions a thread tests per round
+constexpr uint32_t kSearchPerThread = 64;  // bit positions a thread tests per sub-batch
+constexpr uint32_t kSearchSubBatches = 4;  // sub-batches (of 256 x 64 positions) whose candidates are checked together
 constexpr uint32_t kValidateSlots = 16;    // candidates whose code lengths are read at the same time (1.3 KiB of LDS each)
 
 // Tables of the device decoder: 9- and 7-bit fast tables (4.7 + 1 KiB per wave: the decode is bound by the latency
@@ -155,16 +156,21 @@ __global__ __launch_bounds__(256) void inf_search_kernel(const uint8_t *__restri
   const unsigned long long stored_start = found;
   if (stored_start != NONE && stored_start < hi) hi = stored_start;   // a dynamic header counts only below it
   __syncthreads();
-  for (uint64_t base = lo; base < hi; base += 256 * kSearchPerThread) {
+  // A batch is kSearchSubBatches x 16384 bit positions: its candidates for the full check are collected first, sorted, and
+  // checked sixteen at a time in position order until one is a header — the lowest valid position is all that is wanted,
+  // a round of full checks lasts as long as its longest walk (~200 k cycles) whether it has two candidates or sixteen,
+  // and with a round per 16384 positions (7.5 candidates) a chunk paid ten rounds where four do.
+  for (uint64_t base = lo; base < hi; base += 256ull * kSearchPerThread * kSearchSubBatches) {
     if (tid == 0) ncand = 0;
     __syncthreads();
-    {
+    for (uint32_t sub = 0; sub < kSearchSubBatches; ++sub) {
       // In two passes, because the test's second part is a loop of up to 19 steps that one position in nine gets to: run
       // position by position, some lane of the wave got there at nearly every position and the other 56 waited (13 % of
       // the lanes at work, and this scan was the kernel's time).  First every lane marks which of its 64 positions have
       // the header's fields in range — 16 at a time: they start at a byte boundary, and 16 bytes from there cover the
       // fields (padded data); then the lanes go through their marked positions together, one each per step.
-      const uint64_t first = base + (uint64_t)tid * kSearchPerThread;
+      const uint64_t first = base + (uint64_t)sub * 256u * kSearchPerThread + (uint64_t)tid * kSearchPerThread;
+      if (first >= hi) break;  // (the same for every thread of a wave but its last positions': they test p < hi below)
       constexpr uint32_t kGroups = kSearchPerThread / 16;
       uint64_t glo[kGroups], ghi[kGroups];  // 128 bits from each group's first position: all requested before the first is used
 #pragma unroll
@@ -214,6 +220,17 @@ __global__ __launch_bounds__(256) void inf_search_kernel(const uint8_t *__restri
     }
     // one candidate per thread: header and both code-length sets valid?  The lowest position that is wins.
     const uint32_t n = ncand < kMaxCand ? ncand : kMaxCand;
+    {  // in position order (they were collected in any): a candidate's place is the number of lower ones
+      unsigned long long mine = 0;
+      uint32_t place = 0;
+      if (tid < n) {
+        mine = cand[tid];
+        for (uint32_t j = 0; j < n; ++j) place += cand[j] < mine ? 1u : 0u;
+      }
+      __syncthreads();
+      if (tid < n) cand[place] = mine;
+      __syncthreads();
+    }
     if (stats != nullptr && tid == 0) {  // SPZ_AMD_LZ_TIMING: batches of 16384 bit positions, and the candidates in them
       atomicAdd(&stats[0], 1ull);
       atomicAdd(&stats[1], (unsigned long long)ncand);
@@ -222,11 +239,16 @@ __global__ __launch_bounds__(256) void inf_search_kernel(const uint8_t *__restri
     // walk over up to 316 code lengths, a wave lasts as long as its slowest lane, and sixteen in ONE wave with the other
     // three waiting at the barrier was where the kernel's time went (13 % of its lanes at work)
     const uint32_t slot = (tid & 63u) < kValidateSlots / 4u ? (tid >> 6) * (kValidateSlots / 4u) + (tid & 63u) : kValidateSlots;
-    for (uint32_t base = 0; base < n; base += kValidateSlots) {
-      if (slot < kValidateSlots && base + slot < n) {
+    for (uint32_t base2 = 0; base2 < n; base2 += kValidateSlots) {
+      if (slot < kValidateSlots && base2 + slot < n) {
         const SlidingBits sb = {d, in.nbits, in.nbytes};
-        if (hasValidDynamicHeader(sb, cand[base + slot], &s_work[slot])) atomicMin(&found, cand[base + slot]);
+        s_work[slot].walked = 0;
+        if (hasValidDynamicHeader(sb, cand[base2 + slot], &s_work[slot])) atomicMin(&found, cand[base2 + slot]);
+        if (stats) atomicAdd(&stats[5], (unsigned long long)s_work[slot].walked);
       }
+      __syncthreads();
+      if (found != NONE) break;  // every later candidate is at a higher position
+      if (stats != nullptr && tid == 0) atomicAdd(&stats[6], 1ull);
     }
     __syncthreads();
     if (stats) {
@@ -863,11 +885,12 @@ static int inflate_open_impl(const uint8_t *h_deflate, const uint8_t *d_deflate,
   starts[0] = 0;
   lap("search");
   if (timing) {
-    unsigned long long h[5] = {0, 0, 0, 0, 0};
+    unsigned long long h[7] = {0, 0, 0, 0, 0, 0, 0};
     SPZ_HIP_TRY(hipMemcpy(h, d_search_stats, sizeof(h), hipMemcpyDeviceToHost));
     std::fprintf(stderr, "[inflate] search: clock ticks per chunk: stored-block scan %.0f, header scan %.0f, full checks %.0f\n", (double)h[2] / (n_chunks - 1),
                  (double)h[3] / (n_chunks - 1), (double)h[4] / (n_chunks - 1));
-    std::fprintf(stderr, "[inflate] search: %llu batches of 16384 bit positions for %u chunks, %llu candidates for the full check (%.1f per batch)\n", h[0],
+    std::fprintf(stderr, "[inflate] search: %llu code-length symbols decoded by the full checks, %llu rounds of checks that found nothing\n", h[5], h[6]);
+    std::fprintf(stderr, "[inflate] search: %llu batches of 65536 bit positions for %u chunks, %llu candidates for the full check (%.1f per batch)\n", h[0],
                  n_chunks - 1, h[1], h[0] ? (double)h[1] / (double)h[0] : 0.0);
   }
   std::vector<ChunkJob> jobs;
