@@ -213,7 +213,7 @@ struct WindowRank {  // the tile's segment's slab from the window's first positi
 __global__ __launch_bounds__(1024) void lz_match_kernel(const uint8_t *__restrict__ d, const uint16_t *__restrict__ link,
                                                         const uint8_t *__restrict__ delta, const uint16_t *__restrict__ rank_slabs,
                                                         uint64_t n_pos, uint64_t size, uint2 *__restrict__ r,
-                                                        uint32_t first_tile,
+                                                        uint32_t first_tile, uint32_t refill,
                                                         unsigned long long *__restrict__ stats) {
   // one array, so that the order is this one: the bytes and the deltas within reach of a 16-bit instruction offset
   __shared__ uint4 s_all[(kMatchDataDwords * 4 + kMatchWindow + kMatchWindow * 2) / 16 + 1];
@@ -277,11 +277,10 @@ __global__ __launch_bounds__(1024) void lz_match_kernel(const uint8_t *__restric
   const uint32_t n_local = n_pos - t0 < kMatchTile ? (uint32_t)(n_pos - t0) : kMatchTile;  // (the caller launches no tile past n_pos)
   // Walks differ in length by two orders of magnitude (ten candidates on average for an .spz stream, two hundred for
   // the longest), so a wave that gave each lane one position and waited for the slowest had one lane in twelve at
-  // work.  Every lane is a walker of its own instead: one candidate per round; once kRefill lanes of the wave have
+  // work.  Every lane is a walker of its own instead: one candidate per round; once `refill` lanes of the wave (16; 8 … 32 measure the same, 4 is 8 % slower) have
   // finished theirs, they write their results and take the tile's next positions (in any order: a position's entries
   // depend on nothing but the input).  Results are written then and not when a walk ends: some walk ends in nearly
   // every round, and the wave would run the store's address arithmetic each time for the sake of three lanes.
-  constexpr uint32_t kRefill = 16;
   const uint32_t lane = tid & 63u;
   const unsigned long long below_me = (1ull << lane) - 1ull;
   MatchWalk<int32_t> walk;
@@ -314,7 +313,7 @@ __global__ __launch_bounds__(1024) void lz_match_kernel(const uint8_t *__restric
     dry = first + n_idle >= n_local;  // the tile's positions are all given out: the walks are run to their ends
     // ---- one candidate per lane and round, until enough lanes are idle again (a loop of its own: the walks' state
     // stays where it is, which it did not when taking positions was a branch of the same loop)
-    const uint32_t enough = dry ? 64u : kRefill;
+    const uint32_t enough = dry ? 64u : refill;
     for (;;) {
       const unsigned long long walking = __ballot(active);
       if (64u - (uint32_t)__popcll(walking) >= enough) break;
@@ -992,6 +991,17 @@ struct LzSession {
   uint32_t *d_r32() const { return reinterpret_cast<uint32_t *>(block + o_r32); }
 };
 
+// Idle lanes of a wave of the match kernel at which they take new positions (SPZ_AMD_LZ_REFILL, 1 ... 64; measured in
+// round 3: see profiles/README.md)
+static uint32_t lz_refill_lanes() {
+  static const uint32_t v = []() {
+    const char *e = std::getenv("SPZ_AMD_LZ_REFILL");
+    const long x = e ? std::atol(e) : 16;
+    return (uint32_t)(x < 1 ? 1 : (x > 64 ? 64 : x));
+  }();
+  return v;
+}
+
 static uint64_t lz_tail_begin(uint64_t size) { return (size - 2ull * W) / W * W; }  // spz_deflate.cpp: compressWithHeadParser
 
 // A fed session's three streams and four events, kept per device between sessions: creating and destroying them per
@@ -1221,7 +1231,7 @@ static int lz_session_feed(LzSession *q, const uint8_t *d_src, const uint8_t *h_
       SPZ_HIP_TRY(hipStreamWaitEvent(mst, q->copy_done, 0));
     }
     hipLaunchKernelGGL(lz_match_kernel, dim3(tile_to - q->tile_done), dim3(kMatchThreads), 0, mst, q->d_data(), q->d_link(), q->d_delta(), q->d_rank(), q->n_pos,
-                       q->size, reinterpret_cast<uint2 *>(q->d_r128()), q->tile_done,
+                       q->size, reinterpret_cast<uint2 *>(q->d_r128()), q->tile_done, lz_refill_lanes(),
                        std::getenv("SPZ_AMD_LZ_WALK_STATS") ? reinterpret_cast<unsigned long long *>(q->block + q->o_stats) : nullptr);
     SPZ_HIP_TRY(hipGetLastError());
     q->tile_done = tile_to;
